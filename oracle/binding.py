@@ -1,0 +1,190 @@
+"""ctypes bindings for the CPU oracle.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module; nothing under simplefe_amd/ does (tests/test_layout.py checks that).
+
+Two libraries:
+  liboracle.so       -- oracle/sfe_oracle.c, the C restatement (classes Blkconv,
+                        Resample, Decimate below)
+  _ref/libsferef.so  -- the unmodified reference resample/decimate classes compiled from
+                        /root/reference in the authoring container (RefResample,
+                        RefDecimate); present on the GPU box only as the prebuilt .so
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+
+
+def build(ref=True):
+    """(Re)build liboracle.so and, when /root/reference is present, _ref/libsferef.so."""
+    subprocess.check_call(["make", "-s", "-C", HERE, "all" if ref else os.path.join(HERE, "liboracle.so")])
+
+
+def _load(path):
+    if not os.path.exists(path):
+        return None
+    return C.CDLL(path)
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        p = os.path.join(HERE, "liboracle.so")
+        if not os.path.exists(p):
+            build(ref=os.path.isdir("/root/reference"))
+        L = C.CDLL(p)
+        L.orc_blkconv_create.restype = C.c_void_p
+        L.orc_blkconv_create.argtypes = [_f32p, C.c_int, C.c_int]
+        L.orc_blkconv_blksize.argtypes = [C.c_void_p]
+        L.orc_blkconv_buf.restype = C.POINTER(C.c_float)
+        L.orc_blkconv_buf.argtypes = [C.c_void_p]
+        L.orc_blkconv_process.argtypes = [C.c_void_p]
+        L.orc_blkconv_destroy.argtypes = [C.c_void_p]
+        L.orc_blkconv_stream.argtypes = [C.c_void_p, _f32p, _f32p, C.c_long]
+        for k in ("resample", "decimate"):
+            getattr(L, f"orc_{k}_create").restype = C.c_void_p
+            getattr(L, f"orc_{k}_create").argtypes = [_f32p, C.c_int, C.c_int, C.c_int]
+            getattr(L, f"orc_{k}_process").argtypes = [C.c_void_p, _f32p, C.c_int, _f32p, C.c_int, C.c_float]
+            getattr(L, f"orc_{k}_destroy").argtypes = [C.c_void_p]
+        L.orc_rx_u8_to_cf32.argtypes = [_f32p, _u8p, C.c_int]
+        L.orc_rx_u8_to_f32.argtypes = [_f32p, _u8p, C.c_int]
+        L.orc_tx_f32_to_10bit.argtypes = [_u8p, _f32p, C.c_int]
+        _lib = L
+    return _lib
+
+
+def ref_lib():
+    """The compiled reference, or None when oracle/_ref/libsferef.so is absent."""
+    global _ref
+    if _ref is None:
+        p = os.path.join(HERE, "_ref", "libsferef.so")
+        if not os.path.exists(p) and os.path.isdir("/root/reference"):
+            build(ref=True)
+        R = _load(p)
+        if R is None:
+            return None
+        for k in ("resample", "decimate"):
+            getattr(R, f"ref_{k}_create").restype = C.c_void_p
+            getattr(R, f"ref_{k}_create").argtypes = [_f32p, C.c_int, C.c_int, C.c_int]
+            getattr(R, f"ref_{k}_process").argtypes = [C.c_void_p, _f32p, C.c_int, _f32p, C.c_int, C.c_float]
+            getattr(R, f"ref_{k}_destroy").argtypes = [C.c_void_p]
+        _ref = R
+    return _ref
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Blkconv:
+    """orc_blkconv_* : libdsp/blkconv.h:35-62"""
+
+    def __init__(self, taps, fft_len):
+        taps = _f32(taps)
+        self._L = lib()
+        self._h = self._L.orc_blkconv_create(taps, len(taps), int(fft_len))
+        self.blk = self._L.orc_blkconv_blksize(self._h)
+        p = self._L.orc_blkconv_buf(self._h)
+        self.buf = np.ctypeslib.as_array(p, shape=(fft_len + 2,))
+
+    def process(self):
+        self._L.orc_blkconv_process(self._h)
+
+    def stream(self, x):
+        x = _f32(x)
+        y = np.empty_like(x)
+        self._L.orc_blkconv_stream(self._h, x, y, len(x))
+        return y
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.orc_blkconv_destroy(self._h)
+            self._h = None
+
+
+class _Rs:
+    _prefix = None
+    _getlib = staticmethod(lib)
+
+    def __init__(self, taps, upsample, blksize):
+        taps = _f32(taps)
+        self._L = self._getlib()
+        if self._L is None:
+            raise RuntimeError("oracle/_ref/libsferef.so not built")
+        self._p = self._prefix
+        self._h = getattr(self._L, self._p + "_create")(taps, len(taps), int(upsample), int(blksize))
+        self.blksize = blksize
+
+    def process(self, x, out_len, rate):
+        x = _f32(x)
+        out = np.zeros(out_len, dtype=np.float32)
+        n = getattr(self._L, self._p + "_process")(self._h, x, len(x), out, int(out_len), float(rate))
+        return n, out
+
+    def stream(self, x, rate, chunk=None, out_len=None):
+        """Call process() chunk by chunk (as libdsp/test/test_decimate.py:22-25 does);
+        returns (concatenated outputs, list of per-call n_out)."""
+        x = _f32(x)
+        chunk = chunk or self.blksize
+        ys, ns = [], []
+        for off in range(0, len(x), chunk):
+            seg = x[off:off + chunk]
+            ol = out_len if out_len is not None else int(np.ceil(len(seg) / min(rate, 1e9))) + 2
+            n, o = self.process(seg, ol, rate)
+            ys.append(o[:n])
+            ns.append(n)
+        return (np.concatenate(ys) if ys else np.zeros(0, np.float32)), ns
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            getattr(self._L, self._p + "_destroy")(self._h)
+            self._h = None
+
+
+class Resample(_Rs):
+    _prefix = "orc_resample"
+
+
+class Decimate(_Rs):
+    _prefix = "orc_decimate"
+
+
+class RefResample(_Rs):
+    _prefix = "ref_resample"
+    _getlib = staticmethod(ref_lib)
+
+
+class RefDecimate(_Rs):
+    _prefix = "ref_decimate"
+    _getlib = staticmethod(ref_lib)
+
+
+def rx_u8_to_cf32(b):
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    out = np.empty(len(b), dtype=np.float32)
+    lib().orc_rx_u8_to_cf32(out, b, len(b))
+    return out
+
+
+def rx_u8_to_f32(b):
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    out = np.empty(len(b), dtype=np.float32)
+    lib().orc_rx_u8_to_f32(out, b, len(b))
+    return out
+
+
+def tx_f32_to_10bit(x):
+    x = _f32(x)
+    out = np.zeros(len(x) // 4 * 5, dtype=np.uint8)
+    n = lib().orc_tx_f32_to_10bit(out, x, len(x))
+    return out[:n]

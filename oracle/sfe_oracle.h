@@ -1,0 +1,64 @@
+/*
+ * sfe_oracle.h -- CPU oracle for the libdsp sample-stream hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C restatement of the algorithms in
+ * wnmusic/simpleFE's libdsp (blkconv / resample / decimate).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it, and only as
+ * the checker / the reported CPU baseline -- never as the thing shipped or measured
+ * as the product.  The product path (libsfe_dsp.so) does not link or call it.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - orc_resample_* / orc_decimate_* : pinned BIT-EXACT against the unmodified
+ *     reference sources compiled in place into oracle/_ref/ (tests/golden fixtures).
+ *   - orc_blkconv_* : the reference's FFT arithmetic lives in FFTW 3.3.5 (libfftw3f),
+ *     which is not in this image and not vendored as source, so blkconv.cxx is
+ *     unbuildable here.  The restatement is pinned by the reference's own
+ *     known-answer scenario (libdsp/test/test_blkconv.cxx:5-33, which prints but
+ *     asserts nothing) and by float64 direct linear convolution; at the FFTW
+ *     rounding boundary itself parity is UNPINNED.
+ */
+#ifndef SFE_ORACLE_H_
+#define SFE_ORACLE_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- blkconv : libdsp/blkconv.h:35-62, libdsp/blkconv.cxx:34-122 -------------- */
+typedef struct orc_blkconv orc_blkconv;
+orc_blkconv *orc_blkconv_create(const float *taps, int n_taps, int fft_len);
+int          orc_blkconv_blksize(const orc_blkconv *c);      /* blkconv.h:40-43 */
+float       *orc_blkconv_buf(orc_blkconv *c);                /* blkconv.h:44-47 */
+void         orc_blkconv_process(orc_blkconv *c);            /* blkconv.cxx:77-110 */
+void         orc_blkconv_destroy(orc_blkconv *c);
+/* convenience: run a whole real stream through process() block by block; the last
+ * partial block is zero-filled as a caller of the reference would.  y gets n floats. */
+void         orc_blkconv_stream(orc_blkconv *c, const float *x, float *y, long n);
+
+/* ---- resample : libdsp/resample.h:33-61, libdsp/resample.cxx:37-153 ----------- */
+typedef struct orc_resample orc_resample;
+orc_resample *orc_resample_create(const float *taps, int n_taps, int upsample, int blksize);
+int           orc_resample_process(orc_resample *r, const float *in, int n_in,
+                                   float *out, int out_len, float rate);
+void          orc_resample_destroy(orc_resample *r);
+
+/* ---- decimate : libdsp/decimate.h:33-63, libdsp/decimate.cxx:37-140 ----------- */
+typedef struct orc_decimate orc_decimate;
+orc_decimate *orc_decimate_create(const float *taps, int n_taps, int upsample, int blksize);
+int           orc_decimate_process(orc_decimate *d, const float *in, int n_in,
+                                   float *out, int out_len, float rate);
+void          orc_decimate_destroy(orc_decimate *d);
+
+/* ---- wire-format converters (gr-simplefe; "next" row N2) ---------------------- */
+/* u8 offset-binary I/Q -> cf32, gr-simplefe/lib/source_c_impl.cc:121-132 */
+int orc_rx_u8_to_cf32(float *dst, const unsigned char *src, int src_len);
+/* u8 -> f32 single channel, gr-simplefe/lib/source_f_impl.cc:120-129 */
+int orc_rx_u8_to_f32(float *dst, const unsigned char *src, int src_len);
+/* f32 -> 10-bit offset binary, 4 samples in 5 bytes,
+ * gr-simplefe/lib/sink_c_impl.cc:118-144 == examples/bpsk/bpsk.cxx:76-101 */
+int orc_tx_f32_to_10bit(unsigned char *dst, const float *src, int src_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

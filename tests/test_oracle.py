@@ -1,0 +1,165 @@
+"""The CPU oracle (oracle/sfe_oracle.c) against the golden fixtures and, when it has been
+built, against the compiled reference itself (oracle/_ref).  No GPU."""
+import numpy as np
+import pytest
+
+from simplefe_amd import synth
+
+RATES = ("1p77", "5o3", "8", "2p5")
+
+
+def _stream(cls, taps, U, B, x, rate, out_len):
+    o = cls(taps, U, B)
+    return o.stream(x, rate, chunk=B, out_len=out_len)
+
+
+# ---------------------------------------------------------------- resample / decimate
+@pytest.mark.parametrize("tag", RATES + ("0p77",))
+def test_resample_restatement_bit_exact_vs_reference_vector(orc, g4, tag):
+    """libdsp/test/test_resample.py:22-25 driver shape; outputs from the compiled reference."""
+    y, ns = _stream(orc.Resample, g4["taps"], int(g4["U"]), int(g4["B"]), g4["x"],
+                    float(g4[f"rate_{tag}"]), 4 * int(g4["B"]))
+    assert ns == g4[f"n_{tag}"].tolist()
+    assert np.array_equal(y, g4[f"y_{tag}"])          # bit-exact
+
+
+@pytest.mark.parametrize("tag", RATES)
+def test_decimate_restatement_bit_exact_vs_reference_vector(orc, g4, tag):
+    """libdsp/test/test_decimate.py:22-25; decimate == resample exactly (test_decimate.py:36)."""
+    y, ns = _stream(orc.Decimate, g4["taps"], int(g4["U"]), int(g4["B"]), g4["x"],
+                    float(g4[f"rate_{tag}"]), 4 * int(g4["B"]))
+    assert ns == g4[f"n_{tag}"].tolist()
+    assert np.array_equal(y, g4[f"y_{tag}"])
+
+
+@pytest.mark.parametrize("name", ["cfg3", "cfg4", "gen", "gen2"])
+@pytest.mark.parametrize("B", [4096, 1000, 1001])
+@pytest.mark.parametrize("which", ["Resample", "Decimate"])
+def test_baseline_shapes_bit_exact(orc, g5, name, B, which):
+    """BASELINE cfg3/cfg4 shapes, chunked at 4096/1000/1001 (1001 exercises the leftover
+    branch resample.cxx:141-145,119-123)."""
+    x = synth.synth_f32(int(g5["n"]), seed=int(g5["seed"]))
+    rate = float(g5[f"{name}_rate"])
+    ol = int(np.ceil(B / rate)) + 2
+    y, ns = _stream(getattr(orc, which), g5[f"{name}_taps"], int(g5[f"{name}_U"]), B, x, rate, ol)
+    key = f"{name}_y" if f"{name}_y" in g5.files else f"{name}_y_B{B}"
+    assert ns == g5[f"{name}_n_B{B}"].tolist()
+    assert np.array_equal(y, g5[key])
+
+
+def test_parameter_errors_return_zero(orc, g4, capfd):
+    """resample.cxx:91-98, decimate.cxx:75-87: message on stdout and return 0."""
+    taps = g4["taps"]
+    r = orc.Resample(taps, 4, 128)
+    n, _ = r.process(np.zeros(129, np.float32), 512, 1.5)     # n_in > blksize
+    assert n == 0
+    n, _ = r.process(np.zeros(128, np.float32), 512, 0.2)     # rate < 1/U
+    assert n == 0
+    n, _ = r.process(np.zeros(128, np.float32), 10, 1.5)      # out_len too small
+    assert n == 0
+    d = orc.Decimate(taps, 4, 128)
+    n, _ = d.process(np.zeros(128, np.float32), 512, 0.9)     # rate < 1
+    assert n == 0
+    n, _ = d.process(np.zeros(129, np.float32), 512, 2.0)
+    assert n == 0
+
+
+def test_against_live_reference_random(orc):
+    """When oracle/_ref is built: random taps/rates/chunks, restatement == reference."""
+    if orc.ref_lib() is None:
+        pytest.skip("oracle/_ref/libsferef.so not present")
+    rng = np.random.default_rng(3)
+    for trial in range(12):
+        U = int(rng.integers(1, 6))
+        nt = int(rng.integers(U, 60))
+        B = int(rng.integers(max(nt // U + 2, 8), 300))
+        taps = rng.standard_normal(nt).astype(np.float32)
+        x = rng.standard_normal(5 * B + 17).astype(np.float32)
+        rate = float(np.float32(rng.uniform(1.0, 6.0)))
+        ol = int(np.ceil(B / rate)) + 2
+        a, na = _stream(orc.RefResample, taps, U, B, x, rate, ol)
+        b, nb = _stream(orc.Resample, taps, U, B, x, rate, ol)
+        c, nc = _stream(orc.RefDecimate, taps, U, B, x, rate, ol)
+        d, nd = _stream(orc.Decimate, taps, U, B, x, rate, ol)
+        assert na == nb and nc == nd
+        assert np.array_equal(a, b) and np.array_equal(c, d)
+        assert np.array_equal(a, c)
+    # rate < 1 (resample only, >= 1/U)
+    taps = rng.standard_normal(31).astype(np.float32)
+    x = rng.standard_normal(1024).astype(np.float32)
+    a, na = _stream(orc.RefResample, taps, 4, 128, x, 0.41, 4 * 128)
+    b, nb = _stream(orc.Resample, taps, 4, 128, x, 0.41, 4 * 128)
+    assert na == nb and np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------------- blkconv
+def test_blkconv_known_answer(orc, g1):
+    """libdsp/test/test_blkconv.cxx:5-33: boxcar(5), fft 32 -> blksize 28; ones then zeros."""
+    c = orc.Blkconv(g1["taps"], int(g1["fft_len"]))
+    assert c.blk == int(g1["blksize"])
+    c.buf[: c.blk] = g1["in1"]
+    c.process()
+    assert np.allclose(c.buf[: c.blk], g1["out1"], atol=float(g1["print_tol"]))
+    c.buf[: c.blk] = g1["in2"]
+    c.process()
+    assert np.allclose(c.buf[: c.blk], g1["out2"], atol=float(g1["print_tol"]))
+
+
+def test_blkconv_pulse_shaping_vs_float64(orc, g1):
+    """bpsk.cxx:122-164 shape (111 taps, fft 2048) against float64 direct convolution."""
+    c = orc.Blkconv(g1["g2_taps"], int(g1["g2_fft_len"]))
+    y = c.stream(g1["g2_x"])
+    assert synth.rel_rms(y, g1["g2_y64"]) < 1e-6
+
+
+def test_blkconv_cfg1_vs_float64(orc):
+    """BASELINE cfg1: 63-tap real FIR, 2^20 float32 samples, fft 1024 (blk 962)."""
+    from scipy.signal import fftconvolve
+    taps = synth.taps_cfg1()
+    x = synth.synth_f32(1 << 20)
+    c = orc.Blkconv(taps, 1024)
+    assert c.blk == 962
+    y = c.stream(x)
+    ref = fftconvolve(x.astype(np.float64), taps.astype(np.float64))[: len(x)]
+    assert synth.rel_rms(y, ref) < 1e-6
+
+
+def test_blkconv_non_pow2_and_block_independence(orc):
+    """The block law must not show in the output: fft 96 (slow path) == fft 128 == direct."""
+    rng = np.random.default_rng(5)
+    taps = rng.standard_normal(17).astype(np.float32)
+    x = rng.standard_normal(1000).astype(np.float32)
+    ref = np.convolve(x.astype(np.float64), taps.astype(np.float64))[: len(x)]
+    for fl in (96, 128, 64):
+        y = orc.Blkconv(taps, fl).stream(x)
+        assert synth.rel_rms(y, ref) < 2e-6, fl
+
+
+# ---------------------------------------------------------------------- converters
+def test_rx_converters(orc):
+    """source_c_impl.cc:121-132 / source_f_impl.cc:120-129: (b-128)/127."""
+    b = np.arange(256, dtype=np.uint8)
+    f = orc.rx_u8_to_f32(b)
+    assert np.array_equal(f, ((b.astype(np.int32) - 128).astype(np.float32) * np.float32(1.0 / 127.0)))
+    c = orc.rx_u8_to_cf32(b)
+    assert np.array_equal(c, f)            # same arithmetic, interleaved
+
+
+def test_tx_converter_packing(orc):
+    """sink_f_impl.cc:117-143: ((short)(x*511)+512)&0x3FF, 4 samples -> 5 bytes."""
+    x = np.array([0.0, 1.0, -1.0, 0.5, -0.25, 0.999, -0.999, 0.001], dtype=np.float32)
+    out = orc.tx_f32_to_10bit(x)
+    assert len(out) == 10
+    u = ((x * np.float32(511)).astype(np.int16).astype(np.int32) + 512) & 0x3FF
+    for g in range(2):
+        v = u[4 * g: 4 * g + 4]
+        assert out[5 * g] == (v[0] >> 8) | ((v[1] >> 8) << 2) | ((v[2] >> 8) << 4) | ((v[3] >> 8) << 6)
+        assert out[5 * g + 1: 5 * g + 5].tolist() == [int(t & 0xFF) for t in v]
+
+
+def test_synth_is_exact_and_in_range():
+    x = synth.synth_f32(1 << 12)
+    assert x.dtype == np.float32 and x.min() >= -1.0 and x.max() < 1.0
+    assert np.array_equal(x * np.float32(2 ** 23), np.round(x * np.float32(2 ** 23)))
+    assert np.array_equal(synth.synth_f32(100, first=50), synth.synth_f32(150)[50:])
+    assert abs(float(x.mean())) < 0.05
