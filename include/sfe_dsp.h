@@ -1,0 +1,171 @@
+/*
+ * sfe_dsp.h -- C ABI of libsfe_dsp.so, the MI355X (gfx950) implementation of simpleFE's
+ * libdsp sample-stream hot path: blkconv (FIR block convolution), resample and decimate
+ * (polyphase interpolating resamplers).
+ *
+ * This is the drop-in boundary.  The reference has no FFI/plugin registry; what it exposes
+ * for this path is the C++ class surface of its static library `Libdsp`
+ * (libdsp/CMakeLists.txt:16-21; classes at libdsp/blkconv.h:35-62, libdsp/resample.h:33-61,
+ * libdsp/decimate.h:33-63) and its SWIG projection (libdsp/test/pydsp.i:16-22).  Every entry
+ * point below names the reference member it stands behind; include/blkconv.h, resample.h,
+ * decimate.h are header-only classes with the reference's names and signatures that forward
+ * here, so existing callers (examples/bpsk/bpsk.cxx:125-164, libdsp/test/test_blkconv.cxx)
+ * compile unchanged.  INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only: pointers, sizes, ints.  No HIP, torch or C++ types.
+ *   - every function returns an int status: 0 (SFE_OK) or a negative SFE_E* code;
+ *     sfe_dsp_last_error() gives the message of the calling thread's last failure.
+ *   - one handle == one stream of samples with its own filter state, exactly like one
+ *     reference object.  Handles are not thread-safe; callers serialise per handle, the rule
+ *     the reference has (examples/bpsk/bpsk.cxx:132-170).
+ *   - sfe_stream_t is a hipStream_t passed as void* (NULL = the default stream).  The
+ *     *_stream entry points are asynchronous on that stream; the host-pointer entry points
+ *     (class-compatible) return when the result is in host memory.
+ *   - complex samples are interleaved (re, im) float32 pairs -- gr_complex, as gr-simplefe
+ *     uses (gr-simplefe/lib/source_c_impl.cc:46,123-128).  libdsp itself is real-only
+ *     (libdsp/blkconv.h:38-48); complex data is the composition SURVEY.md 8(a) row A0 defines.
+ *   - there is NO CPU fallback: without a usable GPU the create calls fail with SFE_ENODEV.
+ */
+#ifndef SFE_DSP_H_
+#define SFE_DSP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFE_OK       0
+#define SFE_EINVAL  (-1)  /* bad argument */
+#define SFE_ENOMEM  (-2)  /* host or device allocation failed */
+#define SFE_EHIP    (-3)  /* a HIP runtime call failed (message has the HIP error string) */
+#define SFE_ENODEV  (-4)  /* no usable gfx950 device */
+#define SFE_ESTATE  (-5)  /* call not valid in the handle's current state */
+#define SFE_ERANGE  (-6)  /* output buffer too small */
+
+typedef void *sfe_stream_t;   /* hipStream_t */
+typedef void *sfe_fir_t;      /* opaque: one FIR stream (blkconv) */
+typedef void *sfe_rs_t;       /* opaque: one resample/decimate stream */
+typedef void *sfe_timer_t;    /* opaque: a pair of HIP events */
+
+/* ------------------------------------------------------------------ runtime / plumbing */
+const char *sfe_dsp_version(void);
+const char *sfe_dsp_last_error(void);
+int sfe_dsp_device_count(int *count);
+int sfe_dsp_set_device(int device);
+int sfe_dsp_sync(sfe_stream_t stream);                       /* hipStreamSynchronize */
+int sfe_dsp_malloc(void **dptr, size_t bytes);               /* device memory */
+int sfe_dsp_free(void *dptr);
+int sfe_dsp_host_alloc(void **hptr, size_t bytes);           /* pinned host memory */
+int sfe_dsp_host_free(void *hptr);
+int sfe_dsp_memcpy_h2d(void *dptr, const void *hptr, size_t bytes, sfe_stream_t stream);
+int sfe_dsp_memcpy_d2h(void *hptr, const void *dptr, size_t bytes, sfe_stream_t stream);
+int sfe_dsp_memset(void *dptr, int value, size_t bytes, sfe_stream_t stream);
+/* HIP-event timer on `stream` (bench.py's roofline leg): start/stop record events there */
+int sfe_dsp_timer_create(sfe_timer_t *t);
+int sfe_dsp_timer_start(sfe_timer_t t, sfe_stream_t stream);
+int sfe_dsp_timer_stop(sfe_timer_t t, sfe_stream_t stream);
+int sfe_dsp_timer_elapsed_ms(sfe_timer_t t, float *ms);      /* synchronises on stop */
+int sfe_dsp_timer_destroy(sfe_timer_t t);
+/* Synthetic stream generator: float i of the run is
+ * (int32(hash32(seed, channel, first + i)) >> 8) * 2^-23; simplefe_amd/synth.py is the
+ * host twin. */
+int sfe_dsp_synth_fill(void *dptr, uint64_t n_floats, uint32_t seed, uint32_t channel,
+                       uint64_t first, sfe_stream_t stream);
+
+/* ------------------------------------------------------------------------ FIR (blkconv)
+ * y[n] = sum_{k < n_taps} h[k] x[n-k], zero initial state, state carried across calls:
+ * the net effect of blkconv::process() over a stream (libdsp/blkconv.cxx:77-110), for
+ * real or complex data and real or complex taps. */
+#define SFE_FIR_ALGO_AUTO    0
+#define SFE_FIR_ALGO_DIRECT  1   /* time-domain, LDS-staged (short filters; evidence kernel) */
+#define SFE_FIR_ALGO_FFT     2   /* in-LDS 4096-point FFT overlap-save (the headline kernel) */
+
+/* Replaces blkconv::blkconv(float *taps, int n_taps, int fft_len)   libdsp/blkconv.cxx:34-75.
+ *   taps          n_taps floats, or n_taps (re,im) pairs when taps_complex; copied.
+ *   data_complex  0: real float32 samples (libdsp's own case); 1: interleaved cf32.
+ *   n_channels    independent streams sharing the taps, each with its own state (>= 1).
+ *   block_hint    the caller's fft_len: only fixes the size of the class-compatible host
+ *                 block, blk = block_hint + 1 - n_taps (blkconv.cxx:47); 0 = no host block.
+ *   device        HIP device ordinal. */
+int sfe_dsp_fir_create(const float *taps, int n_taps, int taps_complex, int data_complex,
+                       int n_channels, int block_hint, int device, sfe_fir_t *out);
+/* Replaces get_process_buf()/get_blksize()  libdsp/blkconv.h:40-47: a pinned host buffer
+ * owned by the handle, stable for its lifetime; the caller writes and reads [0, blk). */
+int sfe_dsp_fir_host_buffer(sfe_fir_t h, float **buf, int *blk);
+/* Replaces blkconv::process()  libdsp/blkconv.cxx:77-110: filters the blk samples in the
+ * host buffer in place (H2D, kernel, D2H, synchronous); overlap state is carried. */
+int sfe_dsp_fir_process_block(sfe_fir_t h);
+/* Bulk device-resident form of the same law (the measured path): n samples per channel,
+ * channel c at d_in + c*in_stride and d_out + c*out_stride (strides in samples; pass n for
+ * packed).  d_out must not alias d_in.  Asynchronous on `stream`.  Output is complex when
+ * data or taps are complex, else real. */
+int sfe_dsp_fir_process_stream(sfe_fir_t h, const void *d_in, void *d_out, size_t n,
+                               size_t in_stride, size_t out_stride, sfe_stream_t stream);
+int sfe_dsp_fir_set_algo(sfe_fir_t h, int algo);
+/* Zero the carried state (a fresh blkconv object: blkconv.cxx:52-55). */
+int sfe_dsp_fir_reset(sfe_fir_t h);
+/* Replaces blkconv::~blkconv()  libdsp/blkconv.cxx:113-122. */
+int sfe_dsp_fir_destroy(sfe_fir_t h);
+
+/* -------------------------------------------------------------- resample / decimate
+ * Polyphase interpolating resampler: outputs at upsampled-grid instants t (float32
+ * recurrence t += rate*upsample), pos = floor(t), mu = t - pos,
+ *   out = s(pos)*(1-mu) + mu*s(pos+1),  s(p) = sum_j taps[p%U + j*U] * x[p/U - j]
+ * (libdsp/resample.cxx:85-153, libdsp/decimate.cxx:69-140; the two classes give identical
+ * output, libdsp/test/test_decimate.py:36). */
+#define SFE_RS_RESAMPLE 0   /* accepts rate >= 1/upsample  (resample.cxx:91) */
+#define SFE_RS_DECIMATE 1   /* accepts rate >= 1           (decimate.cxx:75) */
+
+/* Replaces resample::resample / decimate::decimate (float *taps, int n_taps, int upsample,
+ * int blksize)   libdsp/resample.cxx:37-69, libdsp/decimate.cxx:37-59. */
+int sfe_dsp_rs_create(const float *taps, int n_taps, int upsample, int blksize,
+                      int data_complex, int n_channels, int device, int mode, sfe_rs_t *out);
+/* Replaces {resample,decimate}::process(float *in, int n_in, float *out, int out_len,
+ * float rate)   libdsp/resample.cxx:85-153, libdsp/decimate.cxx:69-129.  Host pointers,
+ * one channel, synchronous.  Same parameter checks, same messages on stdout and *n_out = 0
+ * (resample.cxx:91-98, decimate.cxx:75-87); same leftover / time-recurrence state. */
+int sfe_dsp_rs_process(sfe_rs_t h, const float *in, int n_in, float *out, int out_len,
+                       float rate, int *n_out);
+/* Bulk device-resident form: consumes n_in samples per channel, writes *n_out samples per
+ * channel (same count for every channel), equal to what the reference object produces when
+ * fed the same stream in chunks of `blksize`.  When fl(rate*upsample) is integer-valued the
+ * result does not depend on the chunking and one closed-form launch is used; otherwise the
+ * float32 time recurrence is replayed on the host, chunk by chunk, and uploaded.
+ * Fails with SFE_ERANGE if out_cap is too small (nothing is written).  Asynchronous. */
+int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t in_stride,
+                              void *d_out, size_t out_cap, size_t out_stride, float rate,
+                              size_t *n_out, sfe_stream_t stream);
+/* exact = 1: separate multiply and add in the reference's order (bit-exact with the CPU
+ * classes); exact = 0 (default for *_stream): fused multiply-add, same order. */
+int sfe_dsp_rs_set_exact(sfe_rs_t h, int exact);
+int sfe_dsp_rs_reset(sfe_rs_t h);
+int sfe_dsp_rs_destroy(sfe_rs_t h);
+
+/* Host-only: replay the time law of ONE process() call without touching the GPU
+ * (resample.cxx:89,119-150).  state = {pos, mu, leftover} in/out.  Writes up to cap
+ * entries: rel_pos[k] = upsampled position of output k relative to the chunk start (-1 for
+ * a leftover output), mu[k] its interpolation weight.  Returns the output count in *n_out. */
+typedef struct {
+    int32_t pos;
+    float   mu;
+    int32_t leftover;
+} sfe_rs_timestate;
+int sfe_dsp_rs_plan(sfe_rs_timestate *state, int upsample, int n_in, int out_len, float rate,
+                    int32_t *rel_pos, float *mu, int cap, int *n_out);
+
+/* ------------------------------------------- wire-format converters ("next" row N2)
+ * RX: u8 offset-binary -> float32 (b-128)*(1/127)
+ *     gr-simplefe/lib/source_c_impl.cc:121-132, source_f_impl.cc:120-129.
+ * TX: float32 -> 10-bit offset binary ((short)(x*511)+512)&0x3FF, 4 samples in 5 bytes
+ *     gr-simplefe/lib/sink_c_impl.cc:118-144, sink_f_impl.cc:117-143,
+ *     examples/bpsk/bpsk.cxx:76-101.   Device pointers, asynchronous. */
+int sfe_dsp_rx_u8_to_f32(const void *d_bytes, void *d_floats, size_t n_bytes, sfe_stream_t stream);
+int sfe_dsp_tx_f32_to_10bit(const void *d_floats, void *d_bytes, size_t n_floats, sfe_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFE_DSP_H_ */

@@ -1,0 +1,71 @@
+"""Build libsfe_dsp.so (the HIP extension) in-tree with hipcc for gfx950.
+
+    python -m simplefe_amd.build          # rebuild if sources are newer than the .so
+
+hipcc cross-compiles without a GPU; the built .so sits next to this file so that it travels
+with the repo snapshot to the GPU box and is the library the tests are seen to load.
+"""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libsfe_dsp.so")
+ARCH = "gfx950"
+# bit-exact restatements of the reference arithmetic: no implicit FMA contraction
+EXACT_SOURCES = ("polyphase.hip", "util.hip")
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _deps():
+    return sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(
+        os.path.join(os.path.dirname(HERE), "include", "*.h"))
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in _deps())
+
+
+def build_lib(force=False, verbose=False, extra=()):
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    odir = os.path.join(HERE, "build")
+    os.makedirs(odir, exist_ok=True)
+    procs = []
+    for src in sources():
+        obj = os.path.join(odir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if (not force and os.path.exists(obj) and
+                os.path.getmtime(obj) > max(os.path.getmtime(p) for p in [src] + glob.glob(os.path.join(CSRC, "*.h"))
+                                            + glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h")))):
+            continue
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
+               "-Wall", "-Wno-unused-function", *extra]
+        if os.path.basename(src) in EXACT_SOURCES:
+            cmd.append("-ffp-contract=off")
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_lib(force="--force" in sys.argv, verbose=True)
+    print(LIB)

@@ -1,0 +1,859 @@
+// api.hip -- the C ABI of libsfe_dsp.so (include/sfe_dsp.h): handles, host-side logic,
+// launches.  Host code only; kernels live in fir_fft.hip / polyphase.hip / util.hip.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "common.h"
+
+namespace sfe {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char *what)
+{
+    set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    return e == hipErrorOutOfMemory ? SFE_ENOMEM : (e == hipErrorNoDevice ? SFE_ENODEV : SFE_EHIP);
+}
+
+static int use_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device available (%s): libsfe_dsp has no CPU fallback",
+                  e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return SFE_ENODEV;
+    }
+    if (device < 0 || device >= n) {
+        set_error("device %d out of range (0..%d)", device, n - 1);
+        return SFE_EINVAL;
+    }
+    SFE_HIP(hipSetDevice(device));
+    return SFE_OK;
+}
+
+// ------------------------------------------------------------------------------ FIR
+struct Fir {
+    int n_taps = 0, taps_complex = 0, data_complex = 0, out_complex = 0, n_channels = 1;
+    int device = 0, algo = SFE_FIR_ALGO_AUTO;
+    int blk = 0, block_hint = 0;
+    int hl = 0;                 // carried history per channel, samples (multiple of 256)
+    bool fft_ok = false;
+    v2f *d_hs = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr;
+    float *d_taps = nullptr;    // real taps for the direct kernel
+    void *d_hist[2] = {nullptr, nullptr};
+    int cur = 0;
+    // class-compatible host block path
+    float *h_buf = nullptr;     // pinned, block_hint+2 floats (blkconv.cxx:44 sizes it so)
+    void *d_blk_in = nullptr, *d_blk_out = nullptr;
+    hipStream_t stream = nullptr;
+    size_t hist_bytes() const { return (size_t)n_channels * hl * (data_complex ? 8 : 4); }
+};
+
+static void fir_free(Fir *f)
+{
+    if (!f) return;
+    (void)hipSetDevice(f->device);
+    if (f->d_hs) (void)hipFree(f->d_hs);
+    if (f->d_tw1) (void)hipFree(f->d_tw1);
+    if (f->d_tw2) (void)hipFree(f->d_tw2);
+    if (f->d_taps) (void)hipFree(f->d_taps);
+    for (int i = 0; i < 2; i++)
+        if (f->d_hist[i]) (void)hipFree(f->d_hist[i]);
+    if (f->h_buf) (void)hipHostFree(f->h_buf);
+    if (f->d_blk_in) (void)hipFree(f->d_blk_in);
+    if (f->d_blk_out) (void)hipFree(f->d_blk_out);
+    if (f->stream) (void)hipStreamDestroy(f->stream);
+    delete f;
+}
+
+static int fir_build_tables(Fir *f, const float *taps)
+{
+    const int N = FFT_N;
+    // spectrum of the zero-padded taps in double precision, scaled by 1/N (blkconv.cxx:50
+    // folds the same 1/fft_len into its multiply), permuted to the kernel's F3 thread order:
+    // thread t (k1 = t&15, k2 = t>>4), register k0 -> bin k2 + 16 k1 + 256 k0.
+    std::vector<double> hr(N, 0.0), hi(N, 0.0);
+    std::vector<double> c(N), s(N);
+    for (int m = 0; m < N; m++) {
+        c[m] = cos(-2.0 * M_PI * m / N);
+        s[m] = sin(-2.0 * M_PI * m / N);
+    }
+    for (int k = 0; k < N; k++) {
+        double ar = 0.0, ai = 0.0;
+        for (int n = 0; n < f->n_taps; n++) {
+            const double tr = f->taps_complex ? taps[2 * n] : taps[n];
+            const double ti = f->taps_complex ? taps[2 * n + 1] : 0.0;
+            const int m = (int)(((long long)n * k) & (N - 1));
+            ar += tr * c[m] - ti * s[m];
+            ai += tr * s[m] + ti * c[m];
+        }
+        hr[k] = ar / N;
+        hi[k] = ai / N;
+    }
+    std::vector<v2f> hs(16 * 256), tw1(7 * 256), tw2(7 * 16);
+    for (int t = 0; t < 256; t++)
+        for (int k0 = 0; k0 < 16; k0++) {
+            const int bin = (t >> 4) + 16 * (t & 15) + 256 * k0;
+            hs[k0 * 256 + t] = (v2f){(float)hr[bin], (float)hi[bin]};
+        }
+    // twiddle bases: row k (1..3) = W^(e k), row k+3 = W^(4 e k); the kernel forms
+    // W^(e (4a+b)) as row[a+3] * row[b]
+    for (int k = 1; k < 4; k++)
+        for (int t = 0; t < 256; t++) {
+            const double a = -2.0 * M_PI * (double)(t * k) / 4096.0;
+            tw1[k * 256 + t] = (v2f){(float)cos(a), (float)sin(a)};
+            tw1[(k + 3) * 256 + t] = (v2f){(float)cos(4.0 * a), (float)sin(4.0 * a)};
+        }
+    for (int k = 1; k < 4; k++)
+        for (int n0 = 0; n0 < 16; n0++) {
+            const double a = -2.0 * M_PI * (double)(n0 * k) / 256.0;
+            tw2[k * 16 + n0] = (v2f){(float)cos(a), (float)sin(a)};
+            tw2[(k + 3) * 16 + n0] = (v2f){(float)cos(4.0 * a), (float)sin(4.0 * a)};
+        }
+    SFE_HIP(hipMalloc(&f->d_hs, hs.size() * sizeof(v2f)));
+    SFE_HIP(hipMalloc(&f->d_tw1, tw1.size() * sizeof(v2f)));
+    SFE_HIP(hipMalloc(&f->d_tw2, tw2.size() * sizeof(v2f)));
+    SFE_HIP(hipMemcpy(f->d_hs, hs.data(), hs.size() * sizeof(v2f), hipMemcpyHostToDevice));
+    SFE_HIP(hipMemcpy(f->d_tw1, tw1.data(), tw1.size() * sizeof(v2f), hipMemcpyHostToDevice));
+    SFE_HIP(hipMemcpy(f->d_tw2, tw2.data(), tw2.size() * sizeof(v2f), hipMemcpyHostToDevice));
+    return SFE_OK;
+}
+
+static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_stride,
+                   size_t out_stride, hipStream_t s)
+{
+    if (n == 0) return SFE_OK;
+    int algo = f->algo;
+    if (algo == SFE_FIR_ALGO_AUTO) algo = f->fft_ok ? SFE_FIR_ALGO_FFT : SFE_FIR_ALGO_DIRECT;
+    int rc;
+    if (algo == SFE_FIR_ALGO_FFT) {
+        if (!f->fft_ok) {
+            set_error("fir: %d taps exceed what one 4096-point transform can overlap", f->n_taps);
+            return SFE_EINVAL;
+        }
+        FirFftArgs a;
+        a.in = d_in;
+        a.out = d_out;
+        a.hist = f->d_hist[f->cur];
+        a.hs = f->d_hs;
+        a.tw1 = f->d_tw1;
+        a.tw2 = f->d_tw2;
+        a.n = (long long)n;
+        a.in_stride = (long long)in_stride;
+        a.out_stride = (long long)out_stride;
+        a.hl = f->hl;
+        a.advance = FFT_N - f->hl;
+        a.nblk = ((long long)n + a.advance - 1) / a.advance;
+        rc = launch_fir_fft(a, f->data_complex, f->out_complex, f->n_channels, s);
+    } else {
+        if (f->taps_complex) {
+            set_error("fir: the direct kernel takes real taps; complex taps need SFE_FIR_ALGO_FFT");
+            return SFE_EINVAL;
+        }
+        PolyArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = d_in;
+        a.out = d_out;
+        a.hist = f->d_hist[f->cur];
+        a.taps = f->d_taps;
+        a.n_in = (long long)n;
+        a.in_stride = (long long)in_stride;
+        a.out_stride = (long long)out_stride;
+        a.hl = f->hl;
+        a.U = 1;
+        a.plen = f->n_taps;
+        a.pos0 = 0;
+        a.step = 1;
+        a.n_out = (long long)n;
+        rc = launch_poly_int(a, f->data_complex, 0, 0, f->n_channels, s);
+    }
+    if (rc != SFE_OK) return rc;
+    rc = launch_history_update(d_in, (long long)n, (long long)in_stride, f->d_hist[f->cur],
+                               f->d_hist[f->cur ^ 1], f->hl, f->data_complex ? 2 : 1, f->n_channels, s);
+    if (rc != SFE_OK) return rc;
+    f->cur ^= 1;
+    return SFE_OK;
+}
+
+// ------------------------------------------------------------------ resample / decimate
+struct Rs {
+    int U = 1, n_taps = 0, plen = 0, blksize = 0, data_complex = 0, n_channels = 1;
+    int device = 0, mode = SFE_RS_RESAMPLE, exact_stream = 0;
+    int hl = 0;
+    float *d_taps = nullptr;               // [U][plen] phase-major
+    void *d_hist[2] = {nullptr, nullptr};
+    int cur = 0;
+    sfe_rs_timestate ts = {0, 0.0f, 0};
+    // class-compatible host path staging (one channel)
+    void *d_in = nullptr, *d_out = nullptr;
+    long long *d_pos = nullptr;
+    float *d_mu = nullptr;
+    size_t out_cap = 0, sched_cap = 0;
+    void *h_stage = nullptr;               // pinned: in/out staging
+    size_t h_stage_bytes = 0;
+    long long *h_pos = nullptr;            // pinned schedule staging
+    float *h_mu = nullptr;
+    hipStream_t stream = nullptr;
+    int esz() const { return data_complex ? 8 : 4; }
+};
+
+static void rs_free(Rs *r)
+{
+    if (!r) return;
+    (void)hipSetDevice(r->device);
+    if (r->d_taps) (void)hipFree(r->d_taps);
+    for (int i = 0; i < 2; i++)
+        if (r->d_hist[i]) (void)hipFree(r->d_hist[i]);
+    if (r->d_in) (void)hipFree(r->d_in);
+    if (r->d_out) (void)hipFree(r->d_out);
+    if (r->d_pos) (void)hipFree(r->d_pos);
+    if (r->d_mu) (void)hipFree(r->d_mu);
+    if (r->h_stage) (void)hipHostFree(r->h_stage);
+    if (r->h_pos) (void)hipHostFree(r->h_pos);
+    if (r->h_mu) (void)hipHostFree(r->h_mu);
+    if (r->stream) (void)hipStreamDestroy(r->stream);
+    delete r;
+}
+
+static int rs_ensure_sched(Rs *r, size_t n)
+{
+    if (n <= r->sched_cap) return SFE_OK;
+    size_t cap = r->sched_cap ? r->sched_cap : 1024;
+    while (cap < n) cap *= 2;
+    if (r->d_pos) (void)hipFree(r->d_pos);
+    if (r->d_mu) (void)hipFree(r->d_mu);
+    if (r->h_pos) (void)hipHostFree(r->h_pos);
+    if (r->h_mu) (void)hipHostFree(r->h_mu);
+    r->d_pos = nullptr; r->d_mu = nullptr; r->h_pos = nullptr; r->h_mu = nullptr;
+    r->sched_cap = 0;
+    SFE_HIP(hipMalloc(&r->d_pos, cap * sizeof(long long)));
+    SFE_HIP(hipMalloc(&r->d_mu, cap * sizeof(float)));
+    SFE_HIP(hipHostMalloc(&r->h_pos, cap * sizeof(long long)));
+    SFE_HIP(hipHostMalloc(&r->h_mu, cap * sizeof(float)));
+    r->sched_cap = cap;
+    return SFE_OK;
+}
+
+static int rs_ensure_out(Rs *r, size_t n)
+{
+    if (n <= r->out_cap) return SFE_OK;
+    size_t cap = r->out_cap ? r->out_cap : 1024;
+    while (cap < n) cap *= 2;
+    if (r->d_out) (void)hipFree(r->d_out);
+    r->d_out = nullptr;
+    r->out_cap = 0;
+    SFE_HIP(hipMalloc(&r->d_out, cap * r->esz()));
+    r->out_cap = cap;
+    return SFE_OK;
+}
+
+static int rs_ensure_stage(Rs *r, size_t bytes)
+{
+    if (bytes <= r->h_stage_bytes) return SFE_OK;
+    if (r->h_stage) (void)hipHostFree(r->h_stage);
+    r->h_stage = nullptr;
+    r->h_stage_bytes = 0;
+    SFE_HIP(hipHostMalloc(&r->h_stage, bytes));
+    r->h_stage_bytes = bytes;
+    return SFE_OK;
+}
+
+// The reference's time law for one process() call, positions only
+// (libdsp/resample.cxx:89,119-150 == libdsp/decimate.cxx:73,96-127).
+template <class Emit>
+static int time_law(sfe_rs_timestate *st, int U, int n_in, int out_len, float rate, Emit emit)
+{
+    int n_out = 0;
+    float t = (float)st->pos + st->mu;
+    const float step = rate * (float)U;
+    if (st->leftover) {
+        emit(-1, st->mu);
+        n_out++;
+        st->leftover = 0;
+        t += step;
+    }
+    for (;;) {
+        st->pos = (int)floorf(t);
+        st->mu = t - (float)st->pos;
+        const int pos1 = st->pos + 1;
+        const int n0 = st->pos / U, n1 = pos1 / U;     // C truncation, as the reference's ints
+        if (n0 >= n_in || n_out >= out_len) break;
+        if (n1 >= n_in) {
+            st->leftover = 1;
+            break;
+        }
+        emit(st->pos, st->mu);
+        n_out++;
+        t += step;
+    }
+    st->pos -= n_in * U;
+    return n_out;
+}
+
+}  // namespace sfe
+
+using namespace sfe;
+
+extern "C" {
+
+const char *sfe_dsp_version(void) { return "simplefe_amd 0.1 (gfx950)"; }
+const char *sfe_dsp_last_error(void) { return g_err; }
+
+int sfe_dsp_device_count(int *count)
+{
+    if (!count) return SFE_EINVAL;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *count = (e == hipSuccess) ? n : 0;
+    return SFE_OK;
+}
+
+int sfe_dsp_set_device(int device) { return use_device(device); }
+
+int sfe_dsp_sync(sfe_stream_t stream)
+{
+    SFE_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return SFE_OK;
+}
+
+int sfe_dsp_malloc(void **dptr, size_t bytes)
+{
+    if (!dptr) return SFE_EINVAL;
+    SFE_HIP(hipMalloc(dptr, bytes ? bytes : 16));
+    return SFE_OK;
+}
+int sfe_dsp_free(void *dptr)
+{
+    if (dptr) SFE_HIP(hipFree(dptr));
+    return SFE_OK;
+}
+int sfe_dsp_host_alloc(void **hptr, size_t bytes)
+{
+    if (!hptr) return SFE_EINVAL;
+    SFE_HIP(hipHostMalloc(hptr, bytes ? bytes : 16));
+    return SFE_OK;
+}
+int sfe_dsp_host_free(void *hptr)
+{
+    if (hptr) SFE_HIP(hipHostFree(hptr));
+    return SFE_OK;
+}
+int sfe_dsp_memcpy_h2d(void *dptr, const void *hptr, size_t bytes, sfe_stream_t stream)
+{
+    SFE_HIP(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return SFE_OK;
+}
+int sfe_dsp_memcpy_d2h(void *hptr, const void *dptr, size_t bytes, sfe_stream_t stream)
+{
+    SFE_HIP(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return SFE_OK;
+}
+int sfe_dsp_memset(void *dptr, int value, size_t bytes, sfe_stream_t stream)
+{
+    SFE_HIP(hipMemsetAsync(dptr, value, bytes, (hipStream_t)stream));
+    return SFE_OK;
+}
+
+struct Timer {
+    hipEvent_t a, b;
+};
+int sfe_dsp_timer_create(sfe_timer_t *t)
+{
+    if (!t) return SFE_EINVAL;
+    Timer *x = new (std::nothrow) Timer;
+    if (!x) return SFE_ENOMEM;
+    SFE_HIP(hipEventCreate(&x->a));
+    SFE_HIP(hipEventCreate(&x->b));
+    *t = x;
+    return SFE_OK;
+}
+int sfe_dsp_timer_start(sfe_timer_t t, sfe_stream_t stream)
+{
+    SFE_HIP(hipEventRecord(static_cast<Timer *>(t)->a, (hipStream_t)stream));
+    return SFE_OK;
+}
+int sfe_dsp_timer_stop(sfe_timer_t t, sfe_stream_t stream)
+{
+    SFE_HIP(hipEventRecord(static_cast<Timer *>(t)->b, (hipStream_t)stream));
+    return SFE_OK;
+}
+int sfe_dsp_timer_elapsed_ms(sfe_timer_t t, float *ms)
+{
+    Timer *x = static_cast<Timer *>(t);
+    SFE_HIP(hipEventSynchronize(x->b));
+    SFE_HIP(hipEventElapsedTime(ms, x->a, x->b));
+    return SFE_OK;
+}
+int sfe_dsp_timer_destroy(sfe_timer_t t)
+{
+    Timer *x = static_cast<Timer *>(t);
+    if (!x) return SFE_OK;
+    (void)hipEventDestroy(x->a);
+    (void)hipEventDestroy(x->b);
+    delete x;
+    return SFE_OK;
+}
+
+int sfe_dsp_synth_fill(void *dptr, uint64_t n_floats, uint32_t seed, uint32_t channel,
+                       uint64_t first, sfe_stream_t stream)
+{
+    if (!dptr && n_floats) return SFE_EINVAL;
+    return launch_synth_fill(static_cast<float *>(dptr), n_floats, seed, channel, first,
+                             (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------- FIR
+int sfe_dsp_fir_create(const float *taps, int n_taps, int taps_complex, int data_complex,
+                       int n_channels, int block_hint, int device, sfe_fir_t *out)
+{
+    if (!out) return SFE_EINVAL;
+    *out = nullptr;
+    if (!taps || n_taps < 1 || n_channels < 1) {
+        set_error("fir_create: need taps, n_taps >= 1, n_channels >= 1");
+        return SFE_EINVAL;
+    }
+    if (block_hint != 0 && block_hint + 1 - n_taps < 1) {
+        set_error("fir_create: fft_len %d leaves no block for %d taps (blkconv.cxx:47)", block_hint, n_taps);
+        return SFE_EINVAL;
+    }
+    int rc = use_device(device);
+    if (rc != SFE_OK) return rc;
+    Fir *f = new (std::nothrow) Fir;
+    if (!f) return SFE_ENOMEM;
+    f->n_taps = n_taps;
+    f->taps_complex = taps_complex ? 1 : 0;
+    f->data_complex = data_complex ? 1 : 0;
+    f->out_complex = (f->taps_complex || f->data_complex) ? 1 : 0;
+    f->n_channels = n_channels;
+    f->device = device;
+    f->block_hint = block_hint;
+    f->blk = block_hint ? block_hint + 1 - n_taps : 0;
+    const int ovl = n_taps - 1;
+    f->hl = ovl <= 0 ? 256 : ((ovl + 255) / 256) * 256;
+    f->fft_ok = f->hl < FFT_N;
+    auto fail = [&](int code) { fir_free(f); return code; };
+#define TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(hip_fail(e__, #call)); } while (0)
+    TRY(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+    if (f->fft_ok) {
+        rc = fir_build_tables(f, taps);
+        if (rc != SFE_OK) return fail(rc);
+    }
+    if (!f->taps_complex) {
+        TRY(hipMalloc(&f->d_taps, (size_t)n_taps * sizeof(float)));
+        TRY(hipMemcpy(f->d_taps, taps, (size_t)n_taps * sizeof(float), hipMemcpyHostToDevice));
+    }
+    for (int i = 0; i < 2; i++) {
+        TRY(hipMalloc(&f->d_hist[i], f->hist_bytes()));
+        TRY(hipMemset(f->d_hist[i], 0, f->hist_bytes()));
+    }
+    if (f->blk > 0) {
+        if (n_channels != 1) {
+            set_error("fir_create: the host block path (block_hint) is single-channel");
+            return fail(SFE_EINVAL);
+        }
+        const size_t in_e = f->data_complex ? 2 : 1, out_e = f->out_complex ? 2 : 1;
+        const size_t hb = ((size_t)block_hint + 2) * (out_e > in_e ? out_e : in_e) * sizeof(float);
+        TRY(hipHostMalloc((void **)&f->h_buf, hb));
+        memset(f->h_buf, 0, hb);
+        TRY(hipMalloc(&f->d_blk_in, (size_t)f->blk * in_e * sizeof(float)));
+        TRY(hipMalloc(&f->d_blk_out, (size_t)f->blk * out_e * sizeof(float)));
+    }
+    TRY(hipDeviceSynchronize());
+#undef TRY
+    *out = f;
+    return SFE_OK;
+}
+
+int sfe_dsp_fir_host_buffer(sfe_fir_t h, float **buf, int *blk)
+{
+    Fir *f = static_cast<Fir *>(h);
+    if (!f || !f->h_buf) {
+        set_error("fir_host_buffer: handle was created without block_hint");
+        return SFE_ESTATE;
+    }
+    if (buf) *buf = f->h_buf;
+    if (blk) *blk = f->blk;
+    return SFE_OK;
+}
+
+int sfe_dsp_fir_process_block(sfe_fir_t h)
+{
+    Fir *f = static_cast<Fir *>(h);
+    if (!f || !f->h_buf) {
+        set_error("fir_process_block: handle was created without block_hint");
+        return SFE_ESTATE;
+    }
+    SFE_HIP(hipSetDevice(f->device));
+    const size_t in_b = (size_t)f->blk * (f->data_complex ? 8 : 4);
+    const size_t out_b = (size_t)f->blk * (f->out_complex ? 8 : 4);
+    SFE_HIP(hipMemcpyAsync(f->d_blk_in, f->h_buf, in_b, hipMemcpyHostToDevice, f->stream));
+    int rc = fir_run(f, f->d_blk_in, f->d_blk_out, (size_t)f->blk, (size_t)f->blk, (size_t)f->blk, f->stream);
+    if (rc != SFE_OK) return rc;
+    SFE_HIP(hipMemcpyAsync(f->h_buf, f->d_blk_out, out_b, hipMemcpyDeviceToHost, f->stream));
+    SFE_HIP(hipStreamSynchronize(f->stream));
+    return SFE_OK;
+}
+
+int sfe_dsp_fir_process_stream(sfe_fir_t h, const void *d_in, void *d_out, size_t n,
+                               size_t in_stride, size_t out_stride, sfe_stream_t stream)
+{
+    Fir *f = static_cast<Fir *>(h);
+    if (!f || (n && (!d_in || !d_out))) {
+        set_error("fir_process_stream: null handle or buffer");
+        return SFE_EINVAL;
+    }
+    if (d_in == d_out) {
+        set_error("fir_process_stream: in-place operation is not supported");
+        return SFE_EINVAL;
+    }
+    if (f->n_channels > 1 && (in_stride < n || out_stride < n)) {
+        set_error("fir_process_stream: channel stride smaller than n");
+        return SFE_EINVAL;
+    }
+    if ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 7) {
+        set_error("fir_process_stream: buffers must be 8-byte aligned");
+        return SFE_EINVAL;
+    }
+    SFE_HIP(hipSetDevice(f->device));
+    return fir_run(f, d_in, d_out, n, in_stride, out_stride, (hipStream_t)stream);
+}
+
+int sfe_dsp_fir_set_algo(sfe_fir_t h, int algo)
+{
+    Fir *f = static_cast<Fir *>(h);
+    if (!f || algo < SFE_FIR_ALGO_AUTO || algo > SFE_FIR_ALGO_FFT) return SFE_EINVAL;
+    f->algo = algo;
+    return SFE_OK;
+}
+
+int sfe_dsp_fir_reset(sfe_fir_t h)
+{
+    Fir *f = static_cast<Fir *>(h);
+    if (!f) return SFE_EINVAL;
+    SFE_HIP(hipSetDevice(f->device));
+    SFE_HIP(hipDeviceSynchronize());
+    for (int i = 0; i < 2; i++) SFE_HIP(hipMemset(f->d_hist[i], 0, f->hist_bytes()));
+    return SFE_OK;
+}
+
+int sfe_dsp_fir_destroy(sfe_fir_t h)
+{
+    Fir *f = static_cast<Fir *>(h);
+    if (!f) return SFE_OK;
+    (void)hipSetDevice(f->device);
+    (void)hipDeviceSynchronize();
+    fir_free(f);
+    return SFE_OK;
+}
+
+// ------------------------------------------------------------------ resample / decimate
+int sfe_dsp_rs_plan(sfe_rs_timestate *state, int upsample, int n_in, int out_len, float rate,
+                    int32_t *rel_pos, float *mu, int cap, int *n_out)
+{
+    if (!state || upsample < 1 || n_in < 0 || !n_out) return SFE_EINVAL;
+    int overflow = 0, k = 0;
+    const int n = time_law(state, upsample, n_in, out_len, rate, [&](int p, float m) {
+        if (k < cap) {
+            if (rel_pos) rel_pos[k] = p;
+            if (mu) mu[k] = m;
+        } else overflow = 1;
+        k++;
+    });
+    *n_out = n;
+    return overflow ? SFE_ERANGE : SFE_OK;
+}
+
+int sfe_dsp_rs_create(const float *taps, int n_taps, int upsample, int blksize, int data_complex,
+                      int n_channels, int device, int mode, sfe_rs_t *out)
+{
+    if (!out) return SFE_EINVAL;
+    *out = nullptr;
+    if (!taps || n_taps < 1 || upsample < 1 || blksize < 1 || n_channels < 1 ||
+        (mode != SFE_RS_RESAMPLE && mode != SFE_RS_DECIMATE)) {
+        set_error("rs_create: bad arguments");
+        return SFE_EINVAL;
+    }
+    int rc = use_device(device);
+    if (rc != SFE_OK) return rc;
+    Rs *r = new (std::nothrow) Rs;
+    if (!r) return SFE_ENOMEM;
+    r->U = upsample;
+    r->n_taps = n_taps;
+    r->blksize = blksize;
+    r->data_complex = data_complex ? 1 : 0;
+    r->n_channels = n_channels;
+    r->device = device;
+    r->mode = mode;
+    // decimate appends a zero tap when n_taps is even (decimate.cxx:42-51); resample pads the
+    // last phase with zeros (resample.cxx:43,55-64).  Both are "ceil to a whole phase row".
+    const int eff = (mode == SFE_RS_DECIMATE && (n_taps % 2 == 0)) ? n_taps + 1 : n_taps;
+    r->plen = (eff + upsample - 1) / upsample;
+    r->hl = ((r->plen + 1 + 63) / 64) * 64;
+    auto fail = [&](int code) { rs_free(r); return code; };
+#define TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(hip_fail(e__, #call)); } while (0)
+    TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+    std::vector<float> pm((size_t)upsample * r->plen, 0.0f);
+    for (int j = 0; j < upsample; j++)
+        for (int i = 0; i < r->plen; i++) {
+            const int n = i * upsample + j;
+            pm[(size_t)j * r->plen + i] = n < n_taps ? taps[n] : 0.0f;
+        }
+    TRY(hipMalloc(&r->d_taps, pm.size() * sizeof(float)));
+    TRY(hipMemcpy(r->d_taps, pm.data(), pm.size() * sizeof(float), hipMemcpyHostToDevice));
+    const size_t hb = (size_t)n_channels * r->hl * r->esz();
+    for (int i = 0; i < 2; i++) {
+        TRY(hipMalloc(&r->d_hist[i], hb));
+        TRY(hipMemset(r->d_hist[i], 0, hb));
+    }
+    TRY(hipMalloc(&r->d_in, (size_t)blksize * r->esz()));
+    TRY(hipDeviceSynchronize());
+#undef TRY
+    *out = r;
+    return SFE_OK;
+}
+
+int sfe_dsp_rs_process(sfe_rs_t h, const float *in, int n_in, float *out, int out_len, float rate,
+                       int *n_out)
+{
+    Rs *r = static_cast<Rs *>(h);
+    if (!r || !n_out) return SFE_EINVAL;
+    *n_out = 0;
+    if (r->n_channels != 1) {
+        set_error("rs_process: the host-pointer call is single-channel");
+        return SFE_EINVAL;
+    }
+    // parameter checks, messages and "return 0 outputs" as the reference
+    if (r->mode == SFE_RS_RESAMPLE) {
+        if (n_in > r->blksize || rate < 1.0 / r->U) {                      // resample.cxx:91-94
+            printf("input parameter is wrong, rate <= 1/upsample, n_in <= blksize\n");
+            return SFE_OK;
+        }
+    } else {
+        if (rate < 1.0) {                                                  // decimate.cxx:75-78
+            printf("rate should be larger than 1.0\n");
+            return SFE_OK;
+        }
+        if (n_in > r->blksize) {                                           // decimate.cxx:79-82
+            printf("number of samples should be less than blksize\n");
+            return SFE_OK;
+        }
+    }
+    if (out_len < floorf(n_in * 1.0f / rate)) {                            // resample.cxx:95-98
+        printf("output buffer is not large enough");
+        return SFE_OK;
+    }
+    if (n_in < 0 || out_len < 0 || (n_in && !in) || (out_len && !out)) return SFE_EINVAL;
+    SFE_HIP(hipSetDevice(r->device));
+
+    int rc = rs_ensure_sched(r, (size_t)out_len + 1);
+    if (rc != SFE_OK) return rc;
+    rc = rs_ensure_out(r, (size_t)out_len + 1);
+    if (rc != SFE_OK) return rc;
+    const size_t in_b = (size_t)n_in * r->esz();
+    const size_t out_b = ((size_t)out_len + 1) * r->esz();
+    rc = rs_ensure_stage(r, in_b > out_b ? in_b : out_b);
+    if (rc != SFE_OK) return rc;
+
+    int k = 0;
+    const int n = time_law(&r->ts, r->U, n_in, out_len, rate, [&](int p, float m) {
+        r->h_pos[k] = p;
+        r->h_mu[k] = m;
+        k++;
+    });
+    if (n_in) {
+        memcpy(r->h_stage, in, in_b);
+        SFE_HIP(hipMemcpyAsync(r->d_in, r->h_stage, in_b, hipMemcpyHostToDevice, r->stream));
+    }
+    if (n > 0) {
+        SFE_HIP(hipMemcpyAsync(r->d_pos, r->h_pos, (size_t)n * sizeof(long long), hipMemcpyHostToDevice, r->stream));
+        SFE_HIP(hipMemcpyAsync(r->d_mu, r->h_mu, (size_t)n * sizeof(float), hipMemcpyHostToDevice, r->stream));
+        PolyArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = r->d_in;
+        a.out = r->d_out;
+        a.hist = r->d_hist[r->cur];
+        a.taps = r->d_taps;
+        a.n_in = n_in;
+        a.in_stride = n_in;
+        a.out_stride = n;
+        a.hl = r->hl;
+        a.U = r->U;
+        a.plen = r->plen;
+        a.n_out = n;
+        a.sched_pos = r->d_pos;
+        a.sched_mu = r->d_mu;
+        rc = launch_poly_sched(a, r->data_complex, 1, 1, r->stream);
+        if (rc != SFE_OK) return rc;
+    }
+    rc = launch_history_update(r->d_in, n_in, n_in, r->d_hist[r->cur], r->d_hist[r->cur ^ 1], r->hl,
+                               r->data_complex ? 2 : 1, 1, r->stream);
+    if (rc != SFE_OK) return rc;
+    r->cur ^= 1;
+    if (n > 0) SFE_HIP(hipMemcpyAsync(r->h_stage, r->d_out, (size_t)n * r->esz(), hipMemcpyDeviceToHost, r->stream));
+    SFE_HIP(hipStreamSynchronize(r->stream));
+    if (n > 0) memcpy(out, r->h_stage, (size_t)n * r->esz());
+    *n_out = n;
+    return SFE_OK;
+}
+
+int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t in_stride,
+                              void *d_out, size_t out_cap, size_t out_stride, float rate,
+                              size_t *n_out, sfe_stream_t stream)
+{
+    Rs *r = static_cast<Rs *>(h);
+    if (!r || !n_out) return SFE_EINVAL;
+    *n_out = 0;
+    if (r->mode == SFE_RS_RESAMPLE ? (rate < 1.0 / r->U) : (rate < 1.0)) {
+        set_error("rs_process_stream: rate %g not accepted by this mode", (double)rate);
+        return SFE_EINVAL;
+    }
+    if (n_in == 0) return SFE_OK;
+    if (!d_in || !d_out || d_in == d_out) {
+        set_error("rs_process_stream: null or aliased buffers");
+        return SFE_EINVAL;
+    }
+    SFE_HIP(hipSetDevice(r->device));
+    hipStream_t s = (hipStream_t)stream;
+    const float stepf = rate * (float)r->U;
+    const bool int_step = stepf >= 1.0f && stepf == floorf(stepf) && stepf < 1.0e6f && r->ts.mu == 0.0f &&
+                          ((double)r->blksize * r->U + stepf) < 16777216.0;
+    PolyArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = d_in;
+    a.out = d_out;
+    a.hist = r->d_hist[r->cur];
+    a.taps = r->d_taps;
+    a.n_in = (long long)n_in;
+    a.in_stride = (long long)in_stride;
+    a.out_stride = (long long)out_stride;
+    a.hl = r->hl;
+    a.U = r->U;
+    a.plen = r->plen;
+    int rc;
+    if (int_step) {
+        // closed form of the law: output k at pos0 + k*S, emitted while pos <= n_in*U - 2
+        // (pos == n_in*U - 1 is the reference's "leftover": it comes out first next call).
+        const long long S = (long long)stepf;
+        const long long pos0 = r->ts.leftover ? -1 : (long long)r->ts.pos;
+        const long long lim = (long long)n_in * r->U - 2;
+        const long long K = pos0 <= lim ? (lim - pos0) / S + 1 : 0;
+        if ((size_t)K > out_cap) {
+            set_error("rs_process_stream: need room for %lld outputs, got %zu", K, out_cap);
+            return SFE_ERANGE;
+        }
+        a.pos0 = pos0;
+        a.step = (int)S;
+        a.n_out = K;
+        rc = launch_poly_int(a, r->data_complex, 0, r->exact_stream, r->n_channels, s);
+        if (rc != SFE_OK) return rc;
+        const long long next = pos0 + K * S - (long long)n_in * r->U;
+        r->ts.leftover = next == -1 ? 1 : 0;
+        r->ts.pos = (int32_t)next;
+        r->ts.mu = 0.0f;
+        *n_out = (size_t)K;
+    } else {
+        // replay the float32 recurrence chunk by chunk, as the reference object would see it
+        sfe_rs_timestate st = r->ts;
+        std::vector<long long> pos;
+        std::vector<float> mu;
+        pos.reserve((size_t)((double)n_in / rate) + 16);
+        mu.reserve(pos.capacity());
+        for (size_t off = 0; off < n_in; off += (size_t)r->blksize) {
+            const int m = (int)((n_in - off) < (size_t)r->blksize ? (n_in - off) : (size_t)r->blksize);
+            const int cap = (int)ceilf((float)m / rate) + 2;
+            time_law(&st, r->U, m, cap, rate, [&](int p, float w) {
+                pos.push_back((long long)off * r->U + p);
+                mu.push_back(w);
+            });
+        }
+        const size_t K = pos.size();
+        if (K > out_cap) {
+            set_error("rs_process_stream: need room for %zu outputs, got %zu", K, out_cap);
+            return SFE_ERANGE;
+        }
+        rc = rs_ensure_sched(r, K + 1);
+        if (rc != SFE_OK) return rc;
+        // the staging buffers are reused across calls: wait for the previous upload's consumer
+        SFE_HIP(hipStreamSynchronize(s));
+        memcpy(r->h_pos, pos.data(), K * sizeof(long long));
+        memcpy(r->h_mu, mu.data(), K * sizeof(float));
+        SFE_HIP(hipMemcpyAsync(r->d_pos, r->h_pos, K * sizeof(long long), hipMemcpyHostToDevice, s));
+        SFE_HIP(hipMemcpyAsync(r->d_mu, r->h_mu, K * sizeof(float), hipMemcpyHostToDevice, s));
+        a.n_out = (long long)K;
+        a.sched_pos = r->d_pos;
+        a.sched_mu = r->d_mu;
+        rc = launch_poly_sched(a, r->data_complex, r->exact_stream, r->n_channels, s);
+        if (rc != SFE_OK) return rc;
+        r->ts = st;
+        *n_out = K;
+    }
+    rc = launch_history_update(d_in, (long long)n_in, (long long)in_stride, r->d_hist[r->cur],
+                               r->d_hist[r->cur ^ 1], r->hl, r->data_complex ? 2 : 1, r->n_channels, s);
+    if (rc != SFE_OK) return rc;
+    r->cur ^= 1;
+    return SFE_OK;
+}
+
+int sfe_dsp_rs_set_exact(sfe_rs_t h, int exact)
+{
+    Rs *r = static_cast<Rs *>(h);
+    if (!r) return SFE_EINVAL;
+    r->exact_stream = exact ? 1 : 0;
+    return SFE_OK;
+}
+
+int sfe_dsp_rs_reset(sfe_rs_t h)
+{
+    Rs *r = static_cast<Rs *>(h);
+    if (!r) return SFE_EINVAL;
+    SFE_HIP(hipSetDevice(r->device));
+    SFE_HIP(hipDeviceSynchronize());
+    const size_t hb = (size_t)r->n_channels * r->hl * r->esz();
+    for (int i = 0; i < 2; i++) SFE_HIP(hipMemset(r->d_hist[i], 0, hb));
+    r->ts.pos = 0;
+    r->ts.mu = 0.0f;
+    r->ts.leftover = 0;
+    return SFE_OK;
+}
+
+int sfe_dsp_rs_destroy(sfe_rs_t h)
+{
+    Rs *r = static_cast<Rs *>(h);
+    if (!r) return SFE_OK;
+    (void)hipSetDevice(r->device);
+    (void)hipDeviceSynchronize();
+    rs_free(r);
+    return SFE_OK;
+}
+
+// ------------------------------------------------------------------------ converters
+int sfe_dsp_rx_u8_to_f32(const void *d_bytes, void *d_floats, size_t n_bytes, sfe_stream_t stream)
+{
+    if (n_bytes && (!d_bytes || !d_floats)) return SFE_EINVAL;
+    return launch_rx_u8_to_f32(static_cast<const uint8_t *>(d_bytes), static_cast<float *>(d_floats),
+                               n_bytes, (hipStream_t)stream);
+}
+
+int sfe_dsp_tx_f32_to_10bit(const void *d_floats, void *d_bytes, size_t n_floats, sfe_stream_t stream)
+{
+    if (n_floats && (!d_bytes || !d_floats)) return SFE_EINVAL;
+    return launch_tx_f32_to_10bit(static_cast<const float *>(d_floats), static_cast<uint8_t *>(d_bytes),
+                                  n_floats, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+// common.h -- shared declarations of libsfe_dsp.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/sfe_dsp.h"
+
+typedef float v2f __attribute__((ext_vector_type(2)));   // one cf32 sample, packed-math friendly
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+namespace sfe {
+
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what);
+
+#define SFE_HIP(call)                                         \
+    do {                                                      \
+        hipError_t e__ = (call);                              \
+        if (e__ != hipSuccess) return ::sfe::hip_fail(e__, #call); \
+    } while (0)
+
+// ---- FIR -----------------------------------------------------------------------------
+constexpr int FFT_N = 4096;         // in-LDS transform length (16 x 16 x 16)
+constexpr int FFT_ROWS = 16;        // rows of 256 samples; thread t owns column t
+constexpr int LDS_K2_STRIDE = 272;  // padded 256 (== 16 mod 32: conflict-free both layouts)
+constexpr int LDS_K1_STRIDE = 17;
+
+struct FirFftArgs {
+    const void *in;       // channel 0 input
+    void       *out;
+    const void *hist;     // [n_channels][hl] samples preceding `in`
+    const v2f  *hs;       // [16][256] taps spectrum / 4096, per-thread order (see fir_fft.hip)
+    const v2f  *tw1;      // [7][256]   rows 1..3: W_4096^(t k), rows 4..6: W_4096^(4 t k)
+    const v2f  *tw2;      // [7][16]    rows 1..3: W_256^(n0 k),  rows 4..6: W_256^(4 n0 k)
+    long long   n;        // samples per channel in this call
+    long long   in_stride, out_stride;   // samples
+    int         hl;       // history rows * 256 = FFT_N - advance
+    int         advance;  // valid outputs per transform
+    long long   nblk;     // transforms per channel
+};
+int launch_fir_fft(const FirFftArgs &a, int in_complex, int out_complex, int n_channels,
+                   hipStream_t s);
+
+struct PolyArgs {
+    const void *in;        // channel 0 input (n_in samples)
+    void       *out;
+    const void *hist;      // [n_channels][hl] samples preceding `in`
+    const float *taps;     // [U][plen] phase-major real taps (or [2][U][plen] re,im planes)
+    long long   n_in, in_stride, out_stride;
+    int         hl;
+    int         U, plen;
+    // integer-step law: output k sits at upsampled position pos0 + k*step
+    long long   pos0;
+    int         step;
+    long long   n_out;
+    // scheduled law (general rate): per-output position / weight arrays
+    const long long *sched_pos;
+    const float     *sched_mu;
+};
+int launch_poly_int(const PolyArgs &a, int data_complex, int taps_complex, int exact,
+                    int n_channels, hipStream_t s);
+int launch_poly_sched(const PolyArgs &a, int data_complex, int exact, int n_channels,
+                      hipStream_t s);
+
+// new_hist[i] = virtual[n_in - hl + i], virtual = old_hist ++ in  (per channel)
+int launch_history_update(const void *in, long long n_in, long long in_stride,
+                          const void *old_hist, void *new_hist, int hl, int elem_floats,
+                          int n_channels, hipStream_t s);
+
+int launch_synth_fill(float *d, uint64_t n, uint32_t seed, uint32_t ch, uint64_t first,
+                      hipStream_t s);
+int launch_rx_u8_to_f32(const uint8_t *src, float *dst, size_t n, hipStream_t s);
+int launch_tx_f32_to_10bit(const float *src, uint8_t *dst, size_t n_floats, hipStream_t s);
+
+}  // namespace sfe

@@ -1,0 +1,229 @@
+// polyphase.hip -- time-domain kernels: the polyphase dot product behind resample/decimate
+// and the direct-form FIR (gfx950).
+//
+//   s(p) = sum_{j < plen} taps[(p mod U) + j*U] * x[floor(p/U) - j]
+// is libdsp/decimate.cxx:132-140 (get_sample) and, value for value, the m_out[phase][n] the
+// resample class precomputes (libdsp/resample.cxx:100-114).  Accumulation runs over ascending
+// j from 0.0f exactly as the reference does; EXACT kernels keep multiply and add separate
+// (the reference is compiled without FMA contraction), the others fuse them.
+//
+//   poly_int_kernel   : integer-valued step (mu == 0): out[k] = s(pos0 + k*step).
+//                       Covers decimate /8 (U=1, step 8), resample 5/3 (U=3, step 5) and the
+//                       direct FIR (U=1, step 1).  Input tile + taps staged in LDS.
+//   poly_sched_kernel : general rate: out[k] = s(P_k)*(1-mu_k) + mu_k*s(P_k+1) with (P_k, mu_k)
+//                       replayed on the host from the reference's float32 recurrence
+//                       (libdsp/resample.cxx:119-150).
+#include "common.h"
+
+// hipcc contracts a*b+c into an FMA by default (and HIP's __fmul_rn/__fadd_rn are plain * and +
+// defined in a header, so they contract too).  This file is compiled with -ffp-contract=off
+// (simplefe_amd/build.py: EXACT_SOURCES) so the EXACT kernels round every product, as the
+// reference built without FMA does; the fast kernels ask for the FMA explicitly.
+#pragma clang fp contract(off)
+
+namespace sfe {
+namespace {
+
+__device__ __forceinline__ long long floordiv(long long a, int b)
+{
+    long long q = a / b;
+    return (a % b != 0 && a < 0) ? q - 1 : q;
+}
+
+template <bool CPLX> struct Elem;
+template <> struct Elem<true> {
+    typedef v2f T;
+    static __device__ __forceinline__ T zero() { return (v2f){0.0f, 0.0f}; }
+};
+template <> struct Elem<false> {
+    typedef float T;
+    static __device__ __forceinline__ T zero() { return 0.0f; }
+};
+
+template <bool EXACT>
+__device__ __forceinline__ float mac(float acc, float t, float x)
+{
+    if constexpr (EXACT) { const float p = t * x; return acc + p; }
+    else return __builtin_fmaf(t, x, acc);
+}
+template <bool EXACT>
+__device__ __forceinline__ v2f mac(v2f acc, float t, v2f x)
+{
+    if constexpr (EXACT) { const v2f p = (v2f){t, t} * x; return acc + p; }
+    else return __builtin_elementwise_fma((v2f){t, t}, x, acc);
+}
+
+// virtual stream: history (hl samples) followed by this call's input; zero outside
+template <bool CPLX>
+__device__ __forceinline__ typename Elem<CPLX>::T vload(const typename Elem<CPLX>::T *in,
+                                                        const typename Elem<CPLX>::T *hist,
+                                                        long long i, long long n_in, int hl)
+{
+    if (i >= 0) return i < n_in ? in[i] : Elem<CPLX>::zero();
+    return (i >= -(long long)hl) ? hist[hl + i] : Elem<CPLX>::zero();
+}
+
+// ------------------------------------------------------------------ integer-step law
+// One workgroup = TILE consecutive outputs.  LDS: [tile_in_cap] samples + [U*plen] taps.
+template <bool CPLX, bool EXACT>
+__global__ __launch_bounds__(256) void poly_int_kernel(PolyArgs a, int tile_out, int tile_in_cap)
+{
+    typedef typename Elem<CPLX>::T T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T *xs = reinterpret_cast<T *>(smem);
+    float *ts = reinterpret_cast<float *>(smem + (size_t)tile_in_cap * sizeof(T));
+
+    const int ch = blockIdx.y;
+    const T *in = static_cast<const T *>(a.in) + (size_t)ch * a.in_stride;
+    const T *hist = static_cast<const T *>(a.hist) + (size_t)ch * a.hl;
+    T *out = static_cast<T *>(a.out) + (size_t)ch * a.out_stride;
+
+    const long long k0 = (long long)blockIdx.x * tile_out;
+    long long k1 = k0 + tile_out;
+    if (k1 > a.n_out) k1 = a.n_out;
+    const long long p_first = a.pos0 + k0 * a.step;
+    const long long p_last = a.pos0 + (k1 - 1) * a.step;
+    const long long n_lo = floordiv(p_first, a.U) - (a.plen - 1);
+    const long long n_hi = floordiv(p_last, a.U);
+    const int tile_len = (int)(n_hi - n_lo + 1);
+
+    for (int i = threadIdx.x; i < tile_len; i += 256) xs[i] = vload<CPLX>(in, hist, n_lo + i, a.n_in, a.hl);
+    for (int i = threadIdx.x; i < a.U * a.plen; i += 256) ts[i] = a.taps[i];
+    __syncthreads();
+
+    for (long long k = k0 + threadIdx.x; k < k1; k += 256) {
+        const long long p = a.pos0 + k * a.step;
+        const long long n = floordiv(p, a.U);
+        const int ph = (int)(p - n * a.U);
+        const float *tp = ts + ph * a.plen;
+        const T *xp = xs + (n - n_lo);
+        T acc = Elem<CPLX>::zero();
+        for (int j = 0; j < a.plen; j++) acc = mac<EXACT>(acc, tp[j], xp[-j]);
+        out[k] = acc;
+    }
+}
+
+// ------------------------------------------------------------------- scheduled law
+template <bool CPLX, bool EXACT>
+__device__ __forceinline__ typename Elem<CPLX>::T dot_at(const PolyArgs &a,
+                                                         const typename Elem<CPLX>::T *in,
+                                                         const typename Elem<CPLX>::T *hist,
+                                                         long long p)
+{
+    typedef typename Elem<CPLX>::T T;
+    const long long n = floordiv(p, a.U);
+    const int ph = (int)(p - n * a.U);
+    const float *tp = a.taps + ph * a.plen;
+    T acc = Elem<CPLX>::zero();
+    for (int j = 0; j < a.plen; j++) acc = mac<EXACT>(acc, tp[j], vload<CPLX>(in, hist, n - j, a.n_in, a.hl));
+    return acc;
+}
+
+template <bool CPLX, bool EXACT>
+__global__ __launch_bounds__(256) void poly_sched_kernel(PolyArgs a)
+{
+    typedef typename Elem<CPLX>::T T;
+    const int ch = blockIdx.y;
+    const T *in = static_cast<const T *>(a.in) + (size_t)ch * a.in_stride;
+    const T *hist = static_cast<const T *>(a.hist) + (size_t)ch * a.hl;
+    T *out = static_cast<T *>(a.out) + (size_t)ch * a.out_stride;
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= a.n_out) return;
+    const long long p = a.sched_pos[k];
+    const float mu = a.sched_mu[k];
+    const T s0 = dot_at<CPLX, EXACT>(a, in, hist, p);
+    const T s1 = dot_at<CPLX, EXACT>(a, in, hist, p + 1);
+    // out = s0*(1.0f-mu) + mu*s1   (libdsp/resample.cxx:147, decimate.cxx:124)
+    const float om = 1.0f - mu;
+    if constexpr (CPLX) {
+        if constexpr (EXACT)
+        {
+            const v2f l = s0 * (v2f){om, om}, r = (v2f){mu, mu} * s1;
+            out[k] = l + r;
+        }
+        else
+            out[k] = __builtin_elementwise_fma((v2f){mu, mu}, s1, s0 * (v2f){om, om});
+    } else {
+        if constexpr (EXACT) { const float l = s0 * om, r = mu * s1; out[k] = l + r; }
+        else out[k] = __builtin_fmaf(mu, s1, s0 * om);
+    }
+}
+
+// ---------------------------------------------------------------- history carry-over
+__global__ __launch_bounds__(256) void history_update_kernel(const float *in, long long n_in,
+                                                             long long in_stride,
+                                                             const float *old_hist, float *new_hist,
+                                                             int hl, int ef)
+{
+    const int ch = blockIdx.y;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // float index in [0, hl*ef)
+    if (i >= (long long)hl * ef) return;
+    const long long src = (n_in - hl) * ef + i;                      // float index in virtual stream
+    const float *inc = in + (size_t)ch * in_stride * ef;
+    const float *oh = old_hist + (size_t)ch * hl * ef;
+    new_hist[(size_t)ch * hl * ef + i] = src >= 0 ? inc[src] : oh[(long long)hl * ef + src];
+}
+
+}  // namespace
+
+int launch_poly_int(const PolyArgs &a, int data_complex, int /*taps_complex*/, int exact,
+                    int n_channels, hipStream_t s)
+{
+    if (a.n_out <= 0) return SFE_OK;
+    const int esz = data_complex ? 8 : 4;
+    // choose the output tile so that input tile + taps fit in 60 KiB of LDS
+    const long long budget = 60 * 1024 - (long long)a.U * a.plen * 4;
+    if (budget < (long long)(a.plen + 64) * esz) {
+        set_error("polyphase: %d taps in %d phases do not fit the LDS tile", a.U * a.plen, a.U);
+        return SFE_EINVAL;
+    }
+    long long tile_out = 2048;
+    auto need = [&](long long to) { return (to * a.step) / a.U + a.plen + 3; };
+    while (tile_out > 64 && need(tile_out) * esz > budget) tile_out >>= 1;
+    if (need(tile_out) * esz > budget) {
+        set_error("polyphase: step %d too large for the LDS tile", a.step);
+        return SFE_EINVAL;
+    }
+    const int tile_in_cap = (int)((need(tile_out) + 3) & ~3LL);
+    const size_t shmem = (size_t)tile_in_cap * esz + (size_t)a.U * a.plen * 4;
+    const long long nb = (a.n_out + tile_out - 1) / tile_out;
+    if (nb > 0x7fffffffLL) {
+        set_error("polyphase: too many tiles");
+        return SFE_EINVAL;
+    }
+    dim3 grid((unsigned)nb, (unsigned)n_channels), block(256);
+#define LAUNCH(C, E) hipLaunchKernelGGL((poly_int_kernel<C, E>), grid, block, shmem, s, a, (int)tile_out, tile_in_cap)
+    if (data_complex) { if (exact) LAUNCH(true, true); else LAUNCH(true, false); }
+    else { if (exact) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+    SFE_HIP(hipGetLastError());
+    return SFE_OK;
+}
+
+int launch_poly_sched(const PolyArgs &a, int data_complex, int exact, int n_channels, hipStream_t s)
+{
+    if (a.n_out <= 0) return SFE_OK;
+    const long long nb = (a.n_out + 255) / 256;
+    dim3 grid((unsigned)nb, (unsigned)n_channels), block(256);
+#define LAUNCH(C, E) hipLaunchKernelGGL((poly_sched_kernel<C, E>), grid, block, 0, s, a)
+    if (data_complex) { if (exact) LAUNCH(true, true); else LAUNCH(true, false); }
+    else { if (exact) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+    SFE_HIP(hipGetLastError());
+    return SFE_OK;
+}
+
+int launch_history_update(const void *in, long long n_in, long long in_stride, const void *old_hist,
+                          void *new_hist, int hl, int elem_floats, int n_channels, hipStream_t s)
+{
+    if (hl <= 0) return SFE_OK;
+    const long long nf = (long long)hl * elem_floats;
+    dim3 grid((unsigned)((nf + 255) / 256), (unsigned)n_channels), block(256);
+    hipLaunchKernelGGL(history_update_kernel, grid, block, 0, s, static_cast<const float *>(in), n_in,
+                       in_stride, static_cast<const float *>(old_hist), static_cast<float *>(new_hist),
+                       hl, elem_floats);
+    SFE_HIP(hipGetLastError());
+    return SFE_OK;
+}
+
+}  // namespace sfe

@@ -1,0 +1,93 @@
+"""ctypes binding of libsfe_dsp.so -- the C ABI declared in include/sfe_dsp.h.
+
+The library is the product: there is no Python or CPU fallback.  If the in-tree .so is
+missing or fails to load this module raises; if no GPU is usable the create calls fail
+with SFE_ENODEV (and SfeError is raised by the wrappers in api.py).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsfe_dsp.so")
+
+SFE_OK, SFE_EINVAL, SFE_ENOMEM, SFE_EHIP, SFE_ENODEV, SFE_ESTATE, SFE_ERANGE = 0, -1, -2, -3, -4, -5, -6
+FIR_ALGO_AUTO, FIR_ALGO_DIRECT, FIR_ALGO_FFT = 0, 1, 2
+RS_RESAMPLE, RS_DECIMATE = 0, 1
+
+
+class TimeState(C.Structure):
+    _fields_ = [("pos", C.c_int32), ("mu", C.c_float), ("leftover", C.c_int32)]
+
+
+vp, sz, i32, f32 = C.c_void_p, C.c_size_t, C.c_int, C.c_float
+fp = C.POINTER(C.c_float)
+
+# name -> (restype, argtypes): every symbol include/sfe_dsp.h declares
+SIGNATURES = {
+    "sfe_dsp_version": (C.c_char_p, []),
+    "sfe_dsp_last_error": (C.c_char_p, []),
+    "sfe_dsp_device_count": (i32, [C.POINTER(i32)]),
+    "sfe_dsp_set_device": (i32, [i32]),
+    "sfe_dsp_sync": (i32, [vp]),
+    "sfe_dsp_malloc": (i32, [C.POINTER(vp), sz]),
+    "sfe_dsp_free": (i32, [vp]),
+    "sfe_dsp_host_alloc": (i32, [C.POINTER(vp), sz]),
+    "sfe_dsp_host_free": (i32, [vp]),
+    "sfe_dsp_memcpy_h2d": (i32, [vp, vp, sz, vp]),
+    "sfe_dsp_memcpy_d2h": (i32, [vp, vp, sz, vp]),
+    "sfe_dsp_memset": (i32, [vp, i32, sz, vp]),
+    "sfe_dsp_timer_create": (i32, [C.POINTER(vp)]),
+    "sfe_dsp_timer_start": (i32, [vp, vp]),
+    "sfe_dsp_timer_stop": (i32, [vp, vp]),
+    "sfe_dsp_timer_elapsed_ms": (i32, [vp, C.POINTER(f32)]),
+    "sfe_dsp_timer_destroy": (i32, [vp]),
+    "sfe_dsp_synth_fill": (i32, [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, vp]),
+    "sfe_dsp_fir_create": (i32, [vp, i32, i32, i32, i32, i32, i32, C.POINTER(vp)]),
+    "sfe_dsp_fir_host_buffer": (i32, [vp, C.POINTER(fp), C.POINTER(i32)]),
+    "sfe_dsp_fir_process_block": (i32, [vp]),
+    "sfe_dsp_fir_process_stream": (i32, [vp, vp, vp, sz, sz, sz, vp]),
+    "sfe_dsp_fir_set_algo": (i32, [vp, i32]),
+    "sfe_dsp_fir_reset": (i32, [vp]),
+    "sfe_dsp_fir_destroy": (i32, [vp]),
+    "sfe_dsp_rs_create": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, C.POINTER(vp)]),
+    "sfe_dsp_rs_process": (i32, [vp, vp, i32, vp, i32, f32, C.POINTER(i32)]),
+    "sfe_dsp_rs_process_stream": (i32, [vp, vp, sz, sz, vp, sz, sz, f32, C.POINTER(sz), vp]),
+    "sfe_dsp_rs_set_exact": (i32, [vp, i32]),
+    "sfe_dsp_rs_reset": (i32, [vp]),
+    "sfe_dsp_rs_destroy": (i32, [vp]),
+    "sfe_dsp_rs_plan": (i32, [C.POINTER(TimeState), i32, i32, i32, f32, vp, vp, i32, C.POINTER(i32)]),
+    "sfe_dsp_rx_u8_to_f32": (i32, [vp, vp, sz, vp]),
+    "sfe_dsp_tx_f32_to_10bit": (i32, [vp, vp, sz, vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the in-tree HIP extension.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m simplefe_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)          # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+class SfeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libsfe_dsp error {code}: {msg}")
+        self.code = code
+
+
+def check(rc):
+    if rc != SFE_OK:
+        raise SfeError(rc, load().sfe_dsp_last_error().decode(errors="replace"))
+    return rc
