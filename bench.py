@@ -74,7 +74,7 @@ def cpu_baseline_fir(taps, n_budget_s):
     orc.Blkconv(taps, 4096).stream(xi)
     dt = time.perf_counter() - t0
     reps = max(1, int(n_budget_s / max(dt, 1e-6)))
-    reps = min(reps, 256)
+    reps = min(reps, 1024)
     cr, ci = orc.Blkconv(taps, 4096), orc.Blkconv(taps, 4096)
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -101,7 +101,7 @@ def cpu_baseline_rs(which, taps, U, rate, n_budget_s):
     cls(taps, U, B).stream(xr, rate)
     cls(taps, U, B).stream(xi, rate)
     dt = time.perf_counter() - t0
-    reps = min(max(1, int(n_budget_s / max(dt, 1e-6))), 256)
+    reps = min(max(1, int(n_budget_s / max(dt, 1e-6))), 4096)
     a, b = cls(taps, U, B), cls(taps, U, B)
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -116,9 +116,8 @@ def cpu_baseline_rs(which, taps, U, rate, n_budget_s):
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from simplefe_amd import shard
+    rank, local_rank, world = shard.env_ranks()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
@@ -128,9 +127,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: libsfe_dsp has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    shard.init_process_group(dev)            # RCCL when WORLD_SIZE > 1
 
     from simplefe_amd import api, lib, synth
     L = lib.load()
@@ -144,11 +141,11 @@ def main():
     wl = args.workload
     if wl == "fir":
         log2n = args.log2n or 28
-        nch = 1 if world == 1 else 8
+        nch = 1 if world == 1 else 8         # N > 1: 8*N channels, block-partitioned over ranks
         taps = synth.taps_cfg2()
         workload = ("256-tap FIR (blkconv law), 2^%d cf32 samples per GPU, %d channel(s) x 2^%d, "
                     "device-resident in/out" % (log2n, nch, log2n - (nch.bit_length() - 1)))
-        key = "fir256_cf32_2p%d" % log2n
+        key = "fir256_cf32_2p%d%s" % (log2n, "_direct" if args.algo == "direct" else "")
     elif wl == "resample":
         log2n = args.log2n or 28
         nch = 1
@@ -170,7 +167,8 @@ def main():
     # ---- device-resident synthetic input (generated on the GPU; host twin: synth.py)
     x = torch.empty(nch * n * 2, dtype=torch.float32, device=dev)
     for c in range(nch):
-        api.check(L.sfe_dsp_synth_fill(x.data_ptr() + c * n * 8, 2 * n, synth.SEED, rank * nch + c, 0, stream))
+        gch = shard.channel_block(nch * world, world, rank)[0] + c      # global channel id = its seed
+        api.check(L.sfe_dsp_synth_fill(x.data_ptr() + c * n * 8, 2 * n, synth.SEED, gch, 0, stream))
     if wl == "fir":
         n_out = n
         y = torch.empty(nch * n * 2, dtype=torch.float32, device=dev)
@@ -231,10 +229,7 @@ def main():
         timers[k].stop(stream)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(elapsed, dev)
     ms_per_step = elapsed * 1e3 / args.steps
     kern_ms = float(np.mean([t.elapsed_ms() for t in timers]))
     value = world * n_gpu / (ms_per_step * 1e-3) / 1e6      # whole-job complex MS/s

@@ -1,0 +1,59 @@
+"""Channel sharding across the GPUs of one node.
+
+Channels are independent streams (one reference object each), so the path shards with no
+data-path exchange: rank r owns a contiguous block of channels and keeps its outputs resident.
+The only collectives are the control-plane ones below -- a MAX over ranks of the elapsed time
+and a SUM of per-rank checksums -- over RCCL ("nccl") on GPUs or gloo on CPU-only hosts.
+"""
+import os
+
+
+def channel_block(n_channels, world, rank):
+    """(first, count) of the contiguous channel block rank `rank` owns."""
+    base, extra = divmod(int(n_channels), int(world))
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
+def env_ranks():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_process_group(device=None):
+    """One process per GPU, rendezvous on 127.0.0.1; returns (rank, local_rank, world)."""
+    import torch.distributed as dist
+    rank, local_rank, world = env_ranks()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if device is not None and device.type == "cuda":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def max_over_ranks(value, device=None):
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(values, device=None):
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.tolist()]
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -1,0 +1,168 @@
+"""CPU-only tests: the C ABI library loads and exports what include/sfe_dsp.h declares, the
+host-side logic (time-law replay, drop-in headers, ring buffer, register DFT) is right, and the
+product tree never reaches into the oracle.  No compute call is made without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INC = os.path.join(ROOT, "include")
+
+
+@pytest.fixture(scope="module")
+def L():
+    from simplefe_amd import build, lib
+    build.build_lib()
+    return lib.load()
+
+
+def _declared():
+    hdr = open(os.path.join(INC, "sfe_dsp.h")).read()
+    return sorted(set(re.findall(r"\b(sfe_dsp_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol(L):
+    from simplefe_amd import lib
+    declared = _declared()
+    assert len(declared) >= 30
+    for s in declared:
+        assert hasattr(L, s), s
+    assert set(declared) == set(lib.SIGNATURES), "ctypes table and header disagree"
+    assert b"gfx950" in L.sfe_dsp_version()
+
+
+def test_header_cites_reference_interfaces():
+    hdr = open(os.path.join(INC, "sfe_dsp.h")).read()
+    for cite in ("libdsp/blkconv.cxx:34-75", "libdsp/blkconv.cxx:77-110", "libdsp/resample.cxx:85-153",
+                 "libdsp/decimate.cxx:69-129", "libdsp/blkconv.h:40-47"):
+        assert cite in hdr, cite
+
+
+def test_no_gpu_means_loud_failure_not_fallback(L):
+    """Without a GPU the create calls fail with SFE_ENODEV; nothing computes on the CPU."""
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present")
+    from simplefe_amd import api, lib
+    with pytest.raises(api.SfeError) as e:
+        api.Fir(np.ones(4, np.float32))
+    assert e.value.code == lib.SFE_ENODEV
+    with pytest.raises(api.SfeError):
+        api.Rs(np.ones(4, np.float32), 1, 64)
+
+
+def test_product_tree_never_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py may use oracle/ (as the checker)."""
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "simplefe_amd")):
+        if os.sep + "build" in base:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(base, f), errors="replace").read()
+                if re.search(r"oracle[./]|liboracle|sfe_oracle|libsferef", txt):
+                    bad.append(os.path.join(base, f))
+    for f in os.listdir(INC):
+        if re.search(r"liboracle|sfe_oracle|libsferef", open(os.path.join(INC, f)).read()):
+            bad.append(f)
+    assert not bad, bad
+    out = subprocess.run(["ldd", os.path.join(ROOT, "simplefe_amd", "libsfe_dsp.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "sferef" not in out
+
+
+# ------------------------------------------------------------------ time-law replay
+def _plan_stream(L, U, B, n_total, rate, out_len):
+    from simplefe_amd import api, lib
+    st = lib.TimeState(0, 0.0, 0)
+    ns, pos, mu = [], [], []
+    for off in range(0, n_total, B):
+        m = min(B, n_total - off)
+        p, w = api.rs_plan(st, U, m, out_len, rate)
+        ns.append(len(p))
+        pos.append(p.astype(np.int64) + off * U)
+        mu.append(w)
+    return ns, np.concatenate(pos), np.concatenate(mu)
+
+
+@pytest.mark.parametrize("tag", ["1p77", "5o3", "8", "2p5", "0p77"])
+def test_plan_counts_match_reference_vector(L, g4, tag):
+    """n_out per process() call as the compiled reference produced them (fixtures G4)."""
+    B, U = int(g4["B"]), int(g4["U"])
+    ns, pos, mu = _plan_stream(L, U, B, len(g4["x"]), float(g4[f"rate_{tag}"]), 4 * B)
+    assert ns == g4[f"n_{tag}"].tolist()
+    assert np.all(np.diff(pos) >= 1) and np.all((mu >= 0) & (mu < 1))
+
+
+@pytest.mark.parametrize("name", ["cfg3", "cfg4", "gen", "gen2"])
+@pytest.mark.parametrize("B", [4096, 1000, 1001])
+def test_plan_counts_match_baseline_shapes(L, g5, name, B):
+    rate = float(g5[f"{name}_rate"])
+    ns, pos, mu = _plan_stream(L, int(g5[f"{name}_U"]), B, int(g5["n"]), rate, int(np.ceil(B / rate)) + 2)
+    assert ns == g5[f"{name}_n_B{B}"].tolist()
+    step = np.float32(rate) * np.float32(int(g5[f"{name}_U"]))
+    if float(step) == np.floor(float(step)):
+        assert not mu.any()                      # integer-valued step: mu == 0 throughout
+        assert np.array_equal(pos, np.arange(len(pos)) * int(step))
+
+
+def test_plan_reproduces_outputs_with_float64_dots(L, g4, orc):
+    """(pos, mu) from the plan + an independent float64 polyphase dot == the reference output
+    to float32 rounding: the schedule itself is what the GPU kernel consumes."""
+    taps, x, U, B = g4["taps"].astype(np.float64), g4["x"].astype(np.float64), int(g4["U"]), int(g4["B"])
+    ns, pos, mu = _plan_stream(L, U, B, len(x), float(g4["rate_1p77"]), 4 * B)
+
+    def s(p):
+        n, ph = p // U, p % U
+        t = taps[ph::U]
+        idx = n - np.arange(len(t))
+        ok = (idx >= 0) & (idx < len(x))
+        return float(np.dot(t[ok], x[idx[ok]]))
+    y = np.array([s(p) * (1.0 - float(m)) + float(m) * s(p + 1) for p, m in zip(pos, mu)])
+    assert np.max(np.abs(y - g4["y_1p77"])) < 2e-6
+
+
+# ------------------------------------------------------------------ C++ host pieces
+def _cxx(args, **kw):
+    return subprocess.run(args, capture_output=True, text=True, **kw)
+
+
+def test_ring_buffer_reference_scenarios(tmp_path):
+    """gr-simplefe/lib/qa_simplefe.cc:103-166 restated on include/ringbuf.h."""
+    exe = str(tmp_path / "rb")
+    r = _cxx(["g++", "-O1", "-Wall", "-fsanitize=address,undefined", os.path.join(ROOT, "tests/host/test_ringbuf.cpp"), "-o", exe])
+    assert r.returncode == 0, r.stderr
+    r = _cxx([exe])
+    assert r.returncode == 0 and "ringbuf ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_register_dft16_host_check(tmp_path):
+    exe = str(tmp_path / "fft16")
+    r = _cxx(["/opt/rocm/bin/hipcc", "-O2", "-x", "hip", "--offload-arch=gfx950",
+              os.path.join(ROOT, "tests/host/test_fft16.cpp"), "-o", exe])
+    assert r.returncode == 0, r.stderr
+    r = _cxx([exe])
+    assert r.returncode == 0, r.stdout
+
+
+def test_dropin_headers_compile_and_link(L, tmp_path):
+    """A caller written against the reference's class surface builds against include/ and
+    links libsfe_dsp.so (run on the GPU by tests/test_gpu_dropin.py)."""
+    exe = str(tmp_path / "dropin")
+    libdir = os.path.join(ROOT, "simplefe_amd")
+    r = _cxx(["g++", "-O1", "-Wall", os.path.join(ROOT, "tests/host/test_dropin.cpp"), "-o", exe,
+              "-L" + libdir, "-lsfe_dsp", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
+              "-Wl,--allow-shlib-undefined"])
+    assert r.returncode == 0, r.stderr
+
+
+def test_reference_own_test_program_builds_against_dropin_header(L):
+    """libdsp/test/test_blkconv.cxx, unmodified, against include/blkconv.h (oracle/Makefile
+    `dropin`); only where /root/reference exists."""
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("reference tree absent")
+    r = _cxx(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "dropin"])
+    assert r.returncode == 0, r.stderr
+    assert os.path.exists(os.path.join(ROOT, "oracle/_ref/test_blkconv_dropin"))

@@ -1,0 +1,83 @@
+"""The N > 1 path on CPU: two gloo ranks, channel-block sharding, MAX/SUM control collectives.
+The per-channel "filter" here is the oracle (this is a test); on GPUs bench.py runs the same
+sharding logic with libsfe_dsp kernels and RCCL."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys, time
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch
+from simplefe_amd import shard, synth
+from oracle import binding as orc
+rank, local_rank, world = shard.init_process_group(torch.device("cpu"))
+NCH, N = 6, 4000
+first, count = shard.channel_block(NCH, world, rank)
+taps = synth.taps_cfg2()
+t0 = time.perf_counter()
+acc = [0.0, 0.0, 0.0]
+for c in range(first, first + count):
+    x = synth.synth_cf32(N, ch=c)
+    for part in (0, 1):
+        y = orc.Blkconv(taps, 1024).stream(np.ascontiguousarray(x[part::2])).astype(np.float64)
+        acc[0] += float(y.sum()); acc[1] += float((y * y).sum()); acc[2] += len(y)
+el = time.perf_counter() - t0 + 0.01 * rank
+shard.barrier()
+tot = shard.sum_over_ranks(acc)
+mx = shard.max_over_ranks(el)
+assert mx >= el
+if rank == 0:
+    print("RESULT", world, tot[0], tot[1], int(tot[2]), flush=True)
+import torch.distributed as dist
+dist.destroy_process_group()
+"""
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_channel_block_partition():
+    from simplefe_amd import shard
+    for nch in (1, 6, 8, 64, 65):
+        for world in (1, 2, 3, 4, 8):
+            blocks = [shard.channel_block(nch, world, r) for r in range(world)]
+            flat = [c for f, k in blocks for c in range(f, f + k)]
+            assert flat == list(range(nch))
+            assert max(k for _, k in blocks) - min(k for _, k in blocks) <= 1
+
+
+def test_two_rank_gloo_sharding_matches_single_process(tmp_path):
+    from oracle import binding as orc
+    from simplefe_amd import synth
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
+        capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    world, s1, s2, cnt = int(line[1]), float(line[2]), float(line[3]), int(line[4])
+    assert world == 2 and cnt == 6 * 2 * 4000
+    taps = synth.taps_cfg2()
+    e1 = e2 = 0.0
+    for c in range(6):
+        x = synth.synth_cf32(4000, ch=c)
+        for part in (0, 1):
+            y = orc.Blkconv(taps, 1024).stream(np.ascontiguousarray(x[part::2])).astype(np.float64)
+            e1 += float(y.sum())
+            e2 += float((y * y).sum())
+    assert abs(s1 - e1) <= 1e-9 * max(1.0, abs(e1)) and abs(s2 - e2) <= 1e-9 * e2
