@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of FIR kernel variants in ONE process on ONE device
+(cdna_hip_programming.md rule 24).  Usage: ab_fir.py "3n" "3p" "2n" "2p:3" ...   (variant[:wg_per_cu])"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from simplefe_amd import api, lib, synth  # noqa: E402
+
+variants = sys.argv[1:] or ["3n", "3p", "2n", "2p"]
+log2n = int(os.environ.get("LOG2N", "28"))
+rounds = int(os.environ.get("ROUNDS", "6"))
+n = 1 << log2n
+x = api.DeviceArray(2 * n)
+x.fill_synth(synth.SEED)
+y = api.DeviceArray(2 * n)
+f = api.Fir(synth.taps_cfg2(), data_complex=True, algo=lib.FIR_ALGO_FFT)
+t = api.Timer()
+res = {v: [] for v in variants}
+for r in range(rounds + 1):
+    for v in variants:
+        vv = v.split(":")
+        os.environ["SFE_FIR_VARIANT"] = vv[0]
+        if len(vv) > 1:
+            os.environ["SFE_FIR_WG_PER_CU"] = vv[1]
+        else:
+            os.environ.pop("SFE_FIR_WG_PER_CU", None)
+        t.start()
+        for _ in range(5):
+            f.process_stream(x, y, n)
+        t.stop()
+        ms = t.elapsed_ms() / 5
+        if r:
+            res[v].append(ms)
+for v in variants:
+    a = np.array(res[v])
+    print(f"{v:8s} median {np.median(a):.4f} ms  min {a.min():.4f}  max {a.max():.4f}  -> {16.0 * n / np.median(a) / 1e6:.0f} GB/s alg, "
+          f"{16.0 * n / np.median(a) / 1e6 / 80:.1f}% of 8 TB/s")

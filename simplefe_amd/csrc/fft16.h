@@ -1,34 +1,106 @@
 // fft16.h -- register-resident 16-point complex DFT (radix-4 x radix-4) on packed cf32.
-// Host+device so tests/host/test_fft16.cpp can check it against a naive DFT without a GPU.
+//
+// On the device every complex primitive is ONE or TWO VOP3P instructions: gfx950's
+// v_pk_{add,mul,fma}_f32 take per-lane operand swizzles (op_sel / op_sel_hi) and sign flips
+// (neg_lo / neg_hi), which is exactly what a complex multiply or a +-j rotation needs.  hipcc
+// does not find those forms from C (it adds v_xor / v_mov / an extra v_pk_add per primitive:
+// 3-4 instructions per complex multiply, 10 per radix-4 butterfly), so they are written as
+// inline asm; the host build (tests/host/test_fft16.cpp checks this header against a naive
+// DFT without a GPU) uses the plain C forms.
 #pragma once
 #include "common.h"
 
 namespace sfe {
 
-__host__ __device__ __forceinline__ v2f cmul(v2f a, v2f w)
+#if defined(__HIP_DEVICE_COMPILE__)
+// a * w
+__device__ __forceinline__ v2f cmul(v2f a, v2f w)
 {
-    // (a.x w.x - a.y w.y, a.y w.x + a.x w.y) as one packed mul + one packed fma
-    v2f t = a * (v2f){w.x, w.x};
-    return __builtin_elementwise_fma((v2f){a.y, a.x}, (v2f){-w.y, w.y}, t);
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));               // (ax wx, ay wx)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"        // (-ay wy, ax wy) + t
+        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
 }
-__host__ __device__ __forceinline__ v2f cmul_conj(v2f a, v2f w)
+// a * conj(w)
+__device__ __forceinline__ v2f cmul_conj(v2f a, v2f w)
 {
-    v2f t = a * (v2f){w.x, w.x};
-    return __builtin_elementwise_fma((v2f){a.y, a.x}, (v2f){w.y, -w.y}, t);
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"        // (ay wy, -ax wy) + t
+        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
 }
+// a - j b = (ax + by, ay - bx)
+__device__ __forceinline__ v2f add_mj(v2f a, v2f b)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + j b = (ax - by, ay + bx)
+__device__ __forceinline__ v2f add_pj(v2f a, v2f b)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// -j a = (ay, -ax)          j a = (-ay, ax)
+__device__ __forceinline__ v2f rot_mj(v2f a)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, 0, %1 op_sel:[0,1] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(a));
+    return r;
+}
+__device__ __forceinline__ v2f rot_pj(v2f a)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, 0, %1 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,1]" : "=v"(r) : "v"(a));
+    return r;
+}
+// s * a (real scale; only the low half of s is read), optionally followed by -j / +j
+__device__ __forceinline__ v2f scale(v2f a, v2f s)
+{
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(s));
+    return r;
+}
+__device__ __forceinline__ v2f scale_mj(v2f a, v2f s)     // s * (ay, -ax)
+{
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(s));
+    return r;
+}
+__device__ __forceinline__ v2f scale_pj(v2f a, v2f s)     // s * (-ay, ax)
+{
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0] neg_lo:[1,0]" : "=v"(r) : "v"(a), "v"(s));
+    return r;
+}
+#else
+__host__ __device__ __forceinline__ v2f cmul(v2f a, v2f w) { return (v2f){a.x * w.x - a.y * w.y, a.y * w.x + a.x * w.y}; }
+__host__ __device__ __forceinline__ v2f cmul_conj(v2f a, v2f w) { return (v2f){a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y}; }
+__host__ __device__ __forceinline__ v2f add_mj(v2f a, v2f b) { return (v2f){a.x + b.y, a.y - b.x}; }
+__host__ __device__ __forceinline__ v2f add_pj(v2f a, v2f b) { return (v2f){a.x - b.y, a.y + b.x}; }
+__host__ __device__ __forceinline__ v2f rot_mj(v2f a) { return (v2f){a.y, -a.x}; }
+__host__ __device__ __forceinline__ v2f rot_pj(v2f a) { return (v2f){-a.y, a.x}; }
+__host__ __device__ __forceinline__ v2f scale(v2f a, v2f s) { return (v2f){a.x * s.x, a.y * s.x}; }
+__host__ __device__ __forceinline__ v2f scale_mj(v2f a, v2f s) { return (v2f){a.y * s.x, -a.x * s.x}; }
+__host__ __device__ __forceinline__ v2f scale_pj(v2f a, v2f s) { return (v2f){-a.y * s.x, a.x * s.x}; }
+#endif
 
+// radix-4 butterfly, DIR = -1 forward (W4 = -j), +1 inverse: 8 packed adds
 template <int DIR>
 __host__ __device__ __forceinline__ void dft4(v2f &a0, v2f &a1, v2f &a2, v2f &a3)
 {
-    v2f s0 = a0 + a2, d0 = a0 - a2, s1 = a1 + a3, d1 = a1 - a3;
-    v2f r = DIR < 0 ? (v2f){d1.y, -d1.x} : (v2f){-d1.y, d1.x};   // -+ j * d1
+    const v2f s0 = a0 + a2, d0 = a0 - a2, s1 = a1 + a3, d1 = a1 - a3;
     a0 = s0 + s1;
     a2 = s0 - s1;
-    a1 = d0 + r;
-    a3 = d0 - r;
+    a1 = DIR < 0 ? add_mj(d0, d1) : add_pj(d0, d1);
+    a3 = DIR < 0 ? add_pj(d0, d1) : add_mj(d0, d1);
 }
 
-// multiply by W_16^(DIR*m), constants folded at compile time
+// multiply by W_16^(DIR*m), m in {0,1,2,3,4,6,9}: 0, 1 or 2 instructions
 template <int DIR, int M>
 __host__ __device__ __forceinline__ v2f tw16(v2f a)
 {
@@ -36,11 +108,11 @@ __host__ __device__ __forceinline__ v2f tw16(v2f a)
     constexpr float R = 0.70710678118654752440f;
     constexpr float sg = DIR < 0 ? -1.0f : 1.0f;     // sign of the imaginary part
     if constexpr (M == 0) return a;
-    else if constexpr (M == 4) return DIR < 0 ? (v2f){a.y, -a.x} : (v2f){-a.y, a.x};
-    else if constexpr (M == 2) return (v2f){R, R} * (DIR < 0 ? (v2f){a.x + a.y, a.y - a.x}
-                                                              : (v2f){a.x - a.y, a.y + a.x});
-    else if constexpr (M == 6) return (v2f){R, R} * (DIR < 0 ? (v2f){a.y - a.x, -a.x - a.y}
-                                                              : (v2f){-a.x - a.y, a.x - a.y});
+    else if constexpr (M == 4) return DIR < 0 ? rot_mj(a) : rot_pj(a);
+    else if constexpr (M == 2)   // R(1 -+ j) a = R (a -+ j a)
+        return scale(DIR < 0 ? add_mj(a, a) : add_pj(a, a), (v2f){R, R});
+    else if constexpr (M == 6)   // W^6 = -+j W^2
+        return DIR < 0 ? scale_mj(add_mj(a, a), (v2f){R, R}) : scale_pj(add_pj(a, a), (v2f){R, R});
     else if constexpr (M == 1) return cmul(a, (v2f){C1, sg * S1});
     else if constexpr (M == 3) return cmul(a, (v2f){S1, sg * C1});
     else /* M == 9 */ return cmul(a, (v2f){-C1, -sg * S1});
@@ -66,6 +138,28 @@ __host__ __device__ __forceinline__ void dft16(v2f (&v)[16])
     v[3 + 12] = tw16<DIR, 9>(v[3 + 12]);
 #pragma unroll
     for (int b = 0; b < 4; b++) dft4<DIR>(v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3]);
+}
+
+// The transposed schedule: takes input element n in v[P16(n)] (i.e. exactly what dft16 leaves
+// behind) and leaves result element k in v[k].  dft16 followed by dft16_rev therefore needs no
+// register shuffling in between -- used for the spectrum-multiply + first inverse stage.
+template <int DIR>
+__host__ __device__ __forceinline__ void dft16_rev(v2f (&v)[16])
+{
+#pragma unroll
+    for (int b = 0; b < 4; b++) dft4<DIR>(v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3]);
+    // v[c + 4b] *= W16^(b*c)
+    v[1 + 4] = tw16<DIR, 1>(v[1 + 4]);
+    v[1 + 8] = tw16<DIR, 2>(v[1 + 8]);
+    v[1 + 12] = tw16<DIR, 3>(v[1 + 12]);
+    v[2 + 4] = tw16<DIR, 2>(v[2 + 4]);
+    v[2 + 8] = tw16<DIR, 4>(v[2 + 8]);
+    v[2 + 12] = tw16<DIR, 6>(v[2 + 12]);
+    v[3 + 4] = tw16<DIR, 3>(v[3 + 4]);
+    v[3 + 8] = tw16<DIR, 6>(v[3 + 8]);
+    v[3 + 12] = tw16<DIR, 9>(v[3 + 12]);
+#pragma unroll
+    for (int c = 0; c < 4; c++) dft4<DIR>(v[c], v[c + 4], v[c + 8], v[c + 12]);
 }
 
 }  // namespace sfe

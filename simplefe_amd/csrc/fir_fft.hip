@@ -21,29 +21,36 @@
 // Twiddle bases live in registers for the life of the (persistent) workgroup, which walks
 // transforms blockIdx.x, +gridDim.x, ...; the taps' spectrum (32 KiB, L2-resident) is
 // re-read per transform.  Budget: <= 128 VGPRs and 34 KiB LDS -> 4 workgroups per CU.
+#include <stdlib.h>
+
 #include "common.h"
 #include "fft16.h"
 
 namespace sfe {
 namespace {
 
+// `p` is wave-uniform (an SGPR pair), `lane` the per-lane element offset: keeps the address
+// math scalar so each row costs one global_load with an SGPR base and a shared VGPR offset.
 template <bool IN_C>
-__device__ __forceinline__ v2f load_sample(const void *p, long long i)
+__device__ __forceinline__ v2f load_sample(const void *p, unsigned lane)
 {
-    if constexpr (IN_C) return reinterpret_cast<const v2f *>(p)[i];
-    else return (v2f){reinterpret_cast<const float *>(p)[i], 0.0f};
+    // nontemporal: the sample stream is read once (measured -4% on the access pattern alone)
+    if constexpr (IN_C) return __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p) + lane);
+    else return (v2f){__builtin_nontemporal_load(reinterpret_cast<const float *>(p) + lane), 0.0f};
 }
 
-template <bool IN_C, bool OUT_C>
-__global__ __launch_bounds__(256, 3) void fir_fft4096_kernel(FirFftArgs a)
+// WAVES = waves per SIMD the register allocator must fit (3 -> <=168 VGPRs, 2 -> <=256);
+// PREFETCH = request transform i+1's rows during transform i's inverse stages.
+template <bool IN_C, bool OUT_C, int WAVES, bool PREFETCH>
+__global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 {
     __shared__ v2f lds[FFT_ROWS * LDS_K2_STRIDE];
-    const int t = threadIdx.x;
+    const unsigned t = threadIdx.x;   // unsigned: lets loads/stores use SGPR base + 32-bit VGPR offset
     const int ch = blockIdx.y;
-    const int lo = t & 15, hi = t >> 4;
-    const int base_a = t;                                   // [k2][t]
-    const int base_b = hi * LDS_K2_STRIDE + lo;             // [k2=hi][.][lo]
-    const int base_c = hi * LDS_K2_STRIDE + lo * LDS_K1_STRIDE;  // [k2=hi][k1=lo][.]
+    const unsigned lo = t & 15, hi = t >> 4;
+    const unsigned base_a = t;                                   // [k2][t]
+    const unsigned base_b = hi * LDS_K2_STRIDE + lo;             // [k2=hi][.][lo]
+    const unsigned base_c = hi * LDS_K2_STRIDE + lo * LDS_K1_STRIDE;  // [k2=hi][k1=lo][.]
 
     const char *in_c = static_cast<const char *>(a.in) + (size_t)ch * a.in_stride * (IN_C ? 8 : 4);
     char *out_c = static_cast<char *>(a.out) + (size_t)ch * a.out_stride * (OUT_C ? 8 : 4);
@@ -60,30 +67,40 @@ __global__ __launch_bounds__(256, 3) void fir_fft4096_kernel(FirFftArgs a)
         p2[k] = a.tw2[k * 16 + lo];          // W_256^(lo k)
         q2[k] = a.tw2[(k + 3) * 16 + lo];    // W_256^(4 lo k)
     }
-    const v2f *hs_t = a.hs + t;
 
     const int row0 = a.hl >> 8;   // rows discarded by overlap-save
-    for (long long blk = blockIdx.x; blk < a.nblk; blk += gridDim.x) {
+
+    // Loads one transform's 16 rows (thread t: samples base + t + 256 r) into registers.
+    auto load_rows = [&](v2f (&x)[16], long long blk) {
         const long long base = blk * a.advance - a.hl;   // stream index of transform element 0
-        v2f v[16];
+        constexpr int ESZ = IN_C ? 8 : 4;
         if (base >= 0 && base + FFT_N <= a.n) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) v[r] = load_sample<IN_C>(in_c, base + t + 256 * r);
+            for (int r = 0; r < 16; r++) x[r] = load_sample<IN_C>(in_c + (base + 256 * r) * ESZ, t);
         } else {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const long long i = base + t + 256 * r;
-                if (i < 0) v[r] = load_sample<IN_C>(hist_c, a.hl + i);
-                else if (i < a.n) v[r] = load_sample<IN_C>(in_c, i);
-                else v[r] = (v2f){0.0f, 0.0f};
+                const long long row = base + 256 * r;          // uniform
+                if (row + (long long)t < 0) x[r] = load_sample<IN_C>(hist_c + (a.hl + row) * ESZ, t);
+                else if (row + (long long)t < a.n) x[r] = load_sample<IN_C>(in_c + row * ESZ, t);
+                else x[r] = (v2f){0.0f, 0.0f};
             }
         }
+    };
 
+    // Software pipeline: the rows of transform i+1 are requested after the spectrum stage of
+    // transform i (where register pressure peaks) and land while its two inverse stages and
+    // its stores run; F1 of the next iteration consumes them.
+    v2f nx[16];
+    if (PREFETCH && (long long)blockIdx.x < a.nblk) load_rows(nx, blockIdx.x);
+    for (long long blk = blockIdx.x; blk < a.nblk; blk += gridDim.x) {
+        v2f v[16];
+        if (!PREFETCH) load_rows(nx, blk);
         // ---- F1: over n2, twiddle W_4096^(t k2), scatter to [k2][t]
-        dft16<-1>(v);
+        dft16<-1>(nx);
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            v2f x = v[P16(k)];
+            v2f x = nx[P16(k)];
             if (k >> 2) x = cmul(x, q1[k >> 2]);
             if (k & 3) x = cmul(x, p1[k & 3]);
             lds[base_a + k * LDS_K2_STRIDE] = x;
@@ -105,20 +122,20 @@ __global__ __launch_bounds__(256, 3) void fir_fft4096_kernel(FirFftArgs a)
         // ---- F3: gather n0 for (k2=hi, k1=lo); spectrum multiply; first inverse stage
 #pragma unroll
         for (int r = 0; r < 16; r++) v[r] = lds[base_c + r];
-        v2f hs[16];   // this thread's 16 bins of H/N: streamed from L2 each transform
-#pragma unroll
-        for (int k = 0; k < 16; k++) hs[k] = hs_t[k * 256];
         dft16<-1>(v);
         {
-            v2f y[16];
+            // spectrum multiply in place (bin k sits in v[P16(k)]), then the first inverse stage
+            // with the transposed schedule, which consumes exactly that order: no shuffling.
+            // H/N for this thread's 16 bins is streamed from L2 each transform.
 #pragma unroll
-            for (int k = 0; k < 16; k++) y[k] = cmul(v[P16(k)], hs[k]);
-            dft16<+1>(y);
+            for (int k = 0; k < 16; k++) v[P16(k)] = cmul(v[P16(k)], (a.hs + k * 256)[t]);
+            dft16_rev<+1>(v);
             // I1: element n0 goes back to the cell this thread read n0 from (no barrier needed)
 #pragma unroll
-            for (int k = 0; k < 16; k++) lds[base_c + k] = y[P16(k)];
+            for (int k = 0; k < 16; k++) lds[base_c + k] = v[k];
         }
         __syncthreads();
+        if (PREFETCH && blk + gridDim.x < a.nblk) load_rows(nx, blk + gridDim.x);   // see above
         // ---- I2: gather k1 for (k2=hi, n0=lo)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -143,27 +160,87 @@ __global__ __launch_bounds__(256, 3) void fir_fft4096_kernel(FirFftArgs a)
         dft16<+1>(v);
         __syncthreads();   // LDS free for the next transform
 
-        const long long obase = blk * a.advance - a.hl + t;   // + 256*row
-        if (blk * a.advance + a.advance <= a.n) {
+        const long long obase = blk * a.advance - a.hl;   // uniform; + 256*row + t
+        constexpr int OSZ = OUT_C ? 8 : 4;
+        const bool whole = blk * a.advance + a.advance <= a.n;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                if (r >= row0) {
-                    const v2f y = v[P16(r)];
-                    if constexpr (OUT_C) reinterpret_cast<v2f *>(out_c)[obase + 256 * r] = y;
-                    else reinterpret_cast<float *>(out_c)[obase + 256 * r] = y.x;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const long long o = obase + 256 * r;
-                if (r >= row0 && o < a.n) {
-                    const v2f y = v[P16(r)];
-                    if constexpr (OUT_C) reinterpret_cast<v2f *>(out_c)[o] = y;
-                    else reinterpret_cast<float *>(out_c)[o] = y.x;
-                }
+        for (int r = 0; r < 16; r++) {
+            const long long orow = obase + 256 * r;          // uniform
+            if (r >= row0 && (whole || orow + (long long)t < a.n)) {
+                const v2f y = v[P16(r)];
+                char *rp = out_c + orow * OSZ;               // uniform row pointer
+                if constexpr (OUT_C) __builtin_nontemporal_store(y, reinterpret_cast<v2f *>(rp) + t);
+                else __builtin_nontemporal_store(y.x, reinterpret_cast<float *>(rp) + t);
             }
         }
+    }
+}
+
+
+// Diagnostic only (SFE_FIR_VARIANT=c): the kernel's global access pattern with no transform --
+// each workgroup loads its 16 rows and stores rows row0..15 unchanged.  Times the memory side
+// of the FIR kernel alone (results are NOT a filter output; never used by the product path).
+template <int WAVES>
+__global__ __launch_bounds__(256, WAVES) void fir_copy_pattern_kernel(FirFftArgs a)
+{
+    const unsigned t = threadIdx.x;
+    const char *in_c = static_cast<const char *>(a.in) + (size_t)blockIdx.y * a.in_stride * 8;
+    char *out_c = static_cast<char *>(a.out) + (size_t)blockIdx.y * a.out_stride * 8;
+    const int row0 = a.hl >> 8;
+    for (long long blk = blockIdx.x; blk < a.nblk; blk += gridDim.x) {
+        const long long base = blk * a.advance - a.hl;
+        if (base < 0 || base + FFT_N > a.n) continue;
+        v2f v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = load_sample<true>(in_c + (base + 256 * r) * 8, t);
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            if (r >= row0) reinterpret_cast<v2f *>(out_c + (base + 256 * r) * 8)[t] = v[r];
+    }
+}
+
+
+// Diagnostic only (SFE_FIR_VARIANT=d / e): same bytes as fir_copy_pattern_kernel moved with
+// 16-byte lanes (d) and with nontemporal 8-byte lanes (e).
+template <int WAVES>
+__global__ __launch_bounds__(256, WAVES) void fir_copy_pattern16_kernel(FirFftArgs a)
+{
+    const unsigned t = threadIdx.x;
+    const char *in_c = static_cast<const char *>(a.in) + (size_t)blockIdx.y * a.in_stride * 8;
+    char *out_c = static_cast<char *>(a.out) + (size_t)blockIdx.y * a.out_stride * 8;
+    const int row0 = a.hl >> 8;
+    const unsigned half = t >> 7, col2 = t & 127;
+    for (long long blk = blockIdx.x; blk < a.nblk; blk += gridDim.x) {
+        const long long base = blk * a.advance - a.hl;
+        if (base < 0 || base + FFT_N > a.n) continue;
+        v4f v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            v[j] = reinterpret_cast<const v4f *>(in_c + (base + 256 * (2 * j)) * 8)[col2 + 128 * half];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (2 * j + (int)half >= row0)
+                reinterpret_cast<v4f *>(out_c + (base + 256 * (2 * j)) * 8)[col2 + 128 * half] = v[j];
+    }
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(256, WAVES) void fir_copy_pattern_nt_kernel(FirFftArgs a)
+{
+    const unsigned t = threadIdx.x;
+    const char *in_c = static_cast<const char *>(a.in) + (size_t)blockIdx.y * a.in_stride * 8;
+    char *out_c = static_cast<char *>(a.out) + (size_t)blockIdx.y * a.out_stride * 8;
+    const int row0 = a.hl >> 8;
+    for (long long blk = blockIdx.x; blk < a.nblk; blk += gridDim.x) {
+        const long long base = blk * a.advance - a.hl;
+        if (base < 0 || base + FFT_N > a.n) continue;
+        v2f v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            v[r] = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(in_c + (base + 256 * r) * 8) + t);
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            if (r >= row0) __builtin_nontemporal_store(v[r], reinterpret_cast<v2f *>(out_c + (base + 256 * r) * 8) + t);
     }
 }
 
@@ -177,18 +254,44 @@ int launch_fir_fft(const FirFftArgs &a, int in_complex, int out_complex, int n_c
         set_error("fir_fft: bad overlap rows (hl=%d advance=%d)", a.hl, a.advance);
         return SFE_EINVAL;
     }
-    // persistent workgroups: enough to fill 256 CUs x 4 resident, shared over channels
+    // variant: SFE_FIR_VARIANT = "<waves><p|n>" e.g. "3n" (3 waves/SIMD, no prefetch), "2p"
+    int variant;
+    {
+        const char *e = getenv("SFE_FIR_VARIANT");    // re-read per launch: cheap, allows A/B in one process
+        int w = 3, pf = 1;             // default: 3 waves/SIMD (162 VGPRs) + prefetch
+        if (e && e[0] >= '2' && e[0] <= '4') { w = e[0] - '0'; pf = (e[1] != 'n'); }
+        variant = w * 2 + pf;
+    }
+    int wg_per_cu = 2 * (variant >> 1);   // 2 x resident: finer tail balance (measured +2%)
+    const char *ev = getenv("SFE_FIR_VARIANT");
+    const bool copy_only = ev && (ev[0] == 'c' || ev[0] == 'd' || ev[0] == 'e');
+    if (const char *e = getenv("SFE_FIR_WG_PER_CU")) wg_per_cu = atoi(e) > 0 ? atoi(e) : wg_per_cu;
+    // persistent workgroups: fill the 256 CUs at the resident count, shared over channels
     long long gx = a.nblk;
-    const long long cap = (256LL * 8 + n_channels - 1) / n_channels;
+    const long long cap = (256LL * wg_per_cu + n_channels - 1) / n_channels;
     if (gx > cap) gx = cap < 1 ? 1 : cap;
     dim3 grid((unsigned)gx, (unsigned)n_channels), block(256);
-    if (in_complex && out_complex) hipLaunchKernelGGL((fir_fft4096_kernel<true, true>), grid, block, 0, s, a);
-    else if (!in_complex && out_complex) hipLaunchKernelGGL((fir_fft4096_kernel<false, true>), grid, block, 0, s, a);
-    else if (!in_complex && !out_complex) hipLaunchKernelGGL((fir_fft4096_kernel<false, false>), grid, block, 0, s, a);
+#define SFE_LAUNCH(IC, OC)                                                                          \
+    switch (variant) {                                                                              \
+    case 4: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 2, false>), grid, block, 0, s, a); break; \
+    case 5: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 2, true>), grid, block, 0, s, a); break;  \
+    case 6: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, false>), grid, block, 0, s, a); break; \
+    case 8: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 4, false>), grid, block, 0, s, a); break; \
+    case 9: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 4, true>), grid, block, 0, s, a); break;  \
+    default: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, true>), grid, block, 0, s, a); break; \
+    }
+    if (copy_only && in_complex && out_complex) {
+        if (ev[0] == 'd') hipLaunchKernelGGL((fir_copy_pattern16_kernel<4>), grid, block, 0, s, a);
+        else if (ev[0] == 'e') hipLaunchKernelGGL((fir_copy_pattern_nt_kernel<4>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((fir_copy_pattern_kernel<4>), grid, block, 0, s, a);
+    } else if (in_complex && out_complex) { SFE_LAUNCH(true, true) }
+    else if (!in_complex && out_complex) { SFE_LAUNCH(false, true) }
+    else if (!in_complex && !out_complex) { SFE_LAUNCH(false, false) }
     else {
         set_error("fir_fft: complex input with real output is not a defined combination");
         return SFE_EINVAL;
     }
+#undef SFE_LAUNCH
     SFE_HIP(hipGetLastError());
     return SFE_OK;
 }

@@ -35,9 +35,27 @@ static double check()
     return worst;
 }
 
+// dft16 then dft16_rev of the opposite direction must give 16 * identity, in natural order
+static double check_roundtrip()
+{
+    double worst = 0.0;
+    for (int trial = 0; trial < 50; trial++) {
+        v2f v[16], x[16];
+        for (int i = 0; i < 16; i++) x[i] = v[i] = (v2f){(float)rand() / RAND_MAX - 0.5f, (float)rand() / RAND_MAX - 0.5f};
+        sfe::dft16<-1>(v);
+        sfe::dft16_rev<+1>(v);
+        for (int i = 0; i < 16; i++)
+            worst = fmax(worst, fmax(fabs(v[i].x / 16 - x[i].x), fabs(v[i].y / 16 - x[i].y)));
+    }
+    return worst;
+}
+
 int main()
 {
     double f = check<-1>(), b = check<+1>();
+    double rt = check_roundtrip();
+    printf("roundtrip %.3g\n", rt);
+    if (rt > 2e-6) return 1;
     // cmul / cmul_conj
     v2f a = {0.3f, -0.7f}, w = {0.6f, 0.8f};
     v2f p = sfe::cmul(a, w), q = sfe::cmul_conj(a, w);
