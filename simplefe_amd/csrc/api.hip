@@ -6,7 +6,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
 #include <new>
+#include <numeric>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -46,6 +49,78 @@ static int use_device(int device)
     return SFE_OK;
 }
 
+// ---- tiled polyphase plans (common.h: PolyTiledPlan) ---------------------------------
+// Fold (U, step, pos0) into zero-padded per-output-phase tap rows of equal length.
+//   taps_pm: [U][plen] phase-major host taps.
+struct PlanCache {
+    std::map<std::pair<int, long long>, PolyTiledPlan> plans;   // (step, pos0) -> plan
+    void clear()
+    {
+        for (auto &kv : plans)
+            if (kv.second.d_G) (void)hipFree(kv.second.d_G);
+        plans.clear();
+    }
+};
+
+static long long floordiv_ll(long long a, long long b)
+{
+    long long q = a / b;
+    return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q;
+}
+
+// returns nullptr when the shape has no tiled kernel (caller uses the generic one)
+static const PolyTiledPlan *get_tiled_plan(PlanCache &cache, const std::vector<float> &taps_pm, int U, int plen,
+                                           int step, long long pos0, int *rc)
+{
+    *rc = SFE_OK;
+    auto key = std::make_pair(step, pos0);
+    auto it = cache.plans.find(key);
+    if (it != cache.plans.end()) return it->second.d_G ? &it->second : nullptr;
+    PolyTiledPlan pl;
+    const int g = std::gcd(step, U);
+    pl.SP = step / g;
+    pl.UP = U / g;
+    // drop trailing all-zero taps (decimate's odd-izing zero, resample's last-phase padding)
+    int plen_eff = plen;
+    while (plen_eff > 1) {
+        bool any = false;
+        for (int ph = 0; ph < U; ph++) any = any || taps_pm[(size_t)ph * plen + plen_eff - 1] != 0.0f;
+        if (any) break;
+        plen_eff--;
+    }
+    std::vector<long long> o(pl.UP);
+    std::vector<int> ph(pl.UP);
+    long long e_max = -(1LL << 60), e_min = (1LL << 60);
+    for (int r = 0; r < pl.UP; r++) {
+        const long long A = pos0 + (long long)r * step;
+        o[r] = floordiv_ll(A, U);
+        ph[r] = (int)(A - o[r] * U);
+        e_max = o[r] > e_max ? o[r] : e_max;
+        e_min = o[r] < e_min ? o[r] : e_min;
+    }
+    const int L = plen_eff + (int)(e_max - e_min);
+    pl.Lp = ((L + pl.SP - 1) / pl.SP) * pl.SP;
+    pl.e_max = (int)e_max;
+    if (!poly_tiled_supported(pl.SP, pl.UP, pl.Lp)) {
+        cache.plans[key] = pl;          // d_G == nullptr marks "unsupported"
+        return nullptr;
+    }
+    std::vector<float> G((size_t)pl.UP * pl.Lp, 0.0f);
+    for (int r = 0; r < pl.UP; r++)
+        for (int q = 0; q < pl.Lp; q++) {
+            const long long j = o[r] - e_max + pl.Lp - 1 - q;     // tap index met at local time q
+            if (j >= 0 && j < plen_eff) G[(size_t)r * pl.Lp + q] = taps_pm[(size_t)ph[r] * plen + j];
+        }
+    hipError_t e = hipMalloc(&pl.d_G, G.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(pl.d_G, G.data(), G.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        *rc = hip_fail(e, "tiled plan upload");
+        return nullptr;
+    }
+    auto ins = cache.plans.emplace(key, pl);
+    return &ins.first->second;
+}
+
 // ------------------------------------------------------------------------------ FIR
 struct Fir {
     int n_taps = 0, taps_complex = 0, data_complex = 0, out_complex = 0, n_channels = 1;
@@ -55,6 +130,8 @@ struct Fir {
     bool fft_ok = false;
     v2f *d_hs = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr;
     float *d_taps = nullptr;    // real taps for the direct kernel
+    std::vector<float> h_taps;  // host copy (direct-kernel plan)
+    PlanCache plans;
     void *d_hist[2] = {nullptr, nullptr};
     int cur = 0;
     // class-compatible host block path
@@ -72,6 +149,7 @@ static void fir_free(Fir *f)
     if (f->d_tw1) (void)hipFree(f->d_tw1);
     if (f->d_tw2) (void)hipFree(f->d_tw2);
     if (f->d_taps) (void)hipFree(f->d_taps);
+    f->plans.clear();
     for (int i = 0; i < 2; i++)
         if (f->d_hist[i]) (void)hipFree(f->d_hist[i]);
     if (f->h_buf) (void)hipHostFree(f->h_buf);
@@ -165,22 +243,40 @@ static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_st
             set_error("fir: the direct kernel takes real taps; complex taps need SFE_FIR_ALGO_FFT");
             return SFE_EINVAL;
         }
-        PolyArgs a;
-        memset(&a, 0, sizeof(a));
-        a.in = d_in;
-        a.out = d_out;
-        a.hist = f->d_hist[f->cur];
-        a.taps = f->d_taps;
-        a.n_in = (long long)n;
-        a.in_stride = (long long)in_stride;
-        a.out_stride = (long long)out_stride;
-        a.hl = f->hl;
-        a.U = 1;
-        a.plen = f->n_taps;
-        a.pos0 = 0;
-        a.step = 1;
-        a.n_out = (long long)n;
-        rc = launch_poly_int(a, f->data_complex, 0, 0, f->n_channels, s);
+        const PolyTiledPlan *pl = get_tiled_plan(f->plans, f->h_taps, 1, f->n_taps, 1, 0, &rc);
+        if (rc != SFE_OK) return rc;
+        if (pl) {
+            PolyTiledArgs ta;
+            ta.in = d_in;
+            ta.out = d_out;
+            ta.hist = f->d_hist[f->cur];
+            ta.G = pl->d_G;
+            ta.n_in = (long long)n;
+            ta.in_stride = (long long)in_stride;
+            ta.out_stride = (long long)out_stride;
+            ta.n_out = (long long)n;
+            ta.hl = f->hl;
+            ta.Lp = pl->Lp;
+            ta.e_max = pl->e_max;
+            rc = launch_poly_tiled(*pl, ta, f->data_complex, 0, f->n_channels, s);
+        } else {
+            PolyArgs a;
+            memset(&a, 0, sizeof(a));
+            a.in = d_in;
+            a.out = d_out;
+            a.hist = f->d_hist[f->cur];
+            a.taps = f->d_taps;
+            a.n_in = (long long)n;
+            a.in_stride = (long long)in_stride;
+            a.out_stride = (long long)out_stride;
+            a.hl = f->hl;
+            a.U = 1;
+            a.plen = f->n_taps;
+            a.pos0 = 0;
+            a.step = 1;
+            a.n_out = (long long)n;
+            rc = launch_poly_int(a, f->data_complex, 0, 0, f->n_channels, s);
+        }
     }
     if (rc != SFE_OK) return rc;
     rc = launch_history_update(d_in, (long long)n, (long long)in_stride, f->d_hist[f->cur],
@@ -196,6 +292,8 @@ struct Rs {
     int device = 0, mode = SFE_RS_RESAMPLE, exact_stream = 0;
     int hl = 0;
     float *d_taps = nullptr;               // [U][plen] phase-major
+    std::vector<float> h_taps_pm;          // host copy of the same (tiled plans)
+    PlanCache plans;
     void *d_hist[2] = {nullptr, nullptr};
     int cur = 0;
     sfe_rs_timestate ts = {0, 0.0f, 0};
@@ -217,6 +315,7 @@ static void rs_free(Rs *r)
     if (!r) return;
     (void)hipSetDevice(r->device);
     if (r->d_taps) (void)hipFree(r->d_taps);
+    r->plans.clear();
     for (int i = 0; i < 2; i++)
         if (r->d_hist[i]) (void)hipFree(r->d_hist[i]);
     if (r->d_in) (void)hipFree(r->d_in);
@@ -454,6 +553,7 @@ int sfe_dsp_fir_create(const float *taps, int n_taps, int taps_complex, int data
         if (rc != SFE_OK) return fail(rc);
     }
     if (!f->taps_complex) {
+        f->h_taps.assign(taps, taps + n_taps);
         TRY(hipMalloc(&f->d_taps, (size_t)n_taps * sizeof(float)));
         TRY(hipMemcpy(f->d_taps, taps, (size_t)n_taps * sizeof(float), hipMemcpyHostToDevice));
     }
@@ -613,6 +713,7 @@ int sfe_dsp_rs_create(const float *taps, int n_taps, int upsample, int blksize, 
             const int n = i * upsample + j;
             pm[(size_t)j * r->plen + i] = n < n_taps ? taps[n] : 0.0f;
         }
+    r->h_taps_pm = pm;
     TRY(hipMalloc(&r->d_taps, pm.size() * sizeof(float)));
     TRY(hipMemcpy(r->d_taps, pm.data(), pm.size() * sizeof(float), hipMemcpyHostToDevice));
     const size_t hb = (size_t)n_channels * r->hl * r->esz();
@@ -759,7 +860,25 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         a.pos0 = pos0;
         a.step = (int)S;
         a.n_out = K;
-        rc = launch_poly_int(a, r->data_complex, 0, r->exact_stream, r->n_channels, s);
+        const PolyTiledPlan *pl = get_tiled_plan(r->plans, r->h_taps_pm, r->U, r->plen, (int)S, pos0, &rc);
+        if (rc != SFE_OK) return rc;
+        if (pl) {
+            PolyTiledArgs ta;
+            ta.in = d_in;
+            ta.out = d_out;
+            ta.hist = r->d_hist[r->cur];
+            ta.G = pl->d_G;
+            ta.n_in = (long long)n_in;
+            ta.in_stride = (long long)in_stride;
+            ta.out_stride = (long long)out_stride;
+            ta.n_out = K;
+            ta.hl = r->hl;
+            ta.Lp = pl->Lp;
+            ta.e_max = pl->e_max;
+            rc = launch_poly_tiled(*pl, ta, r->data_complex, r->exact_stream, r->n_channels, s);
+        } else {
+            rc = launch_poly_int(a, r->data_complex, 0, r->exact_stream, r->n_channels, s);
+        }
         if (rc != SFE_OK) return rc;
         const long long next = pos0 + K * S - (long long)n_in * r->U;
         r->ts.leftover = next == -1 ? 1 : 0;

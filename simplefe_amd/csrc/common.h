@@ -60,6 +60,29 @@ struct PolyArgs {
 };
 int launch_poly_int(const PolyArgs &a, int data_complex, int taps_complex, int exact,
                     int n_channels, hipStream_t s);
+
+// Tiled integer-step kernel (the measured decimate / resample path).  With g = gcd(step, U),
+// UP = U/g outputs are produced per SP = step/g input samples; output k = UP*m + r reads
+// x[SP*m + o_r - j] against phase ph_r, (o_r, ph_r) fixed by pos0.  The host folds that into
+// zero-padded tap rows G[r][q], q ascending in time, all of one length Lp (a multiple of SP),
+// so every lane runs the same straight-line loop (polyphase.hip: poly_tiled_kernel).
+struct PolyTiledPlan {
+    int    SP = 0, UP = 0, Lp = 0, e_max = 0;
+    float *d_G = nullptr;        // [UP][Lp]
+};
+struct PolyTiledArgs {
+    const void *in;
+    void       *out;
+    const void *hist;
+    const float *G;
+    long long   n_in, in_stride, out_stride, n_out;
+    int         hl, Lp, e_max;
+};
+// returns SFE_OK, or SFE_ESTATE when (SP, UP, Lp) has no tiled instantiation (caller falls
+// back to launch_poly_int)
+int launch_poly_tiled(const PolyTiledPlan &plan, const PolyTiledArgs &a, int data_complex, int exact,
+                      int n_channels, hipStream_t s);
+bool poly_tiled_supported(int SP, int UP, int Lp);
 int launch_poly_sched(const PolyArgs &a, int data_complex, int exact, int n_channels,
                       hipStream_t s);
 

@@ -103,6 +103,82 @@ __global__ __launch_bounds__(256) void poly_int_kernel(PolyArgs a, int tile_out,
     }
 }
 
+// ------------------------------------------------------ integer-step law, tiled (fast path)
+// One workgroup = TM consecutive m (TM*UP outputs).  The input span is staged once into LDS,
+// de-interleaved by SP:  X[p][c] = x[n_org + SP*c + p], so that for a fixed tap the 64 lanes of
+// a wave (consecutive m) read 64 consecutive cells of one row -- conflict-free ds_read_b64 --
+// and each staged sample is read once per output that needs it.  Taps are wave-uniform (SGPR
+// loads), UP accumulators per m share every sample read (resample 5/3: one read feeds up to
+// three phase sums).  The loop runs q = Lp-1 .. 0, i.e. tap index ascending, the reference's
+// accumulation order (libdsp/decimate.cxx:134-137).
+constexpr int TM = 512;                 // m per workgroup (2 per thread)
+__host__ __device__ constexpr int tiled_xc(int SP) { return SP >= 4 ? 64 : (SP >= 2 ? 256 : 1024); }
+__host__ __device__ constexpr int tiled_rowlen(int SP) { return TM + tiled_xc(SP) + 2; }   // == 2 mod 16
+
+template <int SP, int UP, bool CPLX, bool EXACT>
+__global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
+{
+    typedef typename Elem<CPLX>::T T;
+    constexpr int ROWLEN = tiled_rowlen(SP);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T *X = reinterpret_cast<T *>(smem);
+
+    const unsigned tid = threadIdx.x;
+    const int ch = blockIdx.y;
+    const T *in = static_cast<const T *>(a.in) + (size_t)ch * a.in_stride;
+    const T *hist = static_cast<const T *>(a.hist) + (size_t)ch * a.hl;
+    T *out = static_cast<T *>(a.out) + (size_t)ch * a.out_stride;
+
+    const long long m0 = (long long)blockIdx.x * TM;
+    const long long n_org = (long long)SP * m0 + a.e_max - (a.Lp - 1);   // stream index of local sample 0
+    const int n_tile = SP * TM + a.Lp;
+
+    // ---- stage: coalesced 8-byte lanes in, transposed into the SP rows
+    if (n_org >= 0 && n_org + n_tile <= a.n_in) {
+        const T *src = in + n_org;                                       // uniform
+        for (unsigned s = tid; s < (unsigned)n_tile; s += 256) {
+            const T v = __builtin_nontemporal_load(src + s);
+            X[(s % SP) * ROWLEN + s / SP] = v;
+        }
+    } else {
+        for (unsigned s = tid; s < (unsigned)n_tile; s += 256)
+            X[(s % SP) * ROWLEN + s / SP] = vload<CPLX>(in, hist, n_org + s, a.n_in, a.hl);
+    }
+    __syncthreads();
+
+    T acc[2][UP];
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int r = 0; r < UP; r++) acc[b][r] = Elem<CPLX>::zero();
+
+    const int nchunk = a.Lp / SP;
+    const T *xp = X + tid + (nchunk - 1);          // column tid + c, walking c downwards
+    const float *g = a.G + (size_t)(nchunk - 1) * SP;
+    for (int c = nchunk - 1; c >= 0; --c) {
+#pragma unroll
+        for (int p = SP - 1; p >= 0; --p) {
+            const T x0 = xp[p * ROWLEN], x1 = xp[p * ROWLEN + 256];
+#pragma unroll
+            for (int r = 0; r < UP; r++) {
+                const float t = g[r * a.Lp + p];   // wave-uniform
+                acc[0][r] = mac<EXACT>(acc[0][r], t, x0);
+                acc[1][r] = mac<EXACT>(acc[1][r], t, x1);
+            }
+        }
+        xp -= 1;
+        g -= SP;
+    }
+
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        const long long k = (long long)UP * (m0 + tid + 256 * b);
+#pragma unroll
+        for (int r = 0; r < UP; r++)
+            if (k + r < a.n_out) __builtin_nontemporal_store(acc[b][r], out + k + r);
+    }
+}
+
 // ------------------------------------------------------------------- scheduled law
 template <bool CPLX, bool EXACT>
 __device__ __forceinline__ typename Elem<CPLX>::T dot_at(const PolyArgs &a,
@@ -196,6 +272,54 @@ int launch_poly_int(const PolyArgs &a, int data_complex, int /*taps_complex*/, i
     if (data_complex) { if (exact) LAUNCH(true, true); else LAUNCH(true, false); }
     else { if (exact) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
+    SFE_HIP(hipGetLastError());
+    return SFE_OK;
+}
+
+bool poly_tiled_supported(int SP, int UP, int Lp)
+{
+    if (Lp <= 0 || Lp % SP) return false;
+    int xc;
+    switch (SP * 16 + UP) {
+    case 1 * 16 + 1: case 2 * 16 + 1: case 3 * 16 + 1: case 4 * 16 + 1: case 5 * 16 + 1: case 8 * 16 + 1:
+    case 10 * 16 + 1: case 5 * 16 + 3: case 3 * 16 + 2: case 5 * 16 + 2: case 5 * 16 + 4:
+        break;
+    default: return false;
+    }
+    xc = tiled_xc(SP);
+    return Lp / SP <= xc;
+}
+
+int launch_poly_tiled(const PolyTiledPlan &plan, const PolyTiledArgs &a, int data_complex, int exact,
+                      int n_channels, hipStream_t s)
+{
+    if (a.n_out <= 0) return SFE_OK;
+    if (!poly_tiled_supported(plan.SP, plan.UP, plan.Lp)) return SFE_ESTATE;
+    const long long mtot = (a.n_out + plan.UP - 1) / plan.UP;
+    const long long tiles = (mtot + TM - 1) / TM;
+    if (tiles > 0x7fffffffLL) {
+        set_error("polyphase: too many tiles");
+        return SFE_EINVAL;
+    }
+    dim3 grid((unsigned)tiles, (unsigned)n_channels), block(256);
+    const size_t esz = data_complex ? 8 : 4;
+#define SFE_T(SPv, UPv)                                                                               \
+    case SPv * 16 + UPv: {                                                                            \
+        const size_t sh = (size_t)SPv * tiled_rowlen(SPv) * esz;                                      \
+        if (data_complex) {                                                                           \
+            if (exact) hipLaunchKernelGGL((poly_tiled_kernel<SPv, UPv, true, true>), grid, block, sh, s, a);   \
+            else hipLaunchKernelGGL((poly_tiled_kernel<SPv, UPv, true, false>), grid, block, sh, s, a);        \
+        } else {                                                                                      \
+            if (exact) hipLaunchKernelGGL((poly_tiled_kernel<SPv, UPv, false, true>), grid, block, sh, s, a);  \
+            else hipLaunchKernelGGL((poly_tiled_kernel<SPv, UPv, false, false>), grid, block, sh, s, a);       \
+        }                                                                                             \
+    } break;
+    switch (plan.SP * 16 + plan.UP) {
+        SFE_T(1, 1) SFE_T(2, 1) SFE_T(3, 1) SFE_T(4, 1) SFE_T(5, 1) SFE_T(8, 1) SFE_T(10, 1)
+        SFE_T(5, 3) SFE_T(3, 2) SFE_T(5, 2) SFE_T(5, 4)
+    default: return SFE_ESTATE;
+    }
+#undef SFE_T
     SFE_HIP(hipGetLastError());
     return SFE_OK;
 }
