@@ -99,7 +99,7 @@ static const PolyTiledPlan *get_tiled_plan(PlanCache &cache, const std::vector<f
         e_min = o[r] < e_min ? o[r] : e_min;
     }
     const int L = plen_eff + (int)(e_max - e_min);
-    pl.Lp = ((L + pl.SP - 1) / pl.SP) * pl.SP;
+    pl.Lp = ((L + 2 * pl.SP - 1) / (2 * pl.SP)) * (2 * pl.SP);   // whole pairs of SP-sample chunks
     pl.e_max = (int)e_max;
     if (!poly_tiled_supported(pl.SP, pl.UP, pl.Lp)) {
         cache.plans[key] = pl;          // d_G == nullptr marks "unsupported"

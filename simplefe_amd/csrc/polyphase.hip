@@ -105,20 +105,31 @@ __global__ __launch_bounds__(256) void poly_int_kernel(PolyArgs a, int tile_out,
 
 // ------------------------------------------------------ integer-step law, tiled (fast path)
 // One workgroup = TM consecutive m (TM*UP outputs).  The input span is staged once into LDS,
-// de-interleaved by SP:  X[p][c] = x[n_org + SP*c + p], so that for a fixed tap the 64 lanes of
-// a wave (consecutive m) read 64 consecutive cells of one row -- conflict-free ds_read_b64 --
-// and each staged sample is read once per output that needs it.  Taps are wave-uniform (SGPR
-// loads), UP accumulators per m share every sample read (resample 5/3: one read feeds up to
-// three phase sums).  The loop runs q = Lp-1 .. 0, i.e. tap index ascending, the reference's
-// accumulation order (libdsp/decimate.cxx:134-137).
-constexpr int TM = 512;                 // m per workgroup (2 per thread)
+// de-interleaved by SP:  X[p][c] = x[n_org + SP*c + p], so that for a fixed tap the lanes of a
+// wave (consecutive m) read consecutive cells of one row, conflict-free.  Each thread owns TWO
+// consecutive m (2i, 2i+1): the cells it needs for them at tap chunk c are X[p][2i+c] and
+// X[p][2i+c+1], so one aligned 16-byte LDS read (a cell pair at an even column) feeds four
+// multiply-accumulates across two chunks -- 1/4 of the LDS instructions of a read per tap.
+// Taps are wave-uniform (SGPR loads); UP accumulators per m share every sample read (resample
+// 5/3: one read feeds up to three phase sums).  The loop runs q = Lp-1 .. 0, i.e. tap index
+// ascending: the reference's accumulation order (libdsp/decimate.cxx:134-137).
+constexpr int TM = 512;                 // m per workgroup (2 consecutive per thread)
 __host__ __device__ constexpr int tiled_xc(int SP) { return SP >= 4 ? 64 : (SP >= 2 ? 256 : 1024); }
-__host__ __device__ constexpr int tiled_rowlen(int SP) { return TM + tiled_xc(SP) + 2; }   // == 2 mod 16
+__host__ __device__ constexpr int tiled_rowlen(int SP) { return TM + tiled_xc(SP) + 2; }   // even, == 2 mod 16
+
+template <bool CPLX> struct Pair;
+template <> struct Pair<true> { typedef v4f P; };
+template <> struct Pair<false> { typedef v2f P; };
+__device__ __forceinline__ v2f pair_lo(v4f p) { return (v2f){p.x, p.y}; }
+__device__ __forceinline__ v2f pair_hi(v4f p) { return (v2f){p.z, p.w}; }
+__device__ __forceinline__ float pair_lo(v2f p) { return p.x; }
+__device__ __forceinline__ float pair_hi(v2f p) { return p.y; }
 
 template <int SP, int UP, bool CPLX, bool EXACT>
 __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
 {
     typedef typename Elem<CPLX>::T T;
+    typedef typename Pair<CPLX>::P P2;
     constexpr int ROWLEN = tiled_rowlen(SP);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T *X = reinterpret_cast<T *>(smem);
@@ -132,14 +143,21 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
     const long long m0 = (long long)blockIdx.x * TM;
     const long long n_org = (long long)SP * m0 + a.e_max - (a.Lp - 1);   // stream index of local sample 0
     const int n_tile = SP * TM + a.Lp;
+    constexpr int MAIN = SP * TM / 256;       // unrolled loads per thread for the body of the tile
 
     // ---- stage: coalesced 8-byte lanes in, transposed into the SP rows
     if (n_org >= 0 && n_org + n_tile <= a.n_in) {
         const T *src = in + n_org;                                       // uniform
-        for (unsigned s = tid; s < (unsigned)n_tile; s += 256) {
-            const T v = __builtin_nontemporal_load(src + s);
-            X[(s % SP) * ROWLEN + s / SP] = v;
+        T v[MAIN];
+#pragma unroll
+        for (int i = 0; i < MAIN; i++) v[i] = __builtin_nontemporal_load(src + tid + 256u * i);
+#pragma unroll
+        for (int i = 0; i < MAIN; i++) {
+            const unsigned s = tid + 256u * i;
+            X[(s % SP) * ROWLEN + s / SP] = v[i];
         }
+        for (unsigned s = SP * TM + tid; s < (unsigned)n_tile; s += 256)
+            X[(s % SP) * ROWLEN + s / SP] = __builtin_nontemporal_load(src + s);
     } else {
         for (unsigned s = tid; s < (unsigned)n_tile; s += 256)
             X[(s % SP) * ROWLEN + s / SP] = vload<CPLX>(in, hist, n_org + s, a.n_in, a.hl);
@@ -152,30 +170,50 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
 #pragma unroll
         for (int r = 0; r < UP; r++) acc[b][r] = Elem<CPLX>::zero();
 
-    const int nchunk = a.Lp / SP;
-    const T *xp = X + tid + (nchunk - 1);          // column tid + c, walking c downwards
-    const float *g = a.G + (size_t)(nchunk - 1) * SP;
-    for (int c = nchunk - 1; c >= 0; --c) {
+    // chunk c covers local times q = c*SP + p.  Two chunks (cc+1, cc) per iteration, cc even.
+    const int nchunk = a.Lp / SP;                                   // even (host pads Lp)
+    const P2 *xp = reinterpret_cast<const P2 *>(X) + tid + nchunk / 2;   // pair column (2*tid + cc)/2
+    P2 nxt[SP];                                                     // pairs at column 2*tid + cc + 2
 #pragma unroll
-        for (int p = SP - 1; p >= 0; --p) {
-            const T x0 = xp[p * ROWLEN], x1 = xp[p * ROWLEN + 256];
+    for (int p = 0; p < SP; p++) nxt[p] = xp[p * (ROWLEN / 2)];
+    const float *g = a.G + (size_t)(nchunk - 1) * SP;               // taps of chunk cc+1
+    for (int cc = nchunk - 2; cc >= 0; cc -= 2) {
+        xp -= 1;
+        P2 cur[SP];
+#pragma unroll
+        for (int p = 0; p < SP; p++) cur[p] = xp[p * (ROWLEN / 2)];
+#pragma unroll
+        for (int p = SP - 1; p >= 0; --p) {                          // chunk cc+1
 #pragma unroll
             for (int r = 0; r < UP; r++) {
-                const float t = g[r * a.Lp + p];   // wave-uniform
-                acc[0][r] = mac<EXACT>(acc[0][r], t, x0);
-                acc[1][r] = mac<EXACT>(acc[1][r], t, x1);
+                const float t = g[r * a.Lp + p];                     // wave-uniform
+                acc[0][r] = mac<EXACT>(acc[0][r], t, pair_hi(cur[p]));
+                acc[1][r] = mac<EXACT>(acc[1][r], t, pair_lo(nxt[p]));
             }
         }
-        xp -= 1;
-        g -= SP;
+#pragma unroll
+        for (int p = SP - 1; p >= 0; --p) {                          // chunk cc
+#pragma unroll
+            for (int r = 0; r < UP; r++) {
+                const float t = g[r * a.Lp + p - SP];
+                acc[0][r] = mac<EXACT>(acc[0][r], t, pair_lo(cur[p]));
+                acc[1][r] = mac<EXACT>(acc[1][r], t, pair_hi(cur[p]));
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < SP; p++) nxt[p] = cur[p];
+        g -= 2 * SP;
     }
 
+    // ---- outputs UP*(m0 + 2*tid) .. + 2*UP - 1: contiguous per lane
+    const long long k = (long long)UP * (m0 + 2 * tid);
+    if (k + 2 * UP <= a.n_out) {
 #pragma unroll
-    for (int b = 0; b < 2; b++) {
-        const long long k = (long long)UP * (m0 + tid + 256 * b);
+        for (int j = 0; j < 2 * UP; j++) __builtin_nontemporal_store(acc[j / UP][j % UP], out + k + j);
+    } else {
 #pragma unroll
-        for (int r = 0; r < UP; r++)
-            if (k + r < a.n_out) __builtin_nontemporal_store(acc[b][r], out + k + r);
+        for (int j = 0; j < 2 * UP; j++)
+            if (k + j < a.n_out) out[k + j] = acc[j / UP][j % UP];
     }
 }
 
@@ -278,7 +316,7 @@ int launch_poly_int(const PolyArgs &a, int data_complex, int /*taps_complex*/, i
 
 bool poly_tiled_supported(int SP, int UP, int Lp)
 {
-    if (Lp <= 0 || Lp % SP) return false;
+    if (Lp <= 0 || Lp % (2 * SP)) return false;   // whole chunk pairs
     int xc;
     switch (SP * 16 + UP) {
     case 1 * 16 + 1: case 2 * 16 + 1: case 3 * 16 + 1: case 4 * 16 + 1: case 5 * 16 + 1: case 8 * 16 + 1:
