@@ -170,16 +170,14 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
 #pragma unroll
         for (int r = 0; r < UP; r++) acc[b][r] = Elem<CPLX>::zero();
 
-    // chunk c covers local times q = c*SP + p.  Two chunks (cc+1, cc) per iteration, cc even.
+    // chunk c covers local times q = c*SP + p.  One STEP = two chunks (cc+1, cc), cc even: it
+    // loads the pair row at column 2*tid+cc into `cur` and uses `nxt` (column 2*tid+cc+2).
+    // STEPs alternate two register sets so no pair is ever copied.
     const int nchunk = a.Lp / SP;                                   // even (host pads Lp)
     const P2 *xp = reinterpret_cast<const P2 *>(X) + tid + nchunk / 2;   // pair column (2*tid + cc)/2
-    P2 nxt[SP];                                                     // pairs at column 2*tid + cc + 2
-#pragma unroll
-    for (int p = 0; p < SP; p++) nxt[p] = xp[p * (ROWLEN / 2)];
     const float *g = a.G + (size_t)(nchunk - 1) * SP;               // taps of chunk cc+1
-    for (int cc = nchunk - 2; cc >= 0; cc -= 2) {
+    auto step = [&](P2 (&cur)[SP], const P2 (&nxt)[SP]) {
         xp -= 1;
-        P2 cur[SP];
 #pragma unroll
         for (int p = 0; p < SP; p++) cur[p] = xp[p * (ROWLEN / 2)];
 #pragma unroll
@@ -200,9 +198,21 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
                 acc[1][r] = mac<EXACT>(acc[1][r], t, pair_hi(cur[p]));
             }
         }
-#pragma unroll
-        for (int p = 0; p < SP; p++) nxt[p] = cur[p];
         g -= 2 * SP;
+    };
+    P2 pa[SP], pb[SP];
+#pragma unroll
+    for (int p = 0; p < SP; p++) pa[p] = xp[p * (ROWLEN / 2)];      // pairs at column 2*tid + nchunk
+    int steps = nchunk / 2;
+    if (steps & 1) {                                                 // odd count: peel one, landing in pa
+        step(pb, pa);
+#pragma unroll
+        for (int p = 0; p < SP; p++) pa[p] = pb[p];
+        steps--;
+    }
+    for (; steps > 0; steps -= 2) {
+        step(pb, pa);
+        step(pa, pb);
     }
 
     // ---- outputs UP*(m0 + 2*tid) .. + 2*UP - 1: contiguous per lane
