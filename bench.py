@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--workload", default="fir", choices=["fir", "resample", "decimate"])
     ap.add_argument("--log2n", type=int, default=None, help="samples per GPU = 2^log2n (default per workload)")
     ap.add_argument("--algo", default="auto", choices=["auto", "fft", "direct"])
+    ap.add_argument("--channels", type=int, default=None,
+                    help="channels per GPU (default 1 at N=1, 8 at N>1: the 64-channel config over 8 GPUs)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -141,7 +143,7 @@ def main():
     wl = args.workload
     if wl == "fir":
         log2n = args.log2n or 28
-        nch = 1 if world == 1 else 8         # N > 1: 8*N channels, block-partitioned over ranks
+        nch = args.channels or (1 if world == 1 else 8)   # N > 1: 8*N channels, block-partitioned over ranks
         taps = synth.taps_cfg2()
         workload = ("256-tap FIR (blkconv law), 2^%d cf32 samples per GPU, %d channel(s) x 2^%d, "
                     "device-resident in/out" % (log2n, nch, log2n - (nch.bit_length() - 1)))

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_<tag>_<workload>/ (scripts/collect_profiles.sh) into the committed
+summaries: profiles/<tag>/<workload>_kernel_stats.csv, ..._pmc.csv and profiles/pmc_<tag>_<workload>.json
+(the file bench.py reads `roofline.traffic` from)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+KEYS = {"fir": ("fir256_cf32_2p28", "fir_fft4096", 16 * 2 ** 28),
+        "decimate": ("decimate8_cf32_2p30", "poly_tiled", 9 * 2 ** 30),
+        "resample": ("resample5o3_cf32_2p28", "poly_tiled", None)}
+os.makedirs(os.path.join(ROOT, "profiles", tag), exist_ok=True)
+for wl, (key, ksub, alg) in KEYS.items():
+    d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{wl}")
+    if not os.path.isdir(d):
+        continue
+    ks = glob.glob(d + "/kt/**/*_kernel_stats.csv", recursive=True)
+    if ks:
+        shutil.copy(ks[0], os.path.join(ROOT, "profiles", tag, f"{wl}_kernel_stats.csv"))
+    vals, rows_out = {}, []
+    for c in ("fetch", "write"):
+        f = glob.glob(d + f"/{c}/**/*_counter_collection.csv", recursive=True)
+        if not f:
+            continue
+        for r in csv.DictReader(open(f[0])):
+            rows_out.append({k: r[k] for k in ("Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size",
+                                               "VGPR_Count", "SGPR_Count", "Counter_Name", "Counter_Value",
+                                               "Start_Timestamp", "End_Timestamp")})
+            if ksub in r["Kernel_Name"]:
+                vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    if rows_out:
+        with open(os.path.join(ROOT, "profiles", tag, f"{wl}_pmc.csv"), "w") as o:
+            w = csv.DictWriter(o, fieldnames=list(rows_out[0].keys()))
+            w.writeheader()
+            w.writerows(rows_out)
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        fetch = sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"])
+        write = sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"])
+        out = {"workload": key, "round": tag, "kernel_substr": ksub, "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB": write,
+               "correction": "gfx950: FETCH_SIZE tallies 128-B requests as 64 B -> x2 (MI355X_MICROARCH.md, HBM); "
+                             "WRITE_SIZE exact (calibrated: synth_fill_kernel writes 2 GiB -> 2097152 KiB)",
+               "hbm_bytes_per_launch": (2 * fetch + write) * 1024, "algorithmic_bytes_per_launch": alg,
+               "how": "separate rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) over bench.py --steps 3 --warmup 1 --no-cpu"}
+        json.dump(out, open(os.path.join(ROOT, "profiles", f"pmc_{tag}_{wl}.json"), "w"), indent=1)
+        print(wl, out["hbm_bytes_per_launch"] / 1e9, "GB per launch")

@@ -215,15 +215,35 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
         step(pa, pb);
     }
 
-    // ---- outputs UP*(m0 + 2*tid) .. + 2*UP - 1: contiguous per lane
-    const long long k = (long long)UP * (m0 + 2 * tid);
-    if (k + 2 * UP <= a.n_out) {
+    // ---- outputs UP*(m0 + 2*tid) .. + 2*UP - 1: contiguous per lane.
+    // UP == 1: one 16-byte streaming store per lane, lanes contiguous.  UP > 1: a lane's 2*UP
+    // results are 16*UP bytes apart from its neighbour's, so the tile is first laid out linearly
+    // in LDS (the input tile is dead by now) and then stored with contiguous 16-byte lanes --
+    // every wave instruction writes whole 128-byte lines (otherwise WRITE_SIZE read +16%).
+    const long long k0 = (long long)UP * m0;                // first output of the tile
+    const bool aligned = ((reinterpret_cast<uintptr_t>(out + k0) & 15) == 0);
+    if (UP == 1 || !aligned || k0 + (long long)UP * TM > a.n_out) {
+        const long long k = k0 + (long long)UP * 2 * tid;
+        if (UP == 1 && aligned && k + 2 <= a.n_out) {
+            P2 v;
+            if constexpr (CPLX) v = (v4f){acc[0][0].x, acc[0][0].y, acc[1][0].x, acc[1][0].y};
+            else v = (v2f){acc[0][0], acc[1][0]};
+            __builtin_nontemporal_store(v, reinterpret_cast<P2 *>(out + k));
+        } else {
 #pragma unroll
-        for (int j = 0; j < 2 * UP; j++) __builtin_nontemporal_store(acc[j / UP][j % UP], out + k + j);
+            for (int j = 0; j < 2 * UP; j++)
+                if (k + j < a.n_out) out[k + j] = acc[j / UP][j % UP];
+        }
     } else {
+        __syncthreads();                                    // everyone is done reading X
+        T *Y = X;
 #pragma unroll
-        for (int j = 0; j < 2 * UP; j++)
-            if (k + j < a.n_out) out[k + j] = acc[j / UP][j % UP];
+        for (int j = 0; j < 2 * UP; j++) Y[2 * UP * tid + j] = acc[j / UP][j % UP];
+        __syncthreads();
+        const P2 *Yp = reinterpret_cast<const P2 *>(Y);
+        P2 *op = reinterpret_cast<P2 *>(out + k0);
+#pragma unroll
+        for (int i = 0; i < UP; i++) __builtin_nontemporal_store(Yp[tid + 256 * i], op + tid + 256 * i);
     }
 }
 
