@@ -121,6 +121,80 @@ static const PolyTiledPlan *get_tiled_plan(PlanCache &cache, const std::vector<f
     return &ins.first->second;
 }
 
+// ---- f32-MFMA plans (common.h: PolyMfmaPlan) ------------------------------------------
+struct MfmaCache {
+    std::map<std::pair<int, long long>, PolyMfmaPlan> plans;
+    void clear()
+    {
+        for (auto &kv : plans)
+            if (kv.second.d_A) (void)hipFree(kv.second.d_A);
+        plans.clear();
+    }
+};
+
+static const PolyMfmaPlan *get_mfma_plan(MfmaCache &cache, const std::vector<float> &taps_pm, int U, int plen,
+                                         int step, long long pos0, int *rc)
+{
+    *rc = SFE_OK;
+    auto key = std::make_pair(step, pos0);
+    auto it = cache.plans.find(key);
+    if (it != cache.plans.end()) return it->second.d_A ? &it->second : nullptr;
+    PolyMfmaPlan pl;
+    const int g = std::gcd(step, U);
+    const int SP = step / g, UP = U / g;
+    if (UP > 16) {
+        cache.plans[key] = pl;
+        return nullptr;
+    }
+    const int DM = 16 / UP;
+    pl.RG = UP * DM;
+    pl.GS = SP * DM;
+    int plen_eff = plen;
+    while (plen_eff > 1) {
+        bool any = false;
+        for (int ph = 0; ph < U; ph++) any = any || taps_pm[(size_t)ph * plen + plen_eff - 1] != 0.0f;
+        if (any) break;
+        plen_eff--;
+    }
+    std::vector<long long> o(UP);
+    std::vector<int> ph(UP);
+    long long e_max = -(1LL << 60), e_min = (1LL << 60);
+    for (int r = 0; r < UP; r++) {
+        const long long A = pos0 + (long long)r * step;
+        o[r] = floordiv_ll(A, U);
+        ph[r] = (int)(A - o[r] * U);
+        e_max = o[r] > e_max ? o[r] : e_max;
+        e_min = o[r] < e_min ? o[r] : e_min;
+    }
+    const long long u_hi = (long long)SP * (DM - 1) + e_max;
+    const long long K0 = u_hi - (e_min - (plen_eff - 1)) + 1;
+    pl.Kp = (int)((K0 + 3) / 4 * 4);
+    pl.u_lo = (int)(u_hi - pl.Kp + 1);
+    pl.density = (float)((double)pl.RG * plen_eff / (16.0 * pl.Kp));
+    if (!poly_mfma_fits(pl.GS, pl.RG, pl.Kp)) {
+        cache.plans[key] = pl;          // d_A == nullptr marks "unsupported"
+        return nullptr;
+    }
+    const int ksteps = pl.Kp / 4;
+    std::vector<float> Af((size_t)ksteps * 64, 0.0f);
+    for (int ks = 0; ks < ksteps; ks++)
+        for (int lane = 0; lane < 64; lane++) {
+            const int row = lane & 15, kk = 4 * ks + (lane >> 4);
+            if (row >= pl.RG) continue;
+            const int d = row / UP, r = row % UP;
+            const long long jt = (long long)SP * d + o[r] - u_hi + kk;      // tap met at window pos u_hi - kk
+            if (jt >= 0 && jt < plen_eff) Af[(size_t)ks * 64 + lane] = taps_pm[(size_t)ph[r] * plen + jt];
+        }
+    hipError_t e = hipMalloc(&pl.d_A, Af.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(pl.d_A, Af.data(), Af.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        *rc = hip_fail(e, "mfma plan upload");
+        return nullptr;
+    }
+    auto ins = cache.plans.emplace(key, pl);
+    return &ins.first->second;
+}
+
 // ------------------------------------------------------------------------------ FIR
 struct Fir {
     int n_taps = 0, taps_complex = 0, data_complex = 0, out_complex = 0, n_channels = 1;
@@ -294,6 +368,7 @@ struct Rs {
     float *d_taps = nullptr;               // [U][plen] phase-major
     std::vector<float> h_taps_pm;          // host copy of the same (tiled plans)
     PlanCache plans;
+    MfmaCache mfma_plans;
     void *d_hist[2] = {nullptr, nullptr};
     int cur = 0;
     sfe_rs_timestate ts = {0, 0.0f, 0};
@@ -316,6 +391,7 @@ static void rs_free(Rs *r)
     (void)hipSetDevice(r->device);
     if (r->d_taps) (void)hipFree(r->d_taps);
     r->plans.clear();
+    r->mfma_plans.clear();
     for (int i = 0; i < 2; i++)
         if (r->d_hist[i]) (void)hipFree(r->d_hist[i]);
     if (r->d_in) (void)hipFree(r->d_in);
@@ -860,9 +936,36 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         a.pos0 = pos0;
         a.step = (int)S;
         a.n_out = K;
-        const PolyTiledPlan *pl = get_tiled_plan(r->plans, r->h_taps_pm, r->U, r->plen, (int)S, pos0, &rc);
+        // matrix-pipe form (fused numerics, cf32): opt-in with SFE_RS_MFMA=1.  Measured slower
+        // than the VALU kernel on the one shape where its tap matrix is dense (polyphase.hip).
+        const PolyMfmaPlan *mp = nullptr;
+        {
+            const char *e = getenv("SFE_RS_MFMA");
+            if (e && e[0] == '1' && !r->exact_stream && r->data_complex) {
+                mp = get_mfma_plan(r->mfma_plans, r->h_taps_pm, r->U, r->plen, (int)S, pos0, &rc);
+                if (rc != SFE_OK) return rc;
+            }
+        }
+        const PolyTiledPlan *pl = mp ? nullptr : get_tiled_plan(r->plans, r->h_taps_pm, r->U, r->plen, (int)S, pos0, &rc);
         if (rc != SFE_OK) return rc;
-        if (pl) {
+        if (mp) {
+            PolyMfmaArgs ma;
+            memset(&ma, 0, sizeof(ma));
+            ma.in = d_in;
+            ma.out = d_out;
+            ma.hist = r->d_hist[r->cur];
+            ma.A = mp->d_A;
+            ma.n_in = (long long)n_in;
+            ma.in_stride = (long long)in_stride;
+            ma.out_stride = (long long)out_stride;
+            ma.n_out = K;
+            ma.hl = r->hl;
+            ma.GS = mp->GS;
+            ma.RG = mp->RG;
+            ma.Kp = mp->Kp;
+            ma.u_lo = mp->u_lo;
+            rc = launch_poly_mfma(ma, r->n_channels, s);
+        } else if (pl) {
             PolyTiledArgs ta;
             ta.in = d_in;
             ta.out = d_out;

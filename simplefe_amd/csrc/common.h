@@ -11,6 +11,19 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 namespace sfe {
 
+// Workgroup barrier for LDS hand-offs that does NOT drain global memory: __syncthreads() emits
+// s_waitcnt vmcnt(0) lgkmcnt(0), which stalls every wave until its prefetch loads and streaming
+// stores have completed; the LDS exchange only needs lgkmcnt(0).  (cdna_hip_programming.md,
+// 'Pipelining across barriers'.)
+__device__ __forceinline__ void lds_barrier()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#endif
+}
+
 void set_error(const char *fmt, ...);
 int hip_fail(hipError_t e, const char *what);
 
@@ -83,6 +96,30 @@ struct PolyTiledArgs {
 int launch_poly_tiled(const PolyTiledPlan &plan, const PolyTiledArgs &a, int data_complex, int exact,
                       int n_channels, hipStream_t s);
 bool poly_tiled_supported(int SP, int UP, int Lp);
+
+// f32-MFMA form of the same integer-step law (fused multiply-add numerics only).  Outputs are
+// taken in groups of RG = UP*DM consecutive outputs (DM consecutive m, RG <= 16) that read a
+// window of Kp input samples starting GS = SP*DM samples apart: D[16 x 16] += A[16 x 4] B[4 x 16]
+// with rows = outputs of a group, columns = (group, re|im), K = window position.  The host
+// builds A (taps, zero where a row does not reach a window position) in fragment order.
+struct PolyMfmaPlan {
+    int    GS = 0, RG = 0, Kp = 0, u_lo = 0;   // u_lo: window start relative to GS*g
+    float  density = 0.0f;                     // useful MACs / issued MACs
+    float *d_A = nullptr;                      // [Kp/4][64] fragments, K ascending = tap index ascending
+};
+struct PolyMfmaArgs {
+    const void *in;
+    void       *out;
+    const void *hist;
+    const float *A;
+    long long   n_in, in_stride, out_stride, n_out;
+    int         hl, GS, RG, Kp, u_lo;
+    int         x_bytes;   // set by the launcher: bytes of the sample / output tile region
+    int         gs;        // set by the launcher: group spacing inside a column block (bank spread)
+    long long   tiles;     // set by the launcher
+};
+int launch_poly_mfma(const PolyMfmaArgs &a, int n_channels, hipStream_t s);   // cf32 data only
+bool poly_mfma_fits(int GS, int RG, int Kp);
 int launch_poly_sched(const PolyArgs &a, int data_complex, int exact, int n_channels,
                       hipStream_t s);
 

@@ -41,16 +41,30 @@ __device__ __forceinline__ v2f load_sample(const void *p, unsigned lane)
 
 // WAVES = waves per SIMD the register allocator must fit (3 -> <=168 VGPRs, 2 -> <=256);
 // PREFETCH = request transform i+1's rows during transform i's inverse stages.
-template <bool IN_C, bool OUT_C, int WAVES, bool PREFETCH>
+template <bool IN_C, bool OUT_C, int WAVES, bool PREFETCH, bool SWZ>
 __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 {
     __shared__ v2f lds[FFT_ROWS * LDS_K2_STRIDE];
     const unsigned t = threadIdx.x;   // unsigned: lets loads/stores use SGPR base + 32-bit VGPR offset
     const int ch = blockIdx.y;
     const unsigned lo = t & 15, hi = t >> 4;
-    const unsigned base_a = t;                                   // [k2][t]
-    const unsigned base_b = hi * LDS_K2_STRIDE + lo;             // [k2=hi][.][lo]
-    const unsigned base_c = hi * LDS_K2_STRIDE + lo * LDS_K1_STRIDE;  // [k2=hi][k1=lo][.]
+    // LDS cell of element (k2, a, n0), a = n1 or k1:
+    //   padded  (SWZ=0): [k2][n1][n0] -> 272 k2 + 16 n1 + n0,  [k2][k1][n0] -> 272 k2 + 17 k1 + n0
+    //   swizzled(SWZ=1): both             272 k2 + 16 a + (n0 ^ a)
+    // The swizzle keeps every access conflict-free AND makes each stage rewrite exactly the cells
+    // it has just read, which removes the three write-after-read barriers (7 -> 4 per transform)
+    // at the price of one v_xor per access in the two middle exchanges.
+    const unsigned base_a = SWZ ? ((t & ~15u) | ((t ^ (t >> 4)) & 15u)) : t;   // + 272 k2
+    unsigned base_b = hi * LDS_K2_STRIDE + lo;                   // SWZ: (base_b ^ a) + 16 a
+    unsigned base_c = hi * LDS_K2_STRIDE + lo * LDS_K1_STRIDE;   // SWZ: base_c ^ n0
+    auto cell_b1 = [&](int a1) -> unsigned { return SWZ ? ((base_b ^ (unsigned)a1) + 16u * a1) : base_b + 16u * a1; };
+    auto cell_b2 = [&](int a1) -> unsigned { return SWZ ? ((base_b ^ (unsigned)a1) + 16u * a1) : base_b + (unsigned)LDS_K1_STRIDE * a1; };
+    auto cell_c = [&](int n0) -> unsigned { return SWZ ? (base_c ^ (unsigned)n0) : base_c + n0; };
+    // Called before each group of swizzled accesses: makes the base opaque there, so the 16
+    // addresses (base ^ i) are recomputed at the point of use (one v_xor each) instead of being
+    // hoisted out of the transform loop / kept live across a DFT16 (16-32 VGPRs).
+    auto fresh_b = [&]() { if (SWZ) asm volatile("" : "+v"(base_b)); };
+    auto fresh_c = [&]() { if (SWZ) asm volatile("" : "+v"(base_c)); };
 
     const char *in_c = static_cast<const char *>(a.in) + (size_t)ch * a.in_stride * (IN_C ? 8 : 4);
     char *out_c = static_cast<char *>(a.out) + (size_t)ch * a.out_stride * (OUT_C ? 8 : 4);
@@ -105,23 +119,27 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             if (k & 3) x = cmul(x, p1[k & 3]);
             lds[base_a + k * LDS_K2_STRIDE] = x;
         }
-        __syncthreads();
+        lds_barrier();
         // ---- F2: gather n1 for (k2=hi, n0=lo)
+        fresh_b();
 #pragma unroll
-        for (int r = 0; r < 16; r++) v[r] = lds[base_b + 16 * r];
+        for (int r = 0; r < 16; r++) v[r] = lds[cell_b1(r)];
         dft16<-1>(v);
-        __syncthreads();
+        if (!SWZ) lds_barrier();
+        else __builtin_amdgcn_sched_barrier(0);   // keep the stages apart in the scheduler (register pressure)
+        fresh_b();
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             v2f x = v[P16(k)];
             if (k >> 2) x = cmul(x, q2[k >> 2]);
             if (k & 3) x = cmul(x, p2[k & 3]);
-            lds[base_b + k * LDS_K1_STRIDE] = x;
+            lds[cell_b2(k)] = x;
         }
-        __syncthreads();
+        lds_barrier();
         // ---- F3: gather n0 for (k2=hi, k1=lo); spectrum multiply; first inverse stage
+        fresh_c();
 #pragma unroll
-        for (int r = 0; r < 16; r++) v[r] = lds[base_c + r];
+        for (int r = 0; r < 16; r++) v[r] = lds[cell_c(r)];
         dft16<-1>(v);
         {
             // spectrum multiply in place (bin k sits in v[P16(k)]), then the first inverse stage
@@ -131,24 +149,28 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             for (int k = 0; k < 16; k++) v[P16(k)] = cmul(v[P16(k)], (a.hs + k * 256)[t]);
             dft16_rev<+1>(v);
             // I1: element n0 goes back to the cell this thread read n0 from (no barrier needed)
+            fresh_c();
 #pragma unroll
-            for (int k = 0; k < 16; k++) lds[base_c + k] = v[k];
+            for (int k = 0; k < 16; k++) lds[cell_c(k)] = v[k];
         }
-        __syncthreads();
+        lds_barrier();
         if (PREFETCH && blk + gridDim.x < a.nblk) load_rows(nx, blk + gridDim.x);   // see above
         // ---- I2: gather k1 for (k2=hi, n0=lo)
+        fresh_b();
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            v2f x = lds[base_b + r * LDS_K1_STRIDE];
+            v2f x = lds[cell_b2(r)];
             if (r >> 2) x = cmul_conj(x, q2[r >> 2]);
             if (r & 3) x = cmul_conj(x, p2[r & 3]);
             v[r] = x;
         }
         dft16<+1>(v);
-        __syncthreads();
+        if (!SWZ) lds_barrier();
+        else __builtin_amdgcn_sched_barrier(0);   // keep the stages apart in the scheduler (register pressure)
+        fresh_b();
 #pragma unroll
-        for (int k = 0; k < 16; k++) lds[base_b + 16 * k] = v[P16(k)];
-        __syncthreads();
+        for (int k = 0; k < 16; k++) lds[cell_b1(k)] = v[P16(k)];
+        lds_barrier();
         // ---- I3: gather k2 for n_lo = t
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -158,7 +180,8 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             v[r] = x;
         }
         dft16<+1>(v);
-        __syncthreads();   // LDS free for the next transform
+        if (!SWZ) lds_barrier();   // LDS free for the next transform
+        else __builtin_amdgcn_sched_barrier(0);
 
         const long long obase = blk * a.advance - a.hl;   // uniform; + 256*row + t
         constexpr int OSZ = OUT_C ? 8 : 4;
@@ -258,11 +281,11 @@ int launch_fir_fft(const FirFftArgs &a, int in_complex, int out_complex, int n_c
     int variant;
     {
         const char *e = getenv("SFE_FIR_VARIANT");    // re-read per launch: cheap, allows A/B in one process
-        int w = 3, pf = 1;             // default: 3 waves/SIMD (162 VGPRs) + prefetch
-        if (e && e[0] >= '2' && e[0] <= '4') { w = e[0] - '0'; pf = (e[1] != 'n'); }
-        variant = w * 2 + pf;
+        int w = 3, pf = 1, sw = 0;     // default: 3 waves/SIMD (162 VGPRs) + prefetch
+        if (e && e[0] >= '2' && e[0] <= '4') { w = e[0] - '0'; pf = (e[1] != 'n'); sw = (e[1] && e[2] == 's'); }
+        variant = w * 2 + pf + (sw ? 16 : 0);
     }
-    int wg_per_cu = 2 * (variant >> 1);   // 2 x resident: finer tail balance (measured +2%)
+    int wg_per_cu = 2 * ((variant & 15) >> 1);   // 2 x resident: finer tail balance (measured +2%)
     const char *ev = getenv("SFE_FIR_VARIANT");
     const bool copy_only = ev && (ev[0] == 'c' || ev[0] == 'd' || ev[0] == 'e');
     if (const char *e = getenv("SFE_FIR_WG_PER_CU")) wg_per_cu = atoi(e) > 0 ? atoi(e) : wg_per_cu;
@@ -271,14 +294,15 @@ int launch_fir_fft(const FirFftArgs &a, int in_complex, int out_complex, int n_c
     const long long cap = (256LL * wg_per_cu + n_channels - 1) / n_channels;
     if (gx > cap) gx = cap < 1 ? 1 : cap;
     dim3 grid((unsigned)gx, (unsigned)n_channels), block(256);
-#define SFE_LAUNCH(IC, OC)                                                                          \
-    switch (variant) {                                                                              \
-    case 4: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 2, false>), grid, block, 0, s, a); break; \
-    case 5: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 2, true>), grid, block, 0, s, a); break;  \
-    case 6: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, false>), grid, block, 0, s, a); break; \
-    case 8: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 4, false>), grid, block, 0, s, a); break; \
-    case 9: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 4, true>), grid, block, 0, s, a); break;  \
-    default: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, true>), grid, block, 0, s, a); break; \
+#define SFE_LAUNCH(IC, OC)                                                                                 \
+    switch (variant) {                                                                                     \
+    case 6: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, false, false>), grid, block, 0, s, a); break; \
+    case 8: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 4, false, false>), grid, block, 0, s, a); break; \
+    case 16 + 6: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, false, true>), grid, block, 0, s, a); break; \
+    case 16 + 7: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, true, true>), grid, block, 0, s, a); break;  \
+    case 16 + 8: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 4, false, true>), grid, block, 0, s, a); break; \
+    case 16 + 9: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 4, true, true>), grid, block, 0, s, a); break;  \
+    default: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, true, false>), grid, block, 0, s, a); break; \
     }
     if (copy_only && in_complex && out_complex) {
         if (ev[0] == 'd') hipLaunchKernelGGL((fir_copy_pattern16_kernel<4>), grid, block, 0, s, a);

@@ -13,6 +13,9 @@
 //   poly_sched_kernel : general rate: out[k] = s(P_k)*(1-mu_k) + mu_k*s(P_k+1) with (P_k, mu_k)
 //                       replayed on the host from the reference's float32 recurrence
 //                       (libdsp/resample.cxx:119-150).
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "common.h"
 
 // hipcc contracts a*b+c into an FMA by default (and HIP's __fmul_rn/__fadd_rn are plain * and +
@@ -151,10 +154,17 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
         T v[MAIN];
 #pragma unroll
         for (int i = 0; i < MAIN; i++) v[i] = __builtin_nontemporal_load(src + tid + 256u * i);
+        // cell of local sample s = tid + 256 i:  s = SP (q0 + c_i) + (r0 + d_i) with compile-time
+        // c_i = 256 i / SP, d_i = 256 i % SP and r0 + d_i < 2 SP: one compare instead of a
+        // division by SP per element.
+        const unsigned q0 = tid / SP, r0 = tid % SP;
+        const unsigned cell0 = r0 * ROWLEN + q0;
 #pragma unroll
         for (int i = 0; i < MAIN; i++) {
-            const unsigned s = tid + 256u * i;
-            X[(s % SP) * ROWLEN + s / SP] = v[i];
+            constexpr unsigned W = SP * ROWLEN - 1;         // row wrap: -SP rows, +1 column
+            const unsigned ci = (256u * i) / SP, di = (256u * i) % SP;
+            const unsigned cell = cell0 + di * ROWLEN + ci;
+            X[(r0 + di >= (unsigned)SP) ? cell - W : cell] = v[i];
         }
         for (unsigned s = SP * TM + tid; s < (unsigned)n_tile; s += 256)
             X[(s % SP) * ROWLEN + s / SP] = __builtin_nontemporal_load(src + s);
@@ -244,6 +254,142 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
         P2 *op = reinterpret_cast<P2 *>(out + k0);
 #pragma unroll
         for (int i = 0; i < UP; i++) __builtin_nontemporal_store(Yp[tid + 256 * i], op + tid + 256 * i);
+    }
+}
+
+// ------------------------------------------- integer-step law on the matrix pipe (f32 MFMA)
+// OPT-IN (SFE_RS_MFMA=1), kept as measured evidence.  The 127-tap-per-arm resampler is VALU-bound
+// in the tiled kernel (130 v_pk_fma_f32 per output is its arithmetic floor; 39 % of the HBM
+// roofline).  Grouping RG = UP*DM consecutive outputs makes the tap matrix A[RG x Kp] 78 % dense
+// for that shape, and v_mfma_f32_16x16x4_f32 is an exact k-ordered fmaf chain
+// (cdna_hip_programming.md section 3), so the result equals the fused VALU kernel's bit for bit.
+// Measured on MI355X (2^28 cf32, 5/3): 1.21 ms at 2.14 GHz with the matrix pipe 62 % busy, against
+// 1.10 ms for the VALU kernel at 1.4-1.8 GHz -- same peak rate (64 FLOP/clk/SIMD), 22 % structural
+// zeros, so the VALU form stays the default.  cf32 only: columns are (group, re|im) and B is
+// read straight from the interleaved LDS tile -- no de-interleave.
+//   A fragment, K-step ks: lane l holds A[row = l&15][kk = 4 ks + (l>>4)]
+//   B fragment:            lane l holds B[kk = 4 ks + (l>>4)][col = l&15],  col = 2*group + part
+//   kk ascending = window position DEscending = tap index ascending (the reference's order)
+//   D: lane l, reg i -> row 4 (l>>4) + i, col l&15
+constexpr int MF_NB = 4;            // column blocks (of 8 groups) per wave (the K loop is written out for 4)
+constexpr int MF_G = 4 * MF_NB * 8; // groups per workgroup (4 waves)
+constexpr int MF_LD = 16;           // staged loads per thread: tiles of up to 4096 samples
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 4) void poly_mfma_kernel(PolyMfmaArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n_tile = a.GS * (MF_G - 1) + a.Kp;                 // samples staged per tile
+    v2f *X = reinterpret_cast<v2f *>(smem);
+    float *Af = reinterpret_cast<float *>(smem + a.x_bytes);
+    const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ch = blockIdx.y;
+    const v2f *in = static_cast<const v2f *>(a.in) + (size_t)ch * a.in_stride;
+    const v2f *hist = static_cast<const v2f *>(a.hist) + (size_t)ch * a.hl;
+    v2f *out = static_cast<v2f *>(a.out) + (size_t)ch * a.out_stride;
+
+    // tap fragments: once per (persistent) workgroup
+    const int ksteps = a.Kp >> 2;
+    for (unsigned i = tid; i < (unsigned)ksteps * 64; i += 256) Af[i] = a.A[i];
+
+    // Column block nb of this wave holds the 8 groups  gs*gi + (nb % gs) + 8*gs*(nb / gs):
+    // the spacing gs (1, 2 or 4; chosen by the host) makes the 32 lanes of a ds_read_b32 group
+    // -- 8 groups x {re,im} x 2 window positions -- fall on 32 different LDS banks.
+    const unsigned j = lane & 15, kq = lane >> 4;
+    const unsigned gs = a.gs;
+    unsigned boff[MF_NB];        // float offset of this lane's B element at K-step 0
+#pragma unroll
+    for (int nb = 0; nb < MF_NB; nb++) {
+        const unsigned grp = wave * (8 * MF_NB) + gs * (j >> 1) + ((unsigned)nb % gs) + 8 * gs * ((unsigned)nb / gs);
+        boff[nb] = 2 * a.GS * grp + (j & 1) + 2 * (a.Kp - 1 - (int)kq);
+    }
+    const float *Xf = reinterpret_cast<const float *>(X);
+    const float *ap = Af + lane;
+
+    // Sample tile: up to MF_LD loads per thread, issued one tile AHEAD (they fly during the
+    // K loop of the current tile) and written to LDS at the top of the next iteration.
+    v2f stg[MF_LD];
+    auto fetch = [&](long long tile) {
+        const long long n_org = (long long)a.GS * (tile * MF_G) + a.u_lo;
+        if (n_org >= 0 && n_org + n_tile <= a.n_in) {
+            const v2f *src = in + n_org;
+#pragma unroll
+            for (int i = 0; i < MF_LD; i++)
+                if (tid + 256u * i < (unsigned)n_tile) stg[i] = __builtin_nontemporal_load(src + tid + 256u * i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < MF_LD; i++)
+                if (tid + 256u * i < (unsigned)n_tile) stg[i] = vload<true>(in, hist, n_org + tid + 256u * i, a.n_in, a.hl);
+        }
+    };
+    if ((long long)blockIdx.x < a.tiles) fetch(blockIdx.x);
+    for (long long tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
+        const long long g_first = tile * MF_G;
+#pragma unroll
+        for (int i = 0; i < MF_LD; i++)
+            if (tid + 256u * i < (unsigned)n_tile) X[tid + 256u * i] = stg[i];
+        lds_barrier();
+        if (tile + gridDim.x < a.tiles) fetch(tile + gridDim.x);
+
+        f32x4 acc[MF_NB];
+        f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+        // Software pipeline, two register sets (0: even K-steps, 1: odd), no copies: the fragments
+        // of step ks+1 are in flight while step ks multiplies.  bq[] walk DOWN 4 samples per step
+        // (ascending tap index); offsets stay non-negative for the ds_read immediate field.
+        const float *aq = ap;                         // step ks at aq[0], ks+1 at aq[64]
+        const float *bq0 = Xf + boff[0] - 8, *bq1 = Xf + boff[1] - 8, *bq2 = Xf + boff[2] - 8, *bq3 = Xf + boff[3] - 8;
+        float a0 = aq[0], a1;                         // bq*: step ks at [8], step ks+1 at [0]
+        float b00 = bq0[8], b01 = bq1[8], b02 = bq2[8], b03 = bq3[8], b10, b11, b12, b13;
+#define SFE_MF4(A, B0, B1, B2, B3)                                                   \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A, B0, acc0, 0, 0, 0);                 \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A, B1, acc1, 0, 0, 0);                 \
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(A, B2, acc2, 0, 0, 0);                 \
+    acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(A, B3, acc3, 0, 0, 0);
+        int ks = 0;
+        for (; ks + 2 < ksteps; ks += 2) {            // steady state: both prefetches unconditional
+            a1 = aq[64];
+            b10 = bq0[0]; b11 = bq1[0]; b12 = bq2[0]; b13 = bq3[0];
+            SFE_MF4(a0, b00, b01, b02, b03)
+            aq += 128;
+            bq0 -= 16; bq1 -= 16; bq2 -= 16; bq3 -= 16;
+            a0 = aq[0];
+            b00 = bq0[8]; b01 = bq1[8]; b02 = bq2[8]; b03 = bq3[8];
+            SFE_MF4(a1, b10, b11, b12, b13)
+        }
+        SFE_MF4(a0, b00, b01, b02, b03)               // step ks (set 0 is loaded)
+        if (ks + 1 < ksteps) {                        // even K-step count: one more
+            a1 = aq[64];
+            b10 = bq0[0]; b11 = bq1[0]; b12 = bq2[0]; b13 = bq3[0];
+            SFE_MF4(a1, b10, b11, b12, b13)
+        }
+#undef SFE_MF4
+        acc[0] = acc0; acc[1] = acc1; acc[2] = acc2; acc[3] = acc3;
+        lds_barrier();                   // everyone is done with X: reuse it for the output tile
+
+        // D -> linear output tile Y[RG * group + row] (complex), then whole-line stores
+        float *Yf = reinterpret_cast<float *>(X);
+#pragma unroll
+        for (int nb = 0; nb < MF_NB; nb++) {
+            const unsigned grp = wave * (8 * MF_NB) + gs * (j >> 1) + ((unsigned)nb % gs) + 8 * gs * ((unsigned)nb / gs);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const unsigned row = 4 * kq + i;
+                if ((int)row < a.RG) Yf[2 * (a.RG * grp + row) + (j & 1)] = acc[nb][i];
+            }
+        }
+        lds_barrier();
+        const long long k0 = (long long)a.RG * g_first;
+        const int n_y = a.RG * MF_G;
+        const v2f *Y = reinterpret_cast<const v2f *>(Yf);
+        if (k0 + n_y <= a.n_out && ((reinterpret_cast<uintptr_t>(out + k0) & 15) == 0) && (n_y & 1) == 0) {
+            const v4f *Y4 = reinterpret_cast<const v4f *>(Y);
+            v4f *o4 = reinterpret_cast<v4f *>(out + k0);
+            for (unsigned i = tid; i < (unsigned)(n_y / 2); i += 256) __builtin_nontemporal_store(Y4[i], o4 + i);
+        } else {
+            for (unsigned i = tid; i < (unsigned)n_y; i += 256)
+                if (k0 + i < a.n_out) out[k0 + i] = Y[i];
+        }
+        lds_barrier();                   // Y is read out before the next tile overwrites X
     }
 }
 
@@ -388,6 +534,63 @@ int launch_poly_tiled(const PolyTiledPlan &plan, const PolyTiledArgs &a, int dat
     default: return SFE_ESTATE;
     }
 #undef SFE_T
+    SFE_HIP(hipGetLastError());
+    return SFE_OK;
+}
+
+bool poly_mfma_fits(int GS, int RG, int Kp)
+{
+    if (RG < 1 || RG > 16 || Kp < 4 || (Kp & 3)) return false;
+    const size_t n_tile = (size_t)GS * (MF_G - 1) + Kp;
+    if (n_tile > (size_t)MF_LD * 256) return false;
+    size_t x_bytes = (n_tile * 8 + 15) & ~(size_t)15;
+    const size_t y_bytes = (size_t)RG * MF_G * 8;
+    if (x_bytes < y_bytes) x_bytes = (y_bytes + 15) & ~(size_t)15;
+    return x_bytes + (size_t)(Kp / 4) * 64 * 4 <= 64 * 1024;
+}
+
+int launch_poly_mfma(const PolyMfmaArgs &a, int n_channels, hipStream_t s)
+{
+    if (a.n_out <= 0) return SFE_OK;
+    if (!poly_mfma_fits(a.GS, a.RG, a.Kp)) return SFE_ESTATE;
+    const long long groups = (a.n_out + a.RG - 1) / a.RG;
+    const long long tiles = (groups + MF_G - 1) / MF_G;
+    const size_t n_tile = (size_t)a.GS * (MF_G - 1) + a.Kp;
+    const size_t y_bytes = (size_t)a.RG * MF_G * 8;
+    size_t x_bytes = (n_tile * 8 + 15) & ~(size_t)15;
+    if (x_bytes < y_bytes) x_bytes = (y_bytes + 15) & ~(size_t)15;   // the output tile reuses X
+    const size_t sh = x_bytes + (size_t)(a.Kp / 4) * 64 * 4;
+    PolyMfmaArgs b = a;
+    b.x_bytes = (int)x_bytes;
+    b.tiles = tiles;
+    // group spacing inside a column block: the 32 lanes of a ds_read_b32 group read float
+    // 2*GS*gs*gi + part - 2*kq (gi < 8, part < 2, kq < 2): pick gs so the banks are all distinct
+    b.gs = 1;
+    for (int gs = 1; gs <= 4; gs *= 2) {
+        unsigned seen = 0;
+        bool ok = true;
+        for (int gi = 0; gi < 8 && ok; gi++)
+            for (int part = 0; part < 2 && ok; part++)
+                for (int kq = 0; kq < 2 && ok; kq++) {
+                    const unsigned bank = (unsigned)(2 * a.GS * gs * gi + part + 64 - 2 * kq) & 31u;
+                    if (seen & (1u << bank)) ok = false;
+                    seen |= 1u << bank;
+                }
+        if (ok) { b.gs = gs; break; }
+    }
+    // persistent grid = what is co-resident (occupancy API; a larger grid runs in two waves of
+    // workgroups and halves the average occupancy)
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, poly_mfma_kernel, 256, sh) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    if (const char *e = getenv("SFE_MFMA_WG_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
+    long long gx = tiles;
+    const long long cap = (256LL * per_cu + n_channels - 1) / n_channels;
+    if (gx > cap) gx = cap;
+    dim3 grid((unsigned)gx, (unsigned)n_channels), block(256);
+    if (getenv("SFE_DEBUG_OCC"))
+        fprintf(stderr, "poly_mfma: lds %zu B, grid %lld, tiles %lld, gs %d, %d blocks/CU\n", sh, gx, tiles, b.gs, per_cu);
+    hipLaunchKernelGGL(poly_mfma_kernel, grid, block, sh, s, b);
     SFE_HIP(hipGetLastError());
     return SFE_OK;
 }

@@ -297,3 +297,29 @@ def test_converters_bit_exact(api, L, orc):
     api.check(lib.sfe_dsp_tx_f32_to_10bit(d_x.ptr, d_o.ptr, len(x), None))
     out = d_o.to_numpy().view(np.uint8)[: len(x) // 4 * 5]
     assert np.array_equal(out, orc.tx_f32_to_10bit(x))
+
+
+# ------------------------------------------------- matrix-pipe (f32 MFMA) polyphase path
+@pytest.mark.parametrize("name,force", [("cfg3", True), ("cfg4", True), ("gen2_int", True)])
+@pytest.mark.parametrize("chunk", [None, 5000, 1001])
+def test_rs_bulk_mfma_path_cf32(api, L, orc, g5, monkeypatch, name, force, chunk):
+    """The opt-in f32-MFMA form of the bulk path (SFE_RS_MFMA=1) on cf32 data: 5/3 resampler
+    (78 % dense tap matrix), 7/3 (odd step), and decimate/8, whose plan does not fit and must fall
+    back to the VALU kernel silently.  Versus the oracle, I and Q as
+    two real passes; chunked calls exercise every carried pos0."""
+    if force:
+        monkeypatch.setenv("SFE_RS_MFMA", "1")
+    if name == "gen2_int":
+        taps, U, rate = g5["cfg3_taps"], 3, 7.0 / 3.0
+    else:
+        taps, U, rate = g5[f"{name}_taps"], int(g5[f"{name}_U"]), float(g5[f"{name}_rate"])
+    n, nch = 40000, 2
+    x = np.stack([synth.synth_cf32(n, ch=c) for c in range(nch)])
+    r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=True, n_channels=nch)
+    y = r.resample_array(x, rate, chunk=chunk)
+    for c in range(nch):
+        for part in (0, 1):
+            ref, _ = orc.Resample(taps, U, 4096).stream(x[c, part::2], rate)
+            got = y[c, part::2]
+            assert len(ref) - len(got) <= 1
+            assert synth.rel_rms(got, ref[: len(got)]) <= TOL, (c, part)
