@@ -41,7 +41,9 @@ __device__ __forceinline__ v2f load_sample(const void *p, unsigned lane)
 
 // WAVES = waves per SIMD the register allocator must fit (3 -> <=168 VGPRs, 2 -> <=256);
 // PREFETCH = request transform i+1's rows during transform i's inverse stages.
-template <bool IN_C, bool OUT_C, int WAVES, bool PREFETCH, bool SWZ>
+// HREG = keep this thread's 16 bins of H/N in registers (32 VGPRs) instead of re-reading 32 KiB
+// from L2 per transform (that stream shares the CU's vector-memory path with the samples).
+template <bool IN_C, bool OUT_C, int WAVES, bool PREFETCH, bool SWZ, bool HREG = false>
 __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 {
     __shared__ v2f lds[FFT_ROWS * LDS_K2_STRIDE];
@@ -83,6 +85,14 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
     }
 
     const int row0 = a.hl >> 8;   // rows discarded by overlap-save
+    v2f hreg[16];
+    if (HREG) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            hreg[k] = (a.hs + k * 256)[t];
+            asm volatile("" : "+v"(hreg[k]));   // pin: otherwise the load is sunk back into the loop
+        }
+    }
 
     // Loads one transform's 16 rows (thread t: samples base + t + 256 r) into registers.
     auto load_rows = [&](v2f (&x)[16], long long blk) {
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             // with the transposed schedule, which consumes exactly that order: no shuffling.
             // H/N for this thread's 16 bins is streamed from L2 each transform.
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[P16(k)] = cmul(v[P16(k)], (a.hs + k * 256)[t]);
+            for (int k = 0; k < 16; k++) v[P16(k)] = cmul(v[P16(k)], HREG ? hreg[k] : (a.hs + k * 256)[t]);
             dft16_rev<+1>(v);
             // I1: element n0 goes back to the cell this thread read n0 from (no barrier needed)
             fresh_c();
@@ -281,11 +291,12 @@ int launch_fir_fft(const FirFftArgs &a, int in_complex, int out_complex, int n_c
     int variant;
     {
         const char *e = getenv("SFE_FIR_VARIANT");    // re-read per launch: cheap, allows A/B in one process
-        int w = 3, pf = 1, sw = 0;     // default: 3 waves/SIMD (162 VGPRs) + prefetch
-        if (e && e[0] >= '2' && e[0] <= '4') { w = e[0] - '0'; pf = (e[1] != 'n'); sw = (e[1] && e[2] == 's'); }
-        variant = w * 2 + pf + (sw ? 16 : 0);
+        int w = 4, pf = 0, sw = 0, hr = 1;   // default "4n.h": 4 waves/SIMD (124 VGPRs), no prefetch, H in registers
+        if (e && e[0] >= '2' && e[0] <= '4') { w = e[0] - '0'; pf = (e[1] != 'n'); sw = (e[1] && e[2] == 's'); hr = (e[1] && e[2] && e[3] == 'h') || (e[1] && e[2] == 'h'); }
+        variant = w * 2 + pf + (sw ? 16 : 0) + (hr ? 32 : 0);
     }
-    int wg_per_cu = 2 * ((variant & 15) >> 1);   // 2 x resident: finer tail balance (measured +2%)
+    int wg_per_cu = 2 * ((variant & 15) >> 1);
+    if ((variant & 32) && (variant & 15) >> 1 == 2) wg_per_cu = 4;   // 2 x resident: finer tail balance (measured +2%)
     const char *ev = getenv("SFE_FIR_VARIANT");
     const bool copy_only = ev && (ev[0] == 'c' || ev[0] == 'd' || ev[0] == 'e');
     if (const char *e = getenv("SFE_FIR_WG_PER_CU")) wg_per_cu = atoi(e) > 0 ? atoi(e) : wg_per_cu;
@@ -298,11 +309,18 @@ int launch_fir_fft(const FirFftArgs &a, int in_complex, int out_complex, int n_c
     switch (variant) {                                                                                     \
     case 6: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, false, false>), grid, block, 0, s, a); break; \
     case 8: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 4, false, false>), grid, block, 0, s, a); break; \
+    case 32 + 6: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, false, false, true>), grid, block, 0, s, a); break; \
+    case 32 + 16 + 6: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, false, true, true>), grid, block, 0, s, a); break; \
+    case 32 + 5: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 2, true, false, true>), grid, block, 0, s, a); break; \
+    case 32 + 7: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, true, false, true>), grid, block, 0, s, a); break; \
+    case 32 + 8: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 4, false, false, true>), grid, block, 0, s, a); break; \
+    case 32 + 16 + 8: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 4, false, true, true>), grid, block, 0, s, a); break; \
     case 16 + 6: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, false, true>), grid, block, 0, s, a); break; \
     case 16 + 7: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, true, true>), grid, block, 0, s, a); break;  \
     case 16 + 8: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 4, false, true>), grid, block, 0, s, a); break; \
     case 16 + 9: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 4, true, true>), grid, block, 0, s, a); break;  \
-    default: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, true, false>), grid, block, 0, s, a); break; \
+    case 7: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, true, false>), grid, block, 0, s, a); break; \
+    default: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 4, false, false, true>), grid, block, 0, s, a); break; \
     }
     if (copy_only && in_complex && out_complex) {
         if (ev[0] == 'd') hipLaunchKernelGGL((fir_copy_pattern16_kernel<4>), grid, block, 0, s, a);
