@@ -104,6 +104,11 @@ int sfe_dsp_fir_process_block(sfe_fir_t h);
  * data or taps are complex, else real. */
 int sfe_dsp_fir_process_stream(sfe_fir_t h, const void *d_in, void *d_out, size_t n,
                                size_t in_stride, size_t out_stride, sfe_stream_t stream);
+/* Host-pointer form of the bulk law for ONE channel and any n: H2D, kernel, D2H through pinned
+ * staging owned by the handle, synchronous, state carried.  This is what a GNU Radio
+ * work(noutput_items, in, out) adapter calls (include/gr_sfe/): gr-simplefe's blocks hand
+ * host buffers of scheduler-chosen length (gr-simplefe/lib/source_c_impl.cc:134-153). */
+int sfe_dsp_fir_process_host(sfe_fir_t h, const void *in, void *out, size_t n);
 int sfe_dsp_fir_set_algo(sfe_fir_t h, int algo);
 /* Zero the carried state (a fresh blkconv object: blkconv.cxx:52-55). */
 int sfe_dsp_fir_reset(sfe_fir_t h);

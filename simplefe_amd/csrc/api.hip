@@ -211,6 +211,9 @@ struct Fir {
     // class-compatible host block path
     float *h_buf = nullptr;     // pinned, block_hint+2 floats (blkconv.cxx:44 sizes it so)
     void *d_blk_in = nullptr, *d_blk_out = nullptr;
+    // host-pointer streaming path (sfe_dsp_fir_process_host): chunked pinned + device staging
+    void *h_stage = nullptr, *d_st_in = nullptr, *d_st_out = nullptr;
+    size_t stage_samples = 0;
     hipStream_t stream = nullptr;
     size_t hist_bytes() const { return (size_t)n_channels * hl * (data_complex ? 8 : 4); }
 };
@@ -229,6 +232,9 @@ static void fir_free(Fir *f)
     if (f->h_buf) (void)hipHostFree(f->h_buf);
     if (f->d_blk_in) (void)hipFree(f->d_blk_in);
     if (f->d_blk_out) (void)hipFree(f->d_blk_out);
+    if (f->h_stage) (void)hipHostFree(f->h_stage);
+    if (f->d_st_in) (void)hipFree(f->d_st_in);
+    if (f->d_st_out) (void)hipFree(f->d_st_out);
     if (f->stream) (void)hipStreamDestroy(f->stream);
     delete f;
 }
@@ -707,6 +713,41 @@ int sfe_dsp_fir_process_stream(sfe_fir_t h, const void *d_in, void *d_out, size_
     }
     SFE_HIP(hipSetDevice(f->device));
     return fir_run(f, d_in, d_out, n, in_stride, out_stride, (hipStream_t)stream);
+}
+
+int sfe_dsp_fir_process_host(sfe_fir_t h, const void *in, void *out, size_t n)
+{
+    Fir *f = static_cast<Fir *>(h);
+    if (!f || (n && (!in || !out))) {
+        set_error("fir_process_host: null handle or buffer");
+        return SFE_EINVAL;
+    }
+    if (f->n_channels != 1) {
+        set_error("fir_process_host: single-channel handles only");
+        return SFE_EINVAL;
+    }
+    SFE_HIP(hipSetDevice(f->device));
+    const size_t in_e = f->data_complex ? 8 : 4, out_e = f->out_complex ? 8 : 4;
+    const size_t CH = (size_t)1 << 20;            // samples per staged chunk
+    if (!f->h_stage) {
+        SFE_HIP(hipHostMalloc(&f->h_stage, CH * (in_e > out_e ? in_e : out_e)));
+        SFE_HIP(hipMalloc(&f->d_st_in, CH * in_e));
+        SFE_HIP(hipMalloc(&f->d_st_out, CH * out_e));
+        f->stage_samples = CH;
+    }
+    const char *ip = static_cast<const char *>(in);
+    char *op = static_cast<char *>(out);
+    for (size_t off = 0; off < n; off += CH) {
+        const size_t m = n - off < CH ? n - off : CH;
+        memcpy(f->h_stage, ip + off * in_e, m * in_e);
+        SFE_HIP(hipMemcpyAsync(f->d_st_in, f->h_stage, m * in_e, hipMemcpyHostToDevice, f->stream));
+        int rc = fir_run(f, f->d_st_in, f->d_st_out, m, m, m, f->stream);
+        if (rc != SFE_OK) return rc;
+        SFE_HIP(hipMemcpyAsync(f->h_stage, f->d_st_out, m * out_e, hipMemcpyDeviceToHost, f->stream));
+        SFE_HIP(hipStreamSynchronize(f->stream));
+        memcpy(op + off * out_e, f->h_stage, m * out_e);
+    }
+    return SFE_OK;
 }
 
 int sfe_dsp_fir_set_algo(sfe_fir_t h, int algo)

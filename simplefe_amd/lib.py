@@ -46,6 +46,7 @@ SIGNATURES = {
     "sfe_dsp_fir_host_buffer": (i32, [vp, C.POINTER(fp), C.POINTER(i32)]),
     "sfe_dsp_fir_process_block": (i32, [vp]),
     "sfe_dsp_fir_process_stream": (i32, [vp, vp, vp, sz, sz, sz, vp]),
+    "sfe_dsp_fir_process_host": (i32, [vp, vp, vp, sz]),
     "sfe_dsp_fir_set_algo": (i32, [vp, i32]),
     "sfe_dsp_fir_reset": (i32, [vp]),
     "sfe_dsp_fir_destroy": (i32, [vp]),

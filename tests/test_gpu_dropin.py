@@ -57,3 +57,53 @@ def test_cxx_resampler_classes_bit_exact(dropin_exe, g4, cls, tmp_path):
     assert r.returncode == 0, r.stderr
     assert [int(t) for t in r.stdout.split()] == g4["n_1p77"].tolist()
     assert np.array_equal(np.fromfile(tmp_path / "y.f32", dtype=np.float32), g4["y_1p77"])
+
+
+# ----------------------------------------------------- GNU-Radio-shaped adapters (N1)
+@pytest.fixture(scope="module")
+def gr_exe(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("gr") / "test_gr_blocks")
+    r = subprocess.run(["g++", "-O1", "-std=c++11", os.path.join(ROOT, "tests/host/test_gr_blocks.cpp"), "-o", exe,
+                        "-L" + LIBDIR, "-lsfe_dsp", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib",
+                        "-Wl,--allow-shlib-undefined"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def _run_gr(gr_exe, tmp_path, kind, taps, x_il, *extra):
+    taps.astype(np.float32).tofile(tmp_path / "t.f32")
+    x_il.astype(np.float32).tofile(tmp_path / "x.f32")
+    r = subprocess.run([gr_exe, kind, str(tmp_path / "t.f32"), str(tmp_path / "x.f32"), str(tmp_path / "y.f32"),
+                        *[str(e) for e in extra]], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return np.fromfile(tmp_path / "y.f32", dtype=np.float32)
+
+
+def test_gr_fir_ccf_block(gr_exe, tmp_path):
+    """work() called with scheduler-sized item counts; result == one streaming convolution."""
+    from simplefe_amd import synth
+    taps = synth.taps_cfg2()
+    n = 60000
+    x = synth.synth_cf32(n)
+    y = _run_gr(gr_exe, tmp_path, "fir", taps, x)
+    for part in (0, 1):
+        ref = np.convolve(x[part::2].astype(np.float64), taps.astype(np.float64))[:n]
+        assert synth.rel_rms(y[part::2], ref) <= 1e-5
+
+
+def test_gr_decimate_and_resampler_blocks_bit_exact(gr_exe, tmp_path, g5, orc):
+    """sync_decimator by 8 and rational resampler 3/5 over cf32, against the oracle's real
+    passes: integer-valued steps, so the scheduler's chunking does not show (bit-exact)."""
+    from simplefe_amd import synth
+    n = 40000
+    x = synth.synth_cf32(n)
+    y = _run_gr(gr_exe, tmp_path, "decimate", g5["cfg4_taps"], x, 8)
+    for part in (0, 1):
+        ref, _ = orc.Decimate(g5["cfg4_taps"], 1, 4096).stream(x[part::2], 8.0)
+        got = y[part::2]
+        assert len(ref) - len(got) <= 1 and np.array_equal(got, ref[: len(got)])
+    y = _run_gr(gr_exe, tmp_path, "resample", g5["cfg3_taps"], x, 5, 3)
+    for part in (0, 1):
+        ref, _ = orc.Resample(g5["cfg3_taps"], 3, 4096).stream(x[part::2], 5.0 / 3.0)
+        got = y[part::2]
+        assert len(ref) - len(got) <= 2 and np.array_equal(got, ref[: len(got)])

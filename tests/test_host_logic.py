@@ -158,6 +158,16 @@ def test_dropin_headers_compile_and_link(L, tmp_path):
     assert r.returncode == 0, r.stderr
 
 
+def test_gr_shaped_blocks_compile_and_link(L, tmp_path):
+    """include/gr_sfe/blocks.h against the stand-in runtime header (GNU Radio is not installed)."""
+    exe = str(tmp_path / "gr")
+    libdir = os.path.join(ROOT, "simplefe_amd")
+    r = _cxx(["g++", "-O1", "-Wall", "-std=c++11", os.path.join(ROOT, "tests/host/test_gr_blocks.cpp"), "-o", exe,
+              "-L" + libdir, "-lsfe_dsp", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
+              "-Wl,--allow-shlib-undefined"])
+    assert r.returncode == 0, r.stderr
+
+
 def test_reference_own_test_program_builds_against_dropin_header(L):
     """libdsp/test/test_blkconv.cxx, unmodified, against include/blkconv.h (oracle/Makefile
     `dropin`); only where /root/reference exists."""
