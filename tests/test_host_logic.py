@@ -65,9 +65,10 @@ def test_product_tree_never_touches_the_oracle():
                 txt = open(os.path.join(base, f), errors="replace").read()
                 if re.search(r"oracle[./]|liboracle|sfe_oracle|libsferef", txt):
                     bad.append(os.path.join(base, f))
-    for f in os.listdir(INC):
-        if re.search(r"liboracle|sfe_oracle|libsferef", open(os.path.join(INC, f)).read()):
-            bad.append(f)
+    for base, _, files in os.walk(INC):
+        for f in files:
+            if re.search(r"liboracle|sfe_oracle|libsferef", open(os.path.join(base, f)).read()):
+                bad.append(f)
     assert not bad, bad
     out = subprocess.run(["ldd", os.path.join(ROOT, "simplefe_amd", "libsfe_dsp.so")], capture_output=True, text=True).stdout
     assert "oracle" not in out and "sferef" not in out
