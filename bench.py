@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--algo", default="auto", choices=["auto", "fft", "direct"])
     ap.add_argument("--channels", type=int, default=None,
                     help="channels per GPU (default 1 at N=1, 8 at N>1: the 64-channel config over 8 GPUs)")
+    ap.add_argument("--input", default="f32", choices=["f32", "u8"],
+                    help="u8: the stream is the device wire format, converted on load (fused RX converter, N2)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -171,29 +173,46 @@ def main():
     for c in range(nch):
         gch = shard.channel_block(nch * world, world, rank)[0] + c      # global channel id = its seed
         api.check(L.sfe_dsp_synth_fill(x.data_ptr() + c * n * 8, 2 * n, synth.SEED, gch, 0, stream))
+    in_bytes = 8.0
+    if args.input == "u8":
+        # wire format: (I,Q) byte pairs.  Derived from the float stream so the parity legs below
+        # still have a float twin: b = round(127 x) + 128, i.e. x_u8 = (b - 128)/127.
+        xb = (torch.round(x * 127.0) + 128.0).clamp_(0, 255).to(torch.uint8)
+        x = ((xb.to(torch.float32) - 128.0) * (1.0 / 127.0))          # the float twin (exact)
+        in_bytes = 2.0
+        key += "_u8"
+        workload += ", u8 (I,Q) wire-format input converted on load"
     if wl == "fir":
         n_out = n
         y = torch.empty(nch * n * 2, dtype=torch.float32, device=dev)
         obj = api.Fir(taps, data_complex=True, n_channels=nch, device=local_rank,
                       algo={"auto": lib.FIR_ALGO_AUTO, "fft": lib.FIR_ALGO_FFT, "direct": lib.FIR_ALGO_DIRECT}[args.algo])
-        bytes_per_launch = 16.0 * n_gpu          # 8 B read + 8 B written per sample
-        kernel = "fir_fft4096_kernel" if args.algo != "direct" else "poly_int_kernel"
+        bytes_per_launch = (in_bytes + 8.0) * n_gpu   # 8 B (2 B for u8) read + 8 B written per sample
+        kernel = "fir_fft4096_kernel" if args.algo != "direct" else "poly_tiled_kernel"
+        src = x
+        if args.input == "u8":
+            obj.set_input_format(lib.FMT_U8)
+            src = xb
 
         def step():
-            obj.process_stream(x.data_ptr(), y.data_ptr(), n, stream=stream)
+            obj.process_stream(src.data_ptr(), y.data_ptr(), n, stream=stream)
     else:
         out_cap = int(n / rate) + 8
         y = torch.empty(nch * out_cap * 2, dtype=torch.float32, device=dev)
         obj = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE if wl == "resample" else lib.RS_DECIMATE,
                      data_complex=True, n_channels=nch, device=local_rank)
         n_out_box = [0]
-        kernel = "poly_int_kernel"
+        kernel = "poly_tiled_kernel"
+        src = x
+        if args.input == "u8":
+            obj.set_input_format(lib.FMT_U8)
+            src = xb
 
         def step():
-            n_out_box[0] = obj.process_stream(x.data_ptr(), n, y.data_ptr(), out_cap, rate, stream=stream)
+            n_out_box[0] = obj.process_stream(src.data_ptr(), n, y.data_ptr(), out_cap, rate, stream=stream)
         step()
         n_out = n_out_box[0]
-        bytes_per_launch = 8.0 * n_gpu + 8.0 * n_out * nch
+        bytes_per_launch = in_bytes * n_gpu + 8.0 * n_out * nch
         rs_parity = [float("nan")]
         if rank == 0:
             # parity of the first (fresh-state) pass on windows: output k sits at upsampled

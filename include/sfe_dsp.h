@@ -110,6 +110,15 @@ int sfe_dsp_fir_process_stream(sfe_fir_t h, const void *d_in, void *d_out, size_
  * host buffers of scheduler-chosen length (gr-simplefe/lib/source_c_impl.cc:134-153). */
 int sfe_dsp_fir_process_host(sfe_fir_t h, const void *in, void *out, size_t n);
 int sfe_dsp_fir_set_algo(sfe_fir_t h, int algo);
+/* Fused receive converter: with SFE_FMT_U8 the bulk call reads the device
+ * wire format directly -- u8 offset binary, one byte per real sample or an (I,Q) byte pair per
+ * complex sample -- converting (b-128)*(1/127) on load exactly as fill_rx_buffer does
+ * (gr-simplefe/lib/source_c_impl.cc:121-132, source_f_impl.cc:120-129): 2 bytes instead of 8
+ * per complex sample from HBM and no separate conversion pass.  in_stride stays in samples.
+ * Applies to *_process_stream only. */
+#define SFE_FMT_F32 0
+#define SFE_FMT_U8  1
+int sfe_dsp_fir_set_input_format(sfe_fir_t h, int fmt);
 /* Zero the carried state (a fresh blkconv object: blkconv.cxx:52-55). */
 int sfe_dsp_fir_reset(sfe_fir_t h);
 /* Replaces blkconv::~blkconv()  libdsp/blkconv.cxx:113-122. */
@@ -146,6 +155,8 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
 /* exact = 1: separate multiply and add in the reference's order (bit-exact with the CPU
  * classes); exact = 0 (default for *_stream): fused multiply-add, same order. */
 int sfe_dsp_rs_set_exact(sfe_rs_t h, int exact);
+/* As sfe_dsp_fir_set_input_format, for the integer-step bulk path (fused numerics). */
+int sfe_dsp_rs_set_input_format(sfe_rs_t h, int fmt);
 int sfe_dsp_rs_reset(sfe_rs_t h);
 int sfe_dsp_rs_destroy(sfe_rs_t h);
 

@@ -50,6 +50,15 @@ class DeviceArray:
         check(d._L.sfe_dsp_sync(stream))
         return d
 
+    @classmethod
+    def from_bytes(cls, b, stream=None):
+        """Device copy of a uint8 array (the u8 wire format), padded to whole floats."""
+        b = np.ascontiguousarray(b, dtype=np.uint8).ravel()
+        d = cls((b.size + 3) // 4 + 4)
+        check(d._L.sfe_dsp_memcpy_h2d(d.ptr, b.ctypes.data, b.nbytes, stream))
+        check(d._L.sfe_dsp_sync(stream))
+        return d
+
     def to_numpy(self, n_floats=None, offset=0, stream=None):
         n = self.n - offset if n_floats is None else int(n_floats)
         out = np.empty(n, dtype=np.float32)
@@ -125,6 +134,10 @@ class Fir:
     def set_algo(self, algo):
         check(self._L.sfe_dsp_fir_set_algo(self._h, algo))
 
+    def set_input_format(self, fmt):
+        """lib.FMT_U8: process_stream reads u8 offset-binary samples (fused RX converter)."""
+        check(self._L.sfe_dsp_fir_set_input_format(self._h, fmt))
+
     def reset(self):
         check(self._L.sfe_dsp_fir_reset(self._h))
 
@@ -182,6 +195,9 @@ class Rs:
 
     def set_exact(self, exact=True):
         check(self._L.sfe_dsp_rs_set_exact(self._h, int(bool(exact))))
+
+    def set_input_format(self, fmt):
+        check(self._L.sfe_dsp_rs_set_input_format(self._h, fmt))
 
     def reset(self):
         check(self._L.sfe_dsp_rs_reset(self._h))

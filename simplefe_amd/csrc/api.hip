@@ -198,7 +198,7 @@ static const PolyMfmaPlan *get_mfma_plan(MfmaCache &cache, const std::vector<flo
 // ------------------------------------------------------------------------------ FIR
 struct Fir {
     int n_taps = 0, taps_complex = 0, data_complex = 0, out_complex = 0, n_channels = 1;
-    int device = 0, algo = SFE_FIR_ALGO_AUTO;
+    int device = 0, algo = SFE_FIR_ALGO_AUTO, in_u8 = 0;
     int blk = 0, block_hint = 0;
     int hl = 0;                 // carried history per channel, samples (multiple of 256)
     bool fft_ok = false;
@@ -317,10 +317,10 @@ static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_st
         a.hl = f->hl;
         a.advance = FFT_N - f->hl;
         a.nblk = ((long long)n + a.advance - 1) / a.advance;
-        rc = launch_fir_fft(a, f->data_complex, f->out_complex, f->n_channels, s);
+        rc = launch_fir_fft(a, f->data_complex, f->out_complex, f->in_u8, f->n_channels, s);
     } else {
-        if (f->taps_complex) {
-            set_error("fir: the direct kernel takes real taps; complex taps need SFE_FIR_ALGO_FFT");
+        if (f->taps_complex || f->in_u8) {
+            set_error("fir: the direct kernel takes real taps and float input; use SFE_FIR_ALGO_FFT");
             return SFE_EINVAL;
         }
         const PolyTiledPlan *pl = get_tiled_plan(f->plans, f->h_taps, 1, f->n_taps, 1, 0, &rc);
@@ -338,7 +338,7 @@ static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_st
             ta.hl = f->hl;
             ta.Lp = pl->Lp;
             ta.e_max = pl->e_max;
-            rc = launch_poly_tiled(*pl, ta, f->data_complex, 0, f->n_channels, s);
+            rc = launch_poly_tiled(*pl, ta, f->data_complex, 0, 0, f->n_channels, s);
         } else {
             PolyArgs a;
             memset(&a, 0, sizeof(a));
@@ -360,7 +360,7 @@ static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_st
     }
     if (rc != SFE_OK) return rc;
     rc = launch_history_update(d_in, (long long)n, (long long)in_stride, f->d_hist[f->cur],
-                               f->d_hist[f->cur ^ 1], f->hl, f->data_complex ? 2 : 1, f->n_channels, s);
+                               f->d_hist[f->cur ^ 1], f->hl, f->data_complex ? 2 : 1, f->n_channels, s, f->in_u8);
     if (rc != SFE_OK) return rc;
     f->cur ^= 1;
     return SFE_OK;
@@ -369,7 +369,7 @@ static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_st
 // ------------------------------------------------------------------ resample / decimate
 struct Rs {
     int U = 1, n_taps = 0, plen = 0, blksize = 0, data_complex = 0, n_channels = 1;
-    int device = 0, mode = SFE_RS_RESAMPLE, exact_stream = 0;
+    int device = 0, mode = SFE_RS_RESAMPLE, exact_stream = 0, in_u8 = 0;
     int hl = 0;
     float *d_taps = nullptr;               // [U][plen] phase-major
     std::vector<float> h_taps_pm;          // host copy of the same (tiled plans)
@@ -707,8 +707,8 @@ int sfe_dsp_fir_process_stream(sfe_fir_t h, const void *d_in, void *d_out, size_
         set_error("fir_process_stream: channel stride smaller than n");
         return SFE_EINVAL;
     }
-    if ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 7) {
-        set_error("fir_process_stream: buffers must be 8-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(d_out) & 7) || (reinterpret_cast<uintptr_t>(d_in) & (f->in_u8 ? 1 : 7))) {
+        set_error("fir_process_stream: buffers must be 8-byte aligned (2-byte for u8 input)");
         return SFE_EINVAL;
     }
     SFE_HIP(hipSetDevice(f->device));
@@ -747,6 +747,18 @@ int sfe_dsp_fir_process_host(sfe_fir_t h, const void *in, void *out, size_t n)
         SFE_HIP(hipStreamSynchronize(f->stream));
         memcpy(op + off * out_e, f->h_stage, m * out_e);
     }
+    return SFE_OK;
+}
+
+int sfe_dsp_fir_set_input_format(sfe_fir_t h, int fmt)
+{
+    Fir *f = static_cast<Fir *>(h);
+    if (!f || (fmt != SFE_FMT_F32 && fmt != SFE_FMT_U8)) return SFE_EINVAL;
+    if (fmt == SFE_FMT_U8 && (!f->fft_ok || f->taps_complex)) {
+        set_error("fir_set_input_format: u8 input needs the FFT kernel with real taps");
+        return SFE_ESTATE;
+    }
+    f->in_u8 = fmt == SFE_FMT_U8;
     return SFE_OK;
 }
 
@@ -982,7 +994,7 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         const PolyMfmaPlan *mp = nullptr;
         {
             const char *e = getenv("SFE_RS_MFMA");
-            if (e && e[0] == '1' && !r->exact_stream && r->data_complex) {
+            if (e && e[0] == '1' && !r->exact_stream && r->data_complex && !r->in_u8) {
                 mp = get_mfma_plan(r->mfma_plans, r->h_taps_pm, r->U, r->plen, (int)S, pos0, &rc);
                 if (rc != SFE_OK) return rc;
             }
@@ -1019,8 +1031,12 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
             ta.hl = r->hl;
             ta.Lp = pl->Lp;
             ta.e_max = pl->e_max;
-            rc = launch_poly_tiled(*pl, ta, r->data_complex, r->exact_stream, r->n_channels, s);
+            rc = launch_poly_tiled(*pl, ta, r->data_complex, r->exact_stream, r->in_u8, r->n_channels, s);
         } else {
+            if (r->in_u8) {
+                set_error("rs_process_stream: u8 input needs a tiled kernel for this rate/tap shape");
+                return SFE_ESTATE;
+            }
             rc = launch_poly_int(a, r->data_complex, 0, r->exact_stream, r->n_channels, s);
         }
         if (rc != SFE_OK) return rc;
@@ -1030,6 +1046,10 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         r->ts.mu = 0.0f;
         *n_out = (size_t)K;
     } else {
+        if (r->in_u8) {
+            set_error("rs_process_stream: u8 input is supported for integer-valued steps only");
+            return SFE_ESTATE;
+        }
         // replay the float32 recurrence chunk by chunk, as the reference object would see it
         sfe_rs_timestate st = r->ts;
         std::vector<long long> pos;
@@ -1066,9 +1086,17 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         *n_out = K;
     }
     rc = launch_history_update(d_in, (long long)n_in, (long long)in_stride, r->d_hist[r->cur],
-                               r->d_hist[r->cur ^ 1], r->hl, r->data_complex ? 2 : 1, r->n_channels, s);
+                               r->d_hist[r->cur ^ 1], r->hl, r->data_complex ? 2 : 1, r->n_channels, s, r->in_u8);
     if (rc != SFE_OK) return rc;
     r->cur ^= 1;
+    return SFE_OK;
+}
+
+int sfe_dsp_rs_set_input_format(sfe_rs_t h, int fmt)
+{
+    Rs *r = static_cast<Rs *>(h);
+    if (!r || (fmt != SFE_FMT_F32 && fmt != SFE_FMT_U8)) return SFE_EINVAL;
+    r->in_u8 = fmt == SFE_FMT_U8;
     return SFE_OK;
 }
 

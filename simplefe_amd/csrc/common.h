@@ -52,7 +52,10 @@ struct FirFftArgs {
     int         advance;  // valid outputs per transform
     long long   nblk;     // transforms per channel
 };
-int launch_fir_fft(const FirFftArgs &a, int in_complex, int out_complex, int n_channels,
+// in_u8: the input stream is the device wire format, u8 offset binary (one byte per real sample,
+// an (I, Q) byte pair per complex sample); it is converted on load, (b - 128) * (1/127)
+// (gr-simplefe/lib/source_c_impl.cc:121-132).  History stays float32.
+int launch_fir_fft(const FirFftArgs &a, int in_complex, int out_complex, int in_u8, int n_channels,
                    hipStream_t s);
 
 struct PolyArgs {
@@ -94,7 +97,7 @@ struct PolyTiledArgs {
 // returns SFE_OK, or SFE_ESTATE when (SP, UP, Lp) has no tiled instantiation (caller falls
 // back to launch_poly_int)
 int launch_poly_tiled(const PolyTiledPlan &plan, const PolyTiledArgs &a, int data_complex, int exact,
-                      int n_channels, hipStream_t s);
+                      int in_u8, int n_channels, hipStream_t s);
 bool poly_tiled_supported(int SP, int UP, int Lp);
 
 // f32-MFMA form of the same integer-step law (fused multiply-add numerics only).  Outputs are
@@ -126,7 +129,10 @@ int launch_poly_sched(const PolyArgs &a, int data_complex, int exact, int n_chan
 // new_hist[i] = virtual[n_in - hl + i], virtual = old_hist ++ in  (per channel)
 int launch_history_update(const void *in, long long n_in, long long in_stride,
                           const void *old_hist, void *new_hist, int hl, int elem_floats,
-                          int n_channels, hipStream_t s);
+                          int n_channels, hipStream_t s, int in_u8 = 0);
+
+// u8 offset binary -> float, bit-exact with the reference converter
+__device__ __forceinline__ float u8_to_f32(unsigned b) { return ((float)b - 128.0f) * (1.0f / 127.0f); }
 
 int launch_synth_fill(float *d, uint64_t n, uint32_t seed, uint32_t ch, uint64_t first,
                       hipStream_t s);

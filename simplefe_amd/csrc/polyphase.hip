@@ -66,6 +66,19 @@ __device__ __forceinline__ typename Elem<CPLX>::T vload(const typename Elem<CPLX
     return (i >= -(long long)hl) ? hist[hl + i] : Elem<CPLX>::zero();
 }
 
+// same virtual stream when the input is u8 offset binary (history is float32 already)
+template <bool CPLX>
+__device__ __forceinline__ typename Elem<CPLX>::T vload_u8(const unsigned char *in, const typename Elem<CPLX>::T *hist,
+                                                           long long i, long long n_in, int hl)
+{
+    if (i >= 0) {
+        if (i >= n_in) return Elem<CPLX>::zero();
+        if constexpr (CPLX) return (v2f){u8_to_f32(in[2 * i]), u8_to_f32(in[2 * i + 1])};
+        else return u8_to_f32(in[i]);
+    }
+    return (i >= -(long long)hl) ? hist[hl + i] : Elem<CPLX>::zero();
+}
+
 // ------------------------------------------------------------------ integer-step law
 // One workgroup = TILE consecutive outputs.  LDS: [tile_in_cap] samples + [U*plen] taps.
 template <bool CPLX, bool EXACT>
@@ -128,7 +141,9 @@ __device__ __forceinline__ v2f pair_hi(v4f p) { return (v2f){p.z, p.w}; }
 __device__ __forceinline__ float pair_lo(v2f p) { return p.x; }
 __device__ __forceinline__ float pair_hi(v2f p) { return p.y; }
 
-template <int SP, int UP, bool CPLX, bool EXACT>
+// IN_U8: the input is the device wire format (u8 offset binary, gr-simplefe source blocks) and
+// is converted while it is staged -- 2 bytes instead of 8 per complex sample from HBM.
+template <int SP, int UP, bool CPLX, bool EXACT, bool IN_U8 = false>
 __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
 {
     typedef typename Elem<CPLX>::T T;
@@ -139,7 +154,8 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
 
     const unsigned tid = threadIdx.x;
     const int ch = blockIdx.y;
-    const T *in = static_cast<const T *>(a.in) + (size_t)ch * a.in_stride;
+    const T *in = static_cast<const T *>(a.in) + (IN_U8 ? 0 : (size_t)ch * a.in_stride);
+    const unsigned char *in8 = static_cast<const unsigned char *>(a.in) + (size_t)ch * a.in_stride * (CPLX ? 2 : 1);
     const T *hist = static_cast<const T *>(a.hist) + (size_t)ch * a.hl;
     T *out = static_cast<T *>(a.out) + (size_t)ch * a.out_stride;
 
@@ -149,7 +165,34 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
     constexpr int MAIN = SP * TM / 256;       // unrolled loads per thread for the body of the tile
 
     // ---- stage: coalesced 8-byte lanes in, transposed into the SP rows
-    if (n_org >= 0 && n_org + n_tile <= a.n_in) {
+    if constexpr (IN_U8) {
+        // 8-byte lanes again, now 4 complex (or 8 real) samples each; the tile start is rounded
+        // down to an 8-byte boundary of the byte stream and the extra samples skipped
+        constexpr int SPL = CPLX ? 4 : 8;                              // samples per 8-byte lane
+        const bool interior = n_org >= 0 && n_org + n_tile + SPL <= a.n_in;
+        if (interior && (reinterpret_cast<uintptr_t>(in8) & 7) == 0) {
+            const long long a0 = n_org & ~(long long)(SPL - 1);
+            const int delta = (int)(n_org - a0);
+            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(in8 + a0 * (CPLX ? 2 : 1));
+            const int nl = (n_tile + delta + SPL - 1) / SPL;
+            for (int l = tid; l < nl; l += 256) {
+                const unsigned long long w = __builtin_nontemporal_load(src + l);
+#pragma unroll
+                for (int q = 0; q < SPL; q++) {
+                    const int s = l * SPL + q - delta;
+                    if (s >= 0 && s < n_tile) {
+                        T v;
+                        if constexpr (CPLX) v = (v2f){u8_to_f32((unsigned)(w >> (16 * q)) & 0xFFu), u8_to_f32((unsigned)(w >> (16 * q + 8)) & 0xFFu)};
+                        else v = u8_to_f32((unsigned)(w >> (8 * q)) & 0xFFu);
+                        X[((unsigned)s % SP) * ROWLEN + (unsigned)s / SP] = v;
+                    }
+                }
+            }
+        } else {
+            for (unsigned s = tid; s < (unsigned)n_tile; s += 256)
+                X[(s % SP) * ROWLEN + s / SP] = vload_u8<CPLX>(in8, hist, n_org + s, a.n_in, a.hl);
+        }
+    } else if (n_org >= 0 && n_org + n_tile <= a.n_in) {
         const T *src = in + n_org;                                       // uniform
         T v[MAIN];
 #pragma unroll
@@ -443,15 +486,18 @@ __global__ __launch_bounds__(256) void poly_sched_kernel(PolyArgs a)
 __global__ __launch_bounds__(256) void history_update_kernel(const float *in, long long n_in,
                                                              long long in_stride,
                                                              const float *old_hist, float *new_hist,
-                                                             int hl, int ef)
+                                                             int hl, int ef, int in_u8)
 {
     const int ch = blockIdx.y;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // float index in [0, hl*ef)
     if (i >= (long long)hl * ef) return;
     const long long src = (n_in - hl) * ef + i;                      // float index in virtual stream
-    const float *inc = in + (size_t)ch * in_stride * ef;
     const float *oh = old_hist + (size_t)ch * hl * ef;
-    new_hist[(size_t)ch * hl * ef + i] = src >= 0 ? inc[src] : oh[(long long)hl * ef + src];
+    float v;
+    if (src < 0) v = oh[(long long)hl * ef + src];
+    else if (in_u8) v = u8_to_f32(reinterpret_cast<const unsigned char *>(in)[(size_t)ch * in_stride * ef + src]);
+    else v = in[(size_t)ch * in_stride * ef + src];
+    new_hist[(size_t)ch * hl * ef + i] = v;
 }
 
 }  // namespace
@@ -505,7 +551,7 @@ bool poly_tiled_supported(int SP, int UP, int Lp)
 }
 
 int launch_poly_tiled(const PolyTiledPlan &plan, const PolyTiledArgs &a, int data_complex, int exact,
-                      int n_channels, hipStream_t s)
+                      int in_u8, int n_channels, hipStream_t s)
 {
     if (a.n_out <= 0) return SFE_OK;
     if (!poly_tiled_supported(plan.SP, plan.UP, plan.Lp)) return SFE_ESTATE;
@@ -517,6 +563,27 @@ int launch_poly_tiled(const PolyTiledPlan &plan, const PolyTiledArgs &a, int dat
     }
     dim3 grid((unsigned)tiles, (unsigned)n_channels), block(256);
     const size_t esz = data_complex ? 8 : 4;
+    if (in_u8) {   // wire-format input: the decimator / resampler shapes a receive chain uses
+        if (exact) {
+            set_error("polyphase: u8 input runs the fused kernels only");
+            return SFE_EINVAL;
+        }
+#define SFE_U8(SPv, UPv)                                                                              \
+    case SPv * 16 + UPv: {                                                                            \
+        const size_t sh = (size_t)SPv * tiled_rowlen(SPv) * esz;                                      \
+        if (data_complex) hipLaunchKernelGGL((poly_tiled_kernel<SPv, UPv, true, false, true>), grid, block, sh, s, a);  \
+        else hipLaunchKernelGGL((poly_tiled_kernel<SPv, UPv, false, false, true>), grid, block, sh, s, a);             \
+    } break;
+        switch (plan.SP * 16 + plan.UP) {
+            SFE_U8(2, 1) SFE_U8(4, 1) SFE_U8(8, 1) SFE_U8(5, 3)
+        default:
+            set_error("polyphase: no u8-input kernel for %d outputs per %d inputs", plan.UP, plan.SP);
+            return SFE_ESTATE;
+        }
+#undef SFE_U8
+        SFE_HIP(hipGetLastError());
+        return SFE_OK;
+    }
 #define SFE_T(SPv, UPv)                                                                               \
     case SPv * 16 + UPv: {                                                                            \
         const size_t sh = (size_t)SPv * tiled_rowlen(SPv) * esz;                                      \
@@ -609,14 +676,14 @@ int launch_poly_sched(const PolyArgs &a, int data_complex, int exact, int n_chan
 }
 
 int launch_history_update(const void *in, long long n_in, long long in_stride, const void *old_hist,
-                          void *new_hist, int hl, int elem_floats, int n_channels, hipStream_t s)
+                          void *new_hist, int hl, int elem_floats, int n_channels, hipStream_t s, int in_u8)
 {
     if (hl <= 0) return SFE_OK;
     const long long nf = (long long)hl * elem_floats;
     dim3 grid((unsigned)((nf + 255) / 256), (unsigned)n_channels), block(256);
     hipLaunchKernelGGL(history_update_kernel, grid, block, 0, s, static_cast<const float *>(in), n_in,
                        in_stride, static_cast<const float *>(old_hist), static_cast<float *>(new_hist),
-                       hl, elem_floats);
+                       hl, elem_floats, in_u8);
     SFE_HIP(hipGetLastError());
     return SFE_OK;
 }

@@ -323,3 +323,68 @@ def test_rs_bulk_mfma_path_cf32(api, L, orc, g5, monkeypatch, name, force, chunk
             got = y[c, part::2]
             assert len(ref) - len(got) <= 1
             assert synth.rel_rms(got, ref[: len(got)]) <= TOL, (c, part)
+
+
+# ------------------------------------------------ fused receive converter (u8 wire format, N2)
+def _u8_stream(n_bytes, seed):
+    return np.random.default_rng(seed).integers(0, 256, size=n_bytes, dtype=np.uint8)
+
+
+def test_fir_u8_input_fused(api, L, orc):
+    """FIR reading (I,Q) byte pairs directly == FIR of the converted floats, bit for bit (the
+    conversion (b-128)/127 is exact, gr-simplefe source_c_impl.cc:121-132), across chunked calls;
+    and within tolerance of the oracle chain converter -> blkconv."""
+    taps = synth.taps_cfg2()
+    n = 50000
+    b = _u8_stream(2 * n, 1)
+    xf = orc.rx_u8_to_cf32(b)
+    f_ref = api.Fir(taps, data_complex=True, algo=L.FIR_ALGO_FFT)
+    want = f_ref.filter(xf)[0]
+    f = api.Fir(taps, data_complex=True, algo=L.FIR_ALGO_FFT)
+    f.set_input_format(L.FMT_U8)
+    got = []
+    for a, e in ((0, 7777), (7777, 7778), (7778, 30001), (30001, n)):
+        d_in = api.DeviceArray.from_bytes(b[2 * a:2 * e])
+        d_out = api.DeviceArray(2 * (e - a))
+        f.process_stream(d_in, d_out, e - a)
+        got.append(d_out.to_numpy())
+    got = np.concatenate(got)
+    assert synth.rel_rms(got, want) <= 2e-6           # chunk seams move transform boundaries
+    one = api.Fir(taps, data_complex=True, algo=L.FIR_ALGO_FFT)
+    one.set_input_format(L.FMT_U8)
+    d_in = api.DeviceArray.from_bytes(b)
+    d_out = api.DeviceArray(2 * n)
+    one.process_stream(d_in, d_out, n)
+    assert np.array_equal(d_out.to_numpy(), want)     # same kernel arithmetic, same bits
+    ref = oracle_fir_cf32(orc, taps, xf)
+    assert synth.rel_rms(got, ref) <= TOL
+
+
+@pytest.mark.parametrize("name,cplx", [("cfg4", True), ("cfg4", False), ("cfg3", True)])
+@pytest.mark.parametrize("chunk", [None, 4099, 1001])
+def test_rs_u8_input_fused(api, L, orc, g5, name, cplx, chunk):
+    """decimate/8 and resample 5/3 reading u8 samples directly: bit-identical to the float path
+    fed the converted samples (fused numerics), any call chunking (odd chunks exercise the
+    8-byte alignment fix-up), and within tolerance of converter -> oracle."""
+    taps, U, rate = g5[f"{name}_taps"], int(g5[f"{name}_U"]), float(g5[f"{name}_rate"])
+    n = 30000
+    w = 2 if cplx else 1
+    b = _u8_stream(w * n, 2)
+    xf = orc.rx_u8_to_f32(b)
+    ref_gpu = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=cplx).resample_array(xf, rate)[0]
+    r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=cplx)
+    r.set_input_format(L.FMT_U8)
+    chunk = chunk or n
+    outs = []
+    for off in range(0, n, chunk):
+        m = min(chunk, n - off)
+        d_in = api.DeviceArray.from_bytes(b[w * off:w * (off + m)])
+        cap = int(m / rate) + 8
+        d_out = api.DeviceArray(w * cap)
+        k = r.process_stream(d_in, m, d_out, cap, rate)
+        outs.append(d_out.to_numpy(w * k))
+    got = np.concatenate(outs)
+    assert np.array_equal(got, ref_gpu[: len(got)]) and len(ref_gpu) - len(got) <= w
+    for part in range(w):
+        ref, _ = orc.Resample(taps, U, 4096).stream(xf[part::w], rate)
+        assert synth.rel_rms(got[part::w], ref[: len(got[part::w])]) <= TOL
