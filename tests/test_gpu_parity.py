@@ -388,3 +388,59 @@ def test_rs_u8_input_fused(api, L, orc, g5, name, cplx, chunk):
     for part in range(w):
         ref, _ = orc.Resample(taps, U, 4096).stream(xf[part::w], rate)
         assert synth.rel_rms(got[part::w], ref[: len(got[part::w])]) <= TOL
+
+
+# ----------------------------------------------------------------- edge cases / misuse
+def test_empty_and_tiny_inputs(api, L, orc):
+    """n = 0 is a no-op; n < n_taps works and carries state; 1-tap filter is a gain."""
+    taps = synth.taps_cfg2()
+    f = api.Fir(taps, data_complex=True)
+    d, d2 = api.DeviceArray(16), api.DeviceArray(16)
+    f.process_stream(d, d2, 0)                      # nothing launched, no error
+    x = synth.synth_cf32(600)
+    parts = [f.filter(x[2 * a:2 * b])[0] for a, b in ((0, 1), (1, 3), (3, 200), (200, 600))]
+    ref = oracle_fir_cf32(orc, taps, x)
+    assert synth.rel_rms(np.concatenate(parts), ref) <= TOL
+    g = api.Fir(np.array([0.5], np.float32), data_complex=False)
+    xr = synth.synth_f32(5000)
+    assert synth.rel_rms(g.filter(xr)[0], 0.5 * xr) <= 1e-6
+    r = api.Rs(synth.taps_cfg4(), 1, 4096, mode=L.RS_DECIMATE)
+    assert r.process_stream(d, 0, d2, 0, 8.0) == 0
+
+
+def test_long_filter_falls_back_to_time_domain(api, L):
+    """More than 3841 taps cannot overlap inside one 4096-point transform: AUTO uses the tiled
+    time-domain kernel (or the generic one) and stays correct; forcing FFT is an error."""
+    rng = np.random.default_rng(9)
+    taps = (rng.standard_normal(5000) / 70).astype(np.float32)
+    x = synth.synth_f32(30000)
+    y = api.Fir(taps, data_complex=False).filter(x)[0]
+    from scipy.signal import fftconvolve
+    ref = fftconvolve(x.astype(np.float64), taps.astype(np.float64))[: len(x)]
+    assert synth.rel_rms(y, ref) <= TOL
+    f = api.Fir(taps, data_complex=False)
+    f.set_algo(L.FIR_ALGO_FFT)
+    with pytest.raises(api.SfeError):
+        f.filter(x)
+
+
+def test_misuse_is_reported_not_crashed(api, L):
+    taps = synth.taps_cfg2()
+    f = api.Fir(taps, data_complex=True)
+    d = api.DeviceArray(64)
+    with pytest.raises(api.SfeError):               # in-place is not supported
+        f.process_stream(d, d, 8)
+    with pytest.raises(api.SfeError):               # host block path needs block_hint
+        f.host_buffer()
+    with pytest.raises(api.SfeError):               # fft_len too small for the taps (blkconv.cxx:47)
+        api.Fir(taps, data_complex=False, block_hint=100)
+    with pytest.raises(api.SfeError):
+        api.Rs(taps, 0, 128)                        # upsample < 1
+    r = api.Rs(taps, 4, 128, mode=L.RS_DECIMATE)
+    with pytest.raises(api.SfeError):               # decimate rejects rate < 1 on the bulk path too
+        r.process_stream(d, 8, api.DeviceArray(64), 32, 0.5)
+    ctaps = synth.complex_taps(64, 0.2)
+    fc = api.Fir(ctaps[0] + 1j * ctaps[1], data_complex=True)
+    fc.set_algo(L.FIR_ALGO_DIRECT)
+    with pytest.raises(api.SfeError):               # complex taps need the FFT kernel
+        fc.filter(synth.synth_cf32(1000))
