@@ -51,7 +51,10 @@ __device__ __forceinline__ v2f load_sample(const void *p, unsigned lane)
 // PREFETCH = request transform i+1's rows during transform i's inverse stages.
 // HREG = keep this thread's 16 bins of H/N in registers (32 VGPRs) instead of re-reading 32 KiB
 // from L2 per transform (that stream shares the CU's vector-memory path with the samples).
-template <bool IN_C, bool OUT_C, int WAVES, bool PREFETCH, bool SWZ, bool HREG = false, bool IN_U8 = false>
+// PAIR (real data, real taps only): the real and imaginary parts of one transform carry two
+// CONSECUTIVE real segments of the stream (z = x_A + j x_B; real taps keep them apart), so a real
+// stream costs what a complex one does per sample instead of twice as much.
+template <bool IN_C, bool OUT_C, int WAVES, bool PREFETCH, bool SWZ, bool HREG = false, bool IN_U8 = false, bool PAIR = false>
 __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 {
     __shared__ v2f lds[FFT_ROWS * LDS_K2_STRIDE];
@@ -105,8 +108,32 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 
     // Loads one transform's 16 rows (thread t: samples base + t + 256 r) into registers.
     auto load_rows = [&](v2f (&x)[16], long long blk) {
-        const long long base = blk * a.advance - a.hl;   // stream index of transform element 0
         constexpr int ESZ = IN_C ? 8 : 4;     // history is always float32
+        if constexpr (PAIR) {
+            // segment A = transform 2*blk of the real stream, segment B = transform 2*blk + 1
+            const long long baseA = 2 * blk * a.advance - a.hl, baseB = baseA + a.advance;
+            if (baseA >= 0 && baseB + FFT_N <= a.n) {
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    x[r] = (v2f){load_sample<false, IN_U8>(in_c + (baseA + 256 * r) * ISZ, t).x,
+                                 load_sample<false, IN_U8>(in_c + (baseB + 256 * r) * ISZ, t).x};
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    float p[2];
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const long long row = (q ? baseB : baseA) + 256 * r;   // uniform
+                        if (row + (long long)t < 0) p[q] = load_sample<false>(hist_c + (a.hl + row) * ESZ, t).x;
+                        else if (row + (long long)t < a.n) p[q] = load_sample<false, IN_U8>(in_c + row * ISZ, t).x;
+                        else p[q] = 0.0f;
+                    }
+                    x[r] = (v2f){p[0], p[1]};
+                }
+            }
+            return;
+        }
+        const long long base = blk * a.advance - a.hl;   // stream index of transform element 0
         if (base >= 0 && base + FFT_N <= a.n) {
 #pragma unroll
             for (int r = 0; r < 16; r++) x[r] = load_sample<IN_C, IN_U8>(in_c + (base + 256 * r) * ISZ, t);
@@ -202,6 +229,20 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         if (!SWZ) lds_barrier();   // LDS free for the next transform
         else __builtin_amdgcn_sched_barrier(0);
 
+        if constexpr (PAIR) {
+            const long long oA = 2 * blk * a.advance - a.hl, oB = oA + a.advance;
+            const bool wholeA = 2 * blk * a.advance + a.advance <= a.n, wholeB = wholeA && oB + a.hl + a.advance <= a.n;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                if (r < row0) continue;
+                const v2f y = v[P16(r)];
+                if (wholeA || oA + 256 * r + (long long)t < a.n)
+                    __builtin_nontemporal_store(y.x, reinterpret_cast<float *>(out_c + (oA + 256 * r) * 4) + t);
+                if (wholeB || oB + 256 * r + (long long)t < a.n)
+                    __builtin_nontemporal_store(y.y, reinterpret_cast<float *>(out_c + (oB + 256 * r) * 4) + t);
+            }
+            continue;
+        }
         const long long obase = blk * a.advance - a.hl;   // uniform; + 256*row + t
         constexpr int OSZ = OUT_C ? 8 : 4;
         const bool whole = blk * a.advance + a.advance <= a.n;
@@ -330,7 +371,15 @@ int launch_fir_fft(const FirFftArgs &a, int in_complex, int out_complex, int in_
     case 7: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, true, false>), grid, block, 0, s, a); break; \
     default: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 4, false, false, true>), grid, block, 0, s, a); break; \
     }
-    if (in_u8) {   // wire-format input: default kernel shape only
+    if (!in_complex && !out_complex && !copy_only && !(ev && ev[0] >= '2' && ev[0] <= '4')) {
+        // real stream, real taps: two segments per transform (PAIR); a.nblk counts transforms
+        FirFftArgs b = a;
+        b.nblk = (a.nblk + 1) / 2;
+        long long g2 = b.nblk < gx ? b.nblk : gx;
+        dim3 grid2((unsigned)(g2 < 1 ? 1 : g2), (unsigned)n_channels);
+        if (in_u8) hipLaunchKernelGGL((fir_fft4096_kernel<false, false, 4, false, false, true, true, true>), grid2, block, 0, s, b);
+        else hipLaunchKernelGGL((fir_fft4096_kernel<false, false, 4, false, false, true, false, true>), grid2, block, 0, s, b);
+    } else if (in_u8) {   // wire-format input: default kernel shape only
         if (in_complex && out_complex) hipLaunchKernelGGL((fir_fft4096_kernel<true, true, 4, false, false, true, true>), grid, block, 0, s, a);
         else if (!in_complex && !out_complex) hipLaunchKernelGGL((fir_fft4096_kernel<false, false, 4, false, false, true, true>), grid, block, 0, s, a);
         else {
