@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "common.h"
+#include "timelaw.h"
 
 namespace sfe {
 
@@ -387,6 +388,8 @@ struct Rs {
     size_t h_stage_bytes = 0;
     long long *h_pos = nullptr;            // pinned schedule staging
     float *h_mu = nullptr;
+    void *d_segs = nullptr, *d_chunks = nullptr, *h_segs = nullptr, *h_chunks = nullptr;   // run-length plans
+    size_t segs_cap = 0, chunks_cap = 0;
     hipStream_t stream = nullptr;
     int esz() const { return data_complex ? 8 : 4; }
 };
@@ -407,6 +410,10 @@ static void rs_free(Rs *r)
     if (r->h_stage) (void)hipHostFree(r->h_stage);
     if (r->h_pos) (void)hipHostFree(r->h_pos);
     if (r->h_mu) (void)hipHostFree(r->h_mu);
+    if (r->d_segs) (void)hipFree(r->d_segs);
+    if (r->d_chunks) (void)hipFree(r->d_chunks);
+    if (r->h_segs) (void)hipHostFree(r->h_segs);
+    if (r->h_chunks) (void)hipHostFree(r->h_chunks);
     if (r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
 }
@@ -452,38 +459,6 @@ static int rs_ensure_stage(Rs *r, size_t bytes)
     SFE_HIP(hipHostMalloc(&r->h_stage, bytes));
     r->h_stage_bytes = bytes;
     return SFE_OK;
-}
-
-// The reference's time law for one process() call, positions only
-// (libdsp/resample.cxx:89,119-150 == libdsp/decimate.cxx:73,96-127).
-template <class Emit>
-static int time_law(sfe_rs_timestate *st, int U, int n_in, int out_len, float rate, Emit emit)
-{
-    int n_out = 0;
-    float t = (float)st->pos + st->mu;
-    const float step = rate * (float)U;
-    if (st->leftover) {
-        emit(-1, st->mu);
-        n_out++;
-        st->leftover = 0;
-        t += step;
-    }
-    for (;;) {
-        st->pos = (int)floorf(t);
-        st->mu = t - (float)st->pos;
-        const int pos1 = st->pos + 1;
-        const int n0 = st->pos / U, n1 = pos1 / U;     // C truncation, as the reference's ints
-        if (n0 >= n_in || n_out >= out_len) break;
-        if (n1 >= n_in) {
-            st->leftover = 1;
-            break;
-        }
-        emit(st->pos, st->mu);
-        n_out++;
-        t += step;
-    }
-    st->pos -= n_in * U;
-    return n_out;
 }
 
 }  // namespace sfe
@@ -1050,37 +1025,102 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
             set_error("rs_process_stream: u8 input is supported for integer-valued steps only");
             return SFE_ESTATE;
         }
-        // replay the float32 recurrence chunk by chunk, as the reference object would see it
+        // Replay the float32 recurrence call by call (blksize samples each), as the reference
+        // object would see the stream -- in closed form: each call becomes a few constant-increment
+        // runs (timelaw.h) that one workgroup expands on the GPU.
         sfe_rs_timestate st = r->ts;
-        std::vector<long long> pos;
-        std::vector<float> mu;
-        pos.reserve((size_t)((double)n_in / rate) + 16);
-        mu.reserve(pos.capacity());
+        std::vector<TlSeg> segs;
+        std::vector<SegChunk> chunks;
+        chunks.reserve(n_in / (size_t)r->blksize + 1);
+        size_t K = 0;
+        int max_m = 0;
         for (size_t off = 0; off < n_in; off += (size_t)r->blksize) {
             const int m = (int)((n_in - off) < (size_t)r->blksize ? (n_in - off) : (size_t)r->blksize);
             const int cap = (int)ceilf((float)m / rate) + 2;
-            time_law(&st, r->U, m, cap, rate, [&](int p, float w) {
-                pos.push_back((long long)off * r->U + p);
-                mu.push_back(w);
-            });
+            SegChunk c;
+            c.in_off = (long long)off;
+            c.k_first = (long long)K;
+            c.m = m;
+            c.seg_first = (int)segs.size();
+            c.n_out = time_law_segments(&st, r->U, m, cap, rate, segs);
+            c.n_seg = (int)segs.size() - c.seg_first;
+            chunks.push_back(c);
+            K += (size_t)c.n_out;
+            max_m = m > max_m ? m : max_m;
         }
-        const size_t K = pos.size();
         if (K > out_cap) {
             set_error("rs_process_stream: need room for %zu outputs, got %zu", K, out_cap);
             return SFE_ERANGE;
         }
-        rc = rs_ensure_sched(r, K + 1);
-        if (rc != SFE_OK) return rc;
-        // the staging buffers are reused across calls: wait for the previous upload's consumer
+        PolySegArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.in = d_in;
+        sa.out = d_out;
+        sa.hist = r->d_hist[r->cur];
+        sa.taps = r->d_taps;
+        sa.n_in = (long long)n_in;
+        sa.in_stride = (long long)in_stride;
+        sa.out_stride = (long long)out_stride;
+        sa.hl = r->hl;
+        sa.U = r->U;
+        sa.plen = r->plen;
+        sa.n_chunks = (int)chunks.size();
+        sa.max_m = max_m;
+        // plan tables: grow-only device + pinned staging; the previous call's kernel may still
+        // be reading them, so wait for the stream before overwriting
         SFE_HIP(hipStreamSynchronize(s));
-        memcpy(r->h_pos, pos.data(), K * sizeof(long long));
-        memcpy(r->h_mu, mu.data(), K * sizeof(float));
-        SFE_HIP(hipMemcpyAsync(r->d_pos, r->h_pos, K * sizeof(long long), hipMemcpyHostToDevice, s));
-        SFE_HIP(hipMemcpyAsync(r->d_mu, r->h_mu, K * sizeof(float), hipMemcpyHostToDevice, s));
-        a.n_out = (long long)K;
-        a.sched_pos = r->d_pos;
-        a.sched_mu = r->d_mu;
-        rc = launch_poly_sched(a, r->data_complex, r->exact_stream, r->n_channels, s);
+        if (segs.size() > r->segs_cap) {
+            if (r->d_segs) (void)hipFree(r->d_segs);
+            if (r->h_segs) (void)hipHostFree(r->h_segs);
+            r->d_segs = r->h_segs = nullptr;
+            r->segs_cap = 0;
+            const size_t cap2 = segs.size() * 2 + 1024;
+            SFE_HIP(hipMalloc(&r->d_segs, cap2 * sizeof(TlSeg)));
+            SFE_HIP(hipHostMalloc(&r->h_segs, cap2 * sizeof(TlSeg)));
+            r->segs_cap = cap2;
+        }
+        if (chunks.size() > r->chunks_cap) {
+            if (r->d_chunks) (void)hipFree(r->d_chunks);
+            if (r->h_chunks) (void)hipHostFree(r->h_chunks);
+            r->d_chunks = r->h_chunks = nullptr;
+            r->chunks_cap = 0;
+            const size_t cap2 = chunks.size() * 2 + 64;
+            SFE_HIP(hipMalloc(&r->d_chunks, cap2 * sizeof(SegChunk)));
+            SFE_HIP(hipHostMalloc(&r->h_chunks, cap2 * sizeof(SegChunk)));
+            r->chunks_cap = cap2;
+        }
+        memcpy(r->h_segs, segs.data(), segs.size() * sizeof(TlSeg));
+        memcpy(r->h_chunks, chunks.data(), chunks.size() * sizeof(SegChunk));
+        SFE_HIP(hipMemcpyAsync(r->d_segs, r->h_segs, segs.size() * sizeof(TlSeg), hipMemcpyHostToDevice, s));
+        SFE_HIP(hipMemcpyAsync(r->d_chunks, r->h_chunks, chunks.size() * sizeof(SegChunk), hipMemcpyHostToDevice, s));
+        sa.segs = r->d_segs;
+        sa.chunks = static_cast<const SegChunk *>(r->d_chunks);
+        rc = launch_poly_seg(sa, r->data_complex, r->exact_stream, r->n_channels, s);
+        if (rc == SFE_ESTATE) {
+            // a call's input does not fit an LDS tile (huge blksize): expand on the host and use
+            // the per-output schedule kernel
+            std::vector<long long> pos(K);
+            std::vector<float> mu(K);
+            for (const SegChunk &c : chunks)
+                for (int i = 0; i < c.n_seg; i++) {
+                    const TlSeg &g = segs[(size_t)c.seg_first + i];
+                    for (int q = 0; q < g.count; q++) {
+                        const double t = g.t0 + (double)q * (double)g.d, fl = floor(t);
+                        pos[(size_t)c.k_first + g.k0 + q] = c.in_off * r->U + (long long)fl;
+                        mu[(size_t)c.k_first + g.k0 + q] = (float)(t - fl);
+                    }
+                }
+            rc = rs_ensure_sched(r, K + 1);
+            if (rc != SFE_OK) return rc;
+            memcpy(r->h_pos, pos.data(), K * sizeof(long long));
+            memcpy(r->h_mu, mu.data(), K * sizeof(float));
+            SFE_HIP(hipMemcpyAsync(r->d_pos, r->h_pos, K * sizeof(long long), hipMemcpyHostToDevice, s));
+            SFE_HIP(hipMemcpyAsync(r->d_mu, r->h_mu, K * sizeof(float), hipMemcpyHostToDevice, s));
+            a.n_out = (long long)K;
+            a.sched_pos = r->d_pos;
+            a.sched_mu = r->d_mu;
+            rc = launch_poly_sched(a, r->data_complex, r->exact_stream, r->n_channels, s);
+        }
         if (rc != SFE_OK) return rc;
         r->ts = st;
         *n_out = K;

@@ -126,6 +126,30 @@ bool poly_mfma_fits(int GS, int RG, int Kp);
 int launch_poly_sched(const PolyArgs &a, int data_complex, int exact, int n_channels,
                       hipStream_t s);
 
+// General rate, run-length form (timelaw.h): the host plans each blksize-sample call of the
+// reference as a handful of constant-increment runs; one workgroup per call expands its runs into
+// (pos, mu) on the fly and evaluates the two polyphase dots from an LDS tile of the call's input.
+struct SegChunk {
+    long long in_off;     // first input sample of the call (relative to this launch's input)
+    long long k_first;    // first output of the call (relative to this launch's output)
+    int       m;          // input samples in the call
+    int       n_out;      // outputs of the call
+    int       seg_first;  // index of the call's first run in the run table
+    int       n_seg;
+};
+struct PolySegArgs {
+    const void *in;
+    void       *out;
+    const void *hist;
+    const float *taps;          // [U][plen] phase-major
+    const void *segs;           // TlSeg[]
+    const SegChunk *chunks;
+    long long   n_in, in_stride, out_stride;
+    int         hl, U, plen, n_chunks, max_m;
+};
+// returns SFE_ESTATE when a call's tile does not fit in LDS (caller falls back to launch_poly_sched)
+int launch_poly_seg(const PolySegArgs &a, int data_complex, int exact, int n_channels, hipStream_t s);
+
 // new_hist[i] = virtual[n_in - hl + i], virtual = old_hist ++ in  (per channel)
 int launch_history_update(const void *in, long long n_in, long long in_stride,
                           const void *old_hist, void *new_hist, int hl, int elem_floats,

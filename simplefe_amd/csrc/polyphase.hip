@@ -482,6 +482,76 @@ __global__ __launch_bounds__(256) void poly_sched_kernel(PolyArgs a)
     }
 }
 
+// ------------------------------------------------------- general rate, run-length form
+struct DevSeg {          // == sfe::TlSeg (timelaw.h), restated here to keep this file HIP-only
+    double t0;
+    float  d;
+    int    k0, count, pad;
+};
+constexpr int SEG_MAX_LDS = 96;
+
+template <bool CPLX, bool EXACT>
+__global__ __launch_bounds__(256) void poly_seg_kernel(PolySegArgs a)
+{
+    typedef typename Elem<CPLX>::T T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevSeg *sg = reinterpret_cast<DevSeg *>(smem);
+    float *ts = reinterpret_cast<float *>(smem + SEG_MAX_LDS * sizeof(DevSeg));
+    T *xs = reinterpret_cast<T *>(smem + SEG_MAX_LDS * sizeof(DevSeg) + (((size_t)a.U * a.plen * 4 + 15) & ~(size_t)15));
+
+    const SegChunk c = a.chunks[blockIdx.x];
+    const int ch = blockIdx.y;
+    const T *in = static_cast<const T *>(a.in) + (size_t)ch * a.in_stride;
+    const T *hist = static_cast<const T *>(a.hist) + (size_t)ch * a.hl;
+    T *out = static_cast<T *>(a.out) + (size_t)ch * a.out_stride + c.k_first;
+    const DevSeg *gseg = static_cast<const DevSeg *>(a.segs) + c.seg_first;
+
+    const int nsl = c.n_seg < SEG_MAX_LDS ? c.n_seg : SEG_MAX_LDS;
+    for (int i = threadIdx.x; i < nsl; i += 256) sg[i] = gseg[i];
+    for (int i = threadIdx.x; i < a.U * a.plen; i += 256) ts[i] = a.taps[i];
+    // tile: samples in_off - plen .. in_off + m - 1   (pos >= -1 reaches back plen samples)
+    const int n_tile = c.m + a.plen;
+    for (int i = threadIdx.x; i < n_tile; i += 256) xs[i] = vload<CPLX>(in, hist, c.in_off - a.plen + i, a.n_in, a.hl);
+    __syncthreads();
+
+    auto dot = [&](long long p) -> T {
+        const long long n = floordiv(p, a.U);
+        const int ph = (int)(p - n * a.U);
+        const float *tp = ts + ph * a.plen;
+        const T *xp = xs + (n + a.plen);
+        T acc = Elem<CPLX>::zero();
+        // positions before the tile (only reachable through the reference's out_len-exhausted
+        // state) read as zero instead of out of bounds
+        const long long reach = n + a.plen + 1;
+        const int jn = reach < a.plen ? (reach > 0 ? (int)reach : 0) : a.plen;
+        for (int j = 0; j < jn; j++) acc = mac<EXACT>(acc, tp[j], xp[-j]);
+        return acc;
+    };
+
+    int s = 0;                                          // runs are visited in order by each thread
+    for (int k = threadIdx.x; k < c.n_out; k += 256) {
+        DevSeg g;
+        for (;;) {
+            g = s < nsl ? sg[s] : gseg[s];
+            if (k < g.k0 + g.count) break;
+            s++;
+        }
+        const double t = g.t0 + (double)(k - g.k0) * (double)g.d;       // exact (timelaw.h)
+        const double fl = floor(t);
+        const float mu = (float)(t - fl);
+        const long long p = (long long)fl;
+        const T s0 = dot(p), s1 = dot(p + 1);
+        const float om = 1.0f - mu;                                       // resample.cxx:147
+        if constexpr (CPLX) {
+            if constexpr (EXACT) { const v2f l = s0 * (v2f){om, om}, r = (v2f){mu, mu} * s1; out[k] = l + r; }
+            else out[k] = __builtin_elementwise_fma((v2f){mu, mu}, s1, s0 * (v2f){om, om});
+        } else {
+            if constexpr (EXACT) { const float l = s0 * om, r = mu * s1; out[k] = l + r; }
+            else out[k] = __builtin_fmaf(mu, s1, s0 * om);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- history carry-over
 __global__ __launch_bounds__(256) void history_update_kernel(const float *in, long long n_in,
                                                              long long in_stride,
@@ -668,6 +738,22 @@ int launch_poly_sched(const PolyArgs &a, int data_complex, int exact, int n_chan
     const long long nb = (a.n_out + 255) / 256;
     dim3 grid((unsigned)nb, (unsigned)n_channels), block(256);
 #define LAUNCH(C, E) hipLaunchKernelGGL((poly_sched_kernel<C, E>), grid, block, 0, s, a)
+    if (data_complex) { if (exact) LAUNCH(true, true); else LAUNCH(true, false); }
+    else { if (exact) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+    SFE_HIP(hipGetLastError());
+    return SFE_OK;
+}
+
+int launch_poly_seg(const PolySegArgs &a, int data_complex, int exact, int n_channels, hipStream_t s)
+{
+    if (a.n_chunks <= 0) return SFE_OK;
+    const size_t esz = data_complex ? 8 : 4;
+    const size_t sh = SEG_MAX_LDS * sizeof(DevSeg) + (((size_t)a.U * a.plen * 4 + 15) & ~(size_t)15) +
+                      (size_t)(a.max_m + a.plen) * esz;
+    if (sh > 64 * 1024) return SFE_ESTATE;
+    dim3 grid((unsigned)a.n_chunks, (unsigned)n_channels), block(256);
+#define LAUNCH(C, E) hipLaunchKernelGGL((poly_seg_kernel<C, E>), grid, block, sh, s, a)
     if (data_complex) { if (exact) LAUNCH(true, true); else LAUNCH(true, false); }
     else { if (exact) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH

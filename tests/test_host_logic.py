@@ -177,3 +177,13 @@ def test_reference_own_test_program_builds_against_dropin_header(L):
     r = _cxx(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "dropin"])
     assert r.returncode == 0, r.stderr
     assert os.path.exists(os.path.join(ROOT, "oracle/_ref/test_blkconv_dropin"))
+
+
+def test_time_law_closed_form_matches_literal_replay(tmp_path):
+    """csrc/timelaw.h: constant-increment runs per float32 binade == the step-by-step recurrence,
+    bit for bit, over 1500 random (U, rate, chunk, out_len) cases (tests/host/test_timelaw.cpp)."""
+    exe = str(tmp_path / "tl")
+    r = _cxx(["g++", "-O2", "-Wall", "-std=c++14", os.path.join(ROOT, "tests/host/test_timelaw.cpp"), "-o", exe])
+    assert r.returncode == 0, r.stderr
+    r = _cxx([exe])
+    assert r.returncode == 0 and "timelaw ok" in r.stdout, r.stdout + r.stderr
