@@ -117,7 +117,8 @@ struct PolyMfmaArgs {
     const float *A;
     long long   n_in, in_stride, out_stride, n_out;
     int         hl, GS, RG, Kp, u_lo;
-    int         x_bytes;   // set by the launcher: bytes of the sample / output tile region
+    int         x_bytes;   // set by the launcher: bytes of one wave's sample / output tile slice
+    int         a_bytes;   // set by the launcher: bytes of the tap-fragment table in front of the slices
     int         gs;        // set by the launcher: group spacing inside a column block (bank spread)
     long long   tiles;     // set by the launcher
 };

@@ -315,64 +315,73 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
 //   kk ascending = window position DEscending = tap index ascending (the reference's order)
 //   D: lane l, reg i -> row 4 (l>>4) + i, col l&15
 constexpr int MF_NB = 4;            // column blocks (of 8 groups) per wave (the K loop is written out for 4)
-constexpr int MF_G = 4 * MF_NB * 8; // groups per workgroup (4 waves)
+constexpr int MF_WG = MF_NB * 8;    // groups per wave tile
 constexpr int MF_LD = 16;           // staged loads per thread: tiles of up to 4096 samples
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256, 4) void poly_mfma_kernel(PolyMfmaArgs a)
 {
+    // WAVE-granular: every wave owns its own tile of MF_WG groups, its own slice of LDS and its
+    // own loop over tiles -- no workgroup barrier after the tap fragments are in place, so the
+    // four waves of a SIMD (one from each resident workgroup) are free to drift apart.  (Measured:
+    // no faster than workgroup-wide tiles with four barriers per tile -- 1.21 ms either way -- so
+    // lockstep phases are not what keeps the matrix pipe at 62 %; scripts/probes/mfma_probe.hip
+    // reaches 82 % with this K loop alone.)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int n_tile = a.GS * (MF_G - 1) + a.Kp;                 // samples staged per tile
-    v2f *X = reinterpret_cast<v2f *>(smem);
-    float *Af = reinterpret_cast<float *>(smem + a.x_bytes);
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_tile = a.GS * (MF_WG - 1) + a.Kp;               // samples staged per wave tile
+    float *Af = reinterpret_cast<float *>(smem);
+    v2f *X = reinterpret_cast<v2f *>(smem + a.a_bytes + (size_t)wave * a.x_bytes);
     const int ch = blockIdx.y;
     const v2f *in = static_cast<const v2f *>(a.in) + (size_t)ch * a.in_stride;
     const v2f *hist = static_cast<const v2f *>(a.hist) + (size_t)ch * a.hl;
     v2f *out = static_cast<v2f *>(a.out) + (size_t)ch * a.out_stride;
 
-    // tap fragments: once per (persistent) workgroup
+    // tap fragments: once per (persistent) workgroup -- the only workgroup-level hand-off
     const int ksteps = a.Kp >> 2;
     for (unsigned i = tid; i < (unsigned)ksteps * 64; i += 256) Af[i] = a.A[i];
+    __syncthreads();
 
-    // Column block nb of this wave holds the 8 groups  gs*gi + (nb % gs) + 8*gs*(nb / gs):
+    // Column block nb holds the 8 groups  gs*gi + (nb % gs) + 8*gs*(nb / gs)  of the wave's 32:
     // the spacing gs (1, 2 or 4; chosen by the host) makes the 32 lanes of a ds_read_b32 group
     // -- 8 groups x {re,im} x 2 window positions -- fall on 32 different LDS banks.
     const unsigned j = lane & 15, kq = lane >> 4;
     const unsigned gs = a.gs;
-    unsigned boff[MF_NB];        // float offset of this lane's B element at K-step 0
+    unsigned boff[MF_NB], ygrp[MF_NB];
 #pragma unroll
     for (int nb = 0; nb < MF_NB; nb++) {
-        const unsigned grp = wave * (8 * MF_NB) + gs * (j >> 1) + ((unsigned)nb % gs) + 8 * gs * ((unsigned)nb / gs);
-        boff[nb] = 2 * a.GS * grp + (j & 1) + 2 * (a.Kp - 1 - (int)kq);
+        ygrp[nb] = gs * (j >> 1) + ((unsigned)nb % gs) + 8 * gs * ((unsigned)nb / gs);
+        boff[nb] = 2 * a.GS * ygrp[nb] + (j & 1) + 2 * (a.Kp - 1 - (int)kq);   // float offset at K-step 0
     }
     const float *Xf = reinterpret_cast<const float *>(X);
     const float *ap = Af + lane;
 
-    // Sample tile: up to MF_LD loads per thread, issued one tile AHEAD (they fly during the
-    // K loop of the current tile) and written to LDS at the top of the next iteration.
+    // Sample tile: up to MF_LD loads per lane, issued one tile AHEAD (in flight during the K
+    // loop of the current tile) and written to the wave's LDS slice at the top of the next one.
     v2f stg[MF_LD];
-    auto fetch = [&](long long tile) {
-        const long long n_org = (long long)a.GS * (tile * MF_G) + a.u_lo;
+    auto fetch = [&](long long wt) {
+        const long long n_org = (long long)a.GS * (wt * MF_WG) + a.u_lo;
         if (n_org >= 0 && n_org + n_tile <= a.n_in) {
             const v2f *src = in + n_org;
 #pragma unroll
             for (int i = 0; i < MF_LD; i++)
-                if (tid + 256u * i < (unsigned)n_tile) stg[i] = __builtin_nontemporal_load(src + tid + 256u * i);
+                if (lane + 64u * i < (unsigned)n_tile) stg[i] = __builtin_nontemporal_load(src + lane + 64u * i);
         } else {
 #pragma unroll
             for (int i = 0; i < MF_LD; i++)
-                if (tid + 256u * i < (unsigned)n_tile) stg[i] = vload<true>(in, hist, n_org + tid + 256u * i, a.n_in, a.hl);
+                if (lane + 64u * i < (unsigned)n_tile) stg[i] = vload<true>(in, hist, n_org + lane + 64u * i, a.n_in, a.hl);
         }
     };
-    if ((long long)blockIdx.x < a.tiles) fetch(blockIdx.x);
-    for (long long tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
-        const long long g_first = tile * MF_G;
+    const long long wstride = (long long)gridDim.x * 4;
+    long long wt = (long long)blockIdx.x * 4 + wave;             // this wave's tile index
+    if (wt < a.tiles) fetch(wt);
+    for (; wt < a.tiles; wt += wstride) {
+        const long long g_first = wt * MF_WG;
 #pragma unroll
         for (int i = 0; i < MF_LD; i++)
-            if (tid + 256u * i < (unsigned)n_tile) X[tid + 256u * i] = stg[i];
-        lds_barrier();
-        if (tile + gridDim.x < a.tiles) fetch(tile + gridDim.x);
+            if (lane + 64u * i < (unsigned)n_tile) X[lane + 64u * i] = stg[i];
+        asm volatile("" ::: "memory");      // LDS ops of one wave execute in order: no barrier needed
+        if (wt + wstride < a.tiles) fetch(wt + wstride);
 
         f32x4 acc[MF_NB];
         f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
@@ -407,32 +416,32 @@ __global__ __launch_bounds__(256, 4) void poly_mfma_kernel(PolyMfmaArgs a)
         }
 #undef SFE_MF4
         acc[0] = acc0; acc[1] = acc1; acc[2] = acc2; acc[3] = acc3;
-        lds_barrier();                   // everyone is done with X: reuse it for the output tile
+        asm volatile("" ::: "memory");
 
-        // D -> linear output tile Y[RG * group + row] (complex), then whole-line stores
+        // D -> linear output tile Y[RG * group + row] (complex) in the wave's own slice (X is dead:
+        // the wave's LDS reads above have all returned into registers), then whole-line stores
         float *Yf = reinterpret_cast<float *>(X);
 #pragma unroll
         for (int nb = 0; nb < MF_NB; nb++) {
-            const unsigned grp = wave * (8 * MF_NB) + gs * (j >> 1) + ((unsigned)nb % gs) + 8 * gs * ((unsigned)nb / gs);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const unsigned row = 4 * kq + i;
-                if ((int)row < a.RG) Yf[2 * (a.RG * grp + row) + (j & 1)] = acc[nb][i];
+                if ((int)row < a.RG) Yf[2 * (a.RG * ygrp[nb] + row) + (j & 1)] = acc[nb][i];
             }
         }
-        lds_barrier();
+        asm volatile("" ::: "memory");
         const long long k0 = (long long)a.RG * g_first;
-        const int n_y = a.RG * MF_G;
+        const int n_y = a.RG * MF_WG;
         const v2f *Y = reinterpret_cast<const v2f *>(Yf);
         if (k0 + n_y <= a.n_out && ((reinterpret_cast<uintptr_t>(out + k0) & 15) == 0) && (n_y & 1) == 0) {
             const v4f *Y4 = reinterpret_cast<const v4f *>(Y);
             v4f *o4 = reinterpret_cast<v4f *>(out + k0);
-            for (unsigned i = tid; i < (unsigned)(n_y / 2); i += 256) __builtin_nontemporal_store(Y4[i], o4 + i);
+            for (unsigned i = lane; i < (unsigned)(n_y / 2); i += 64) __builtin_nontemporal_store(Y4[i], o4 + i);
         } else {
-            for (unsigned i = tid; i < (unsigned)n_y; i += 256)
+            for (unsigned i = lane; i < (unsigned)n_y; i += 64)
                 if (k0 + i < a.n_out) out[k0 + i] = Y[i];
         }
-        lds_barrier();                   // Y is read out before the next tile overwrites X
+        asm volatile("" ::: "memory");
     }
 }
 
@@ -675,15 +684,23 @@ int launch_poly_tiled(const PolyTiledPlan &plan, const PolyTiledArgs &a, int dat
     return SFE_OK;
 }
 
+static void mfma_lds_layout(int GS, int RG, int Kp, size_t *a_bytes, size_t *x_bytes, size_t *n_tile)
+{
+    *n_tile = (size_t)GS * (MF_WG - 1) + Kp;
+    size_t xb = (*n_tile * 8 + 15) & ~(size_t)15;
+    const size_t yb = ((size_t)RG * MF_WG * 8 + 15) & ~(size_t)15;
+    if (xb < yb) xb = yb;                         // the output tile reuses the wave's sample slice
+    *x_bytes = xb;
+    *a_bytes = ((size_t)(Kp / 4) * 64 * 4 + 15) & ~(size_t)15;
+}
+
 bool poly_mfma_fits(int GS, int RG, int Kp)
 {
     if (RG < 1 || RG > 16 || Kp < 4 || (Kp & 3)) return false;
-    const size_t n_tile = (size_t)GS * (MF_G - 1) + Kp;
-    if (n_tile > (size_t)MF_LD * 256) return false;
-    size_t x_bytes = (n_tile * 8 + 15) & ~(size_t)15;
-    const size_t y_bytes = (size_t)RG * MF_G * 8;
-    if (x_bytes < y_bytes) x_bytes = (y_bytes + 15) & ~(size_t)15;
-    return x_bytes + (size_t)(Kp / 4) * 64 * 4 <= 64 * 1024;
+    size_t ab, xb, nt;
+    mfma_lds_layout(GS, RG, Kp, &ab, &xb, &nt);
+    if (nt > (size_t)MF_LD * 64) return false;
+    return ab + 4 * xb <= 64 * 1024;
 }
 
 int launch_poly_mfma(const PolyMfmaArgs &a, int n_channels, hipStream_t s)
@@ -691,14 +708,13 @@ int launch_poly_mfma(const PolyMfmaArgs &a, int n_channels, hipStream_t s)
     if (a.n_out <= 0) return SFE_OK;
     if (!poly_mfma_fits(a.GS, a.RG, a.Kp)) return SFE_ESTATE;
     const long long groups = (a.n_out + a.RG - 1) / a.RG;
-    const long long tiles = (groups + MF_G - 1) / MF_G;
-    const size_t n_tile = (size_t)a.GS * (MF_G - 1) + a.Kp;
-    const size_t y_bytes = (size_t)a.RG * MF_G * 8;
-    size_t x_bytes = (n_tile * 8 + 15) & ~(size_t)15;
-    if (x_bytes < y_bytes) x_bytes = (y_bytes + 15) & ~(size_t)15;   // the output tile reuses X
-    const size_t sh = x_bytes + (size_t)(a.Kp / 4) * 64 * 4;
+    const long long tiles = (groups + MF_WG - 1) / MF_WG;          // wave tiles
+    size_t ab, xb, nt;
+    mfma_lds_layout(a.GS, a.RG, a.Kp, &ab, &xb, &nt);
+    const size_t sh = ab + 4 * xb;
     PolyMfmaArgs b = a;
-    b.x_bytes = (int)x_bytes;
+    b.x_bytes = (int)xb;
+    b.a_bytes = (int)ab;
     b.tiles = tiles;
     // group spacing inside a column block: the 32 lanes of a ds_read_b32 group read float
     // 2*GS*gs*gi + part - 2*kq (gi < 8, part < 2, kq < 2): pick gs so the banks are all distinct
@@ -715,18 +731,17 @@ int launch_poly_mfma(const PolyMfmaArgs &a, int n_channels, hipStream_t s)
                 }
         if (ok) { b.gs = gs; break; }
     }
-    // persistent grid = what is co-resident (occupancy API; a larger grid runs in two waves of
-    // workgroups and halves the average occupancy)
+    // persistent grid = what is co-resident
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, poly_mfma_kernel, 256, sh) != hipSuccess || per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
     if (const char *e = getenv("SFE_MFMA_WG_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
-    long long gx = tiles;
+    long long gx = (tiles + 3) / 4;
     const long long cap = (256LL * per_cu + n_channels - 1) / n_channels;
     if (gx > cap) gx = cap;
     dim3 grid((unsigned)gx, (unsigned)n_channels), block(256);
     if (getenv("SFE_DEBUG_OCC"))
-        fprintf(stderr, "poly_mfma: lds %zu B, grid %lld, tiles %lld, gs %d, %d blocks/CU\n", sh, gx, tiles, b.gs, per_cu);
+        fprintf(stderr, "poly_mfma: lds %zu B, grid %lld, wave tiles %lld, gs %d, %d blocks/CU\n", sh, gx, tiles, b.gs, per_cu);
     hipLaunchKernelGGL(poly_mfma_kernel, grid, block, sh, s, b);
     SFE_HIP(hipGetLastError());
     return SFE_OK;
