@@ -107,3 +107,64 @@ def test_gr_decimate_and_resampler_blocks_bit_exact(gr_exe, tmp_path, g5, orc):
         ref, _ = orc.Resample(g5["cfg3_taps"], 3, 4096).stream(x[part::2], 5.0 / 3.0)
         got = y[part::2]
         assert len(ref) - len(got) <= 2 and np.array_equal(got, ref[: len(got)])
+
+
+# ------------------------------------------ bpsk pipeline end to end on the GPU path (N3)
+def _bpsk_stream(n_blocks, blk):
+    """The process thread's symbol generator of examples/bpsk_gpu/bpsk_gpu.cpp, in Python."""
+    sps, amp = 10, np.float32(.85) / np.float32(1.35)
+    state, n_phase, out = 12345, 0, []
+    for _ in range(n_blocks):
+        buf = []
+        if n_phase > 0:
+            for _i in range(n_phase, sps):
+                if len(buf) < blk:
+                    buf.append(0.0)
+            n_phase = 0
+        while len(buf) < blk:
+            state = (state * 1664525 + 1013904223) & 0xFFFFFFFF
+            word = state >> 1
+            for j in range(31):
+                if len(buf) >= blk:
+                    break
+                buf.append(-amp if (word >> j) & 1 else amp)
+                n_phase = 1
+                while n_phase < sps and len(buf) < blk:
+                    buf.append(0.0)
+                    n_phase += 1
+                if n_phase == sps:
+                    n_phase = 0
+        out.extend(buf)
+    return np.array(out, dtype=np.float32)
+
+
+def _unpack10(b):
+    b = b.reshape(-1, 5).astype(np.int32)
+    hi = b[:, 0]
+    return np.stack([((hi >> (2 * k)) & 3) << 8 | b[:, 1 + k] for k in range(4)], axis=1).reshape(-1)
+
+
+def test_bpsk_pipeline_end_to_end(tmp_path, orc, g1):
+    """examples/bpsk/bpsk.cxx:104-174 on the GPU path: process thread (drop-in blkconv + ring_buffer)
+    and a consumer thread doing the converting read (10-bit packing) -- against the same chain
+    built from the oracle.  Byte-exact except where a sample sits within float rounding of a
+    quantiser step (|difference| <= 1 LSB there)."""
+    exe = str(tmp_path / "bpsk_gpu")
+    r = subprocess.run(["g++", "-O1", "-pthread", os.path.join(ROOT, "examples/bpsk_gpu/bpsk_gpu.cpp"), "-o", exe,
+                        "-L" + LIBDIR, "-lsfe_dsp", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib",
+                        "-Wl,--allow-shlib-undefined"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    taps, fft_len, n_blocks = g1["g2_taps"], 2048, 40
+    taps.astype(np.float32).tofile(tmp_path / "taps.f32")
+    r = subprocess.run([exe, str(n_blocks), str(tmp_path / "tx.bin"), str(fft_len), str(tmp_path / "taps.f32")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.fromfile(tmp_path / "tx.bin", dtype=np.uint8)
+    blk = fft_len + 1 - len(taps)
+    x = _bpsk_stream(n_blocks, blk)
+    y = orc.Blkconv(taps, fft_len).stream(x)
+    n_xfer = len(y) // 2048
+    assert len(got) == n_xfer * 2560 and n_xfer > 30
+    want = orc.tx_f32_to_10bit(y[: n_xfer * 2048])
+    dv = np.abs(_unpack10(got) - _unpack10(want))
+    assert dv.max() <= 1 and np.count_nonzero(dv) <= 0.002 * len(dv)
