@@ -129,6 +129,8 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libsfe_dsp has no CPU fallback")
+    if os.environ.get("SFE_BENCH_ONE_DEVICE"):      # rehearsal: every rank on cuda:0 (with SFE_DIST_BACKEND=gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     shard.init_process_group(dev)            # RCCL when WORLD_SIZE > 1

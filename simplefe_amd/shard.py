@@ -27,10 +27,13 @@ def init_process_group(device=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if device is not None and device.type == "cuda":
+        # RCCL ("nccl") on GPUs, gloo on CPU-only hosts; SFE_DIST_BACKEND=gloo lets the N > 1 code
+        # path be rehearsed with several ranks on ONE GPU (RCCL refuses two ranks on a device)
+        backend = os.environ.get("SFE_DIST_BACKEND") or ("nccl" if device is not None and device.type == "cuda" else "gloo")
+        if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
 
