@@ -300,6 +300,7 @@ static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_st
     int algo = f->algo;
     if (algo == SFE_FIR_ALGO_AUTO) algo = f->fft_ok ? SFE_FIR_ALGO_FFT : SFE_FIR_ALGO_DIRECT;
     int rc;
+    bool hist_fused = false;
     if (algo == SFE_FIR_ALGO_FFT) {
         if (!f->fft_ok) {
             set_error("fir: %d taps exceed what one 4096-point transform can overlap", f->n_taps);
@@ -309,6 +310,8 @@ static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_st
         a.in = d_in;
         a.out = d_out;
         a.hist = f->d_hist[f->cur];
+        hist_fused = n >= (size_t)f->hl;                 // else the old history still contributes
+        a.hist_out = hist_fused ? f->d_hist[f->cur ^ 1] : nullptr;
         a.hs = f->d_hs;
         a.tw1 = f->d_tw1;
         a.tw2 = f->d_tw2;
@@ -360,9 +363,11 @@ static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_st
         }
     }
     if (rc != SFE_OK) return rc;
-    rc = launch_history_update(d_in, (long long)n, (long long)in_stride, f->d_hist[f->cur],
-                               f->d_hist[f->cur ^ 1], f->hl, f->data_complex ? 2 : 1, f->n_channels, s, f->in_u8);
-    if (rc != SFE_OK) return rc;
+    if (!hist_fused) {
+        rc = launch_history_update(d_in, (long long)n, (long long)in_stride, f->d_hist[f->cur],
+                                   f->d_hist[f->cur ^ 1], f->hl, f->data_complex ? 2 : 1, f->n_channels, s, f->in_u8);
+        if (rc != SFE_OK) return rc;
+    }
     f->cur ^= 1;
     return SFE_OK;
 }

@@ -43,6 +43,8 @@ struct FirFftArgs {
     const void *in;       // channel 0 input
     void       *out;
     const void *hist;     // [n_channels][hl] samples preceding `in`
+    void       *hist_out; // if non-null (needs n >= hl): the kernel also writes the NEXT call's
+                          // history, in[n-hl .. n) as float32, saving the separate carry-over launch
     const v2f  *hs;       // [16][256] taps spectrum / 4096, per-thread order (see fir_fft.hip)
     const v2f  *tw1;      // [7][256]   rows 1..3: W_4096^(t k), rows 4..6: W_4096^(4 t k)
     const v2f  *tw2;      // [7][16]    rows 1..3: W_256^(n0 k),  rows 4..6: W_256^(4 n0 k)

@@ -97,6 +97,16 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
     }
 
     const int row0 = a.hl >> 8;   // rows discarded by overlap-save
+    // state carry-over fused in (one workgroup per channel): next call's history = the last hl
+    // input samples, converted to float32 if the stream is u8
+    if (a.hist_out && blockIdx.x == 0) {
+        char *ho = static_cast<char *>(a.hist_out) + (size_t)ch * a.hl * (IN_C ? 8 : 4);
+        for (int r = 0; r < row0; r++) {
+            const v2f s = load_sample<IN_C, IN_U8>(in_c + (a.n - a.hl + 256 * r) * ISZ, t);
+            if constexpr (IN_C) reinterpret_cast<v2f *>(ho)[256 * r + t] = s;
+            else reinterpret_cast<float *>(ho)[256 * r + t] = s.x;
+        }
+    }
     v2f hreg[16];
     if (HREG) {
 #pragma unroll
