@@ -33,6 +33,29 @@ int hip_fail(hipError_t e, const char *what)
     return e == hipErrorOutOfMemory ? SFE_ENOMEM : (e == hipErrorNoDevice ? SFE_ENODEV : SFE_EHIP);
 }
 
+// Every entry point that touches a handle runs on the handle's device and puts the caller's
+// current device back afterwards (the library must not change the caller's HIP context state).
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) ok = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+#define SFE_ON_DEVICE(dev)                                   \
+    DeviceGuard guard__(dev);                                \
+    if (!guard__.ok) {                                       \
+        set_error("cannot select device %d", (int)(dev));    \
+        return SFE_EHIP;                                     \
+    }
+
 static int use_device(int device)
 {
     int n = 0;
@@ -198,6 +221,7 @@ static const PolyMfmaPlan *get_mfma_plan(MfmaCache &cache, const std::vector<flo
 
 // ------------------------------------------------------------------------------ FIR
 struct Fir {
+    uint32_t magic = 0x46495231u;   // 'FIR1': catches stale or foreign handles
     int n_taps = 0, taps_complex = 0, data_complex = 0, out_complex = 0, n_channels = 1;
     int device = 0, algo = SFE_FIR_ALGO_AUTO, in_u8 = 0;
     int blk = 0, block_hint = 0;
@@ -219,10 +243,21 @@ struct Fir {
     size_t hist_bytes() const { return (size_t)n_channels * hl * (data_complex ? 8 : 4); }
 };
 
+static Fir *as_fir(void *h)
+{
+    Fir *f = static_cast<Fir *>(h);
+    if (f && f->magic != 0x46495231u) {
+        set_error("not a live FIR handle");
+        return nullptr;
+    }
+    return f;
+}
+
 static void fir_free(Fir *f)
 {
     if (!f) return;
-    (void)hipSetDevice(f->device);
+    f->magic = 0;
+    DeviceGuard g(f->device);
     if (f->d_hs) (void)hipFree(f->d_hs);
     if (f->d_tw1) (void)hipFree(f->d_tw1);
     if (f->d_tw2) (void)hipFree(f->d_tw2);
@@ -374,6 +409,7 @@ static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_st
 
 // ------------------------------------------------------------------ resample / decimate
 struct Rs {
+    uint32_t magic = 0x52533031u;   // 'RS01'
     int U = 1, n_taps = 0, plen = 0, blksize = 0, data_complex = 0, n_channels = 1;
     int device = 0, mode = SFE_RS_RESAMPLE, exact_stream = 0, in_u8 = 0;
     int hl = 0;
@@ -399,10 +435,21 @@ struct Rs {
     int esz() const { return data_complex ? 8 : 4; }
 };
 
+static Rs *as_rs(void *h)
+{
+    Rs *r = static_cast<Rs *>(h);
+    if (r && r->magic != 0x52533031u) {
+        set_error("not a live resample/decimate handle");
+        return nullptr;
+    }
+    return r;
+}
+
 static void rs_free(Rs *r)
 {
     if (!r) return;
-    (void)hipSetDevice(r->device);
+    r->magic = 0;
+    DeviceGuard g(r->device);
     if (r->d_taps) (void)hipFree(r->d_taps);
     r->plans.clear();
     r->mfma_plans.clear();
@@ -592,8 +639,11 @@ int sfe_dsp_fir_create(const float *taps, int n_taps, int taps_complex, int data
         set_error("fir_create: fft_len %d leaves no block for %d taps (blkconv.cxx:47)", block_hint, n_taps);
         return SFE_EINVAL;
     }
+    int prev_dev = -1;
+    (void)hipGetDevice(&prev_dev);
     int rc = use_device(device);
     if (rc != SFE_OK) return rc;
+    struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore__{prev_dev};
     Fir *f = new (std::nothrow) Fir;
     if (!f) return SFE_ENOMEM;
     f->n_taps = n_taps;
@@ -643,7 +693,7 @@ int sfe_dsp_fir_create(const float *taps, int n_taps, int taps_complex, int data
 
 int sfe_dsp_fir_host_buffer(sfe_fir_t h, float **buf, int *blk)
 {
-    Fir *f = static_cast<Fir *>(h);
+    Fir *f = as_fir(h);
     if (!f || !f->h_buf) {
         set_error("fir_host_buffer: handle was created without block_hint");
         return SFE_ESTATE;
@@ -655,12 +705,12 @@ int sfe_dsp_fir_host_buffer(sfe_fir_t h, float **buf, int *blk)
 
 int sfe_dsp_fir_process_block(sfe_fir_t h)
 {
-    Fir *f = static_cast<Fir *>(h);
+    Fir *f = as_fir(h);
     if (!f || !f->h_buf) {
         set_error("fir_process_block: handle was created without block_hint");
         return SFE_ESTATE;
     }
-    SFE_HIP(hipSetDevice(f->device));
+    SFE_ON_DEVICE(f->device);
     const size_t in_b = (size_t)f->blk * (f->data_complex ? 8 : 4);
     const size_t out_b = (size_t)f->blk * (f->out_complex ? 8 : 4);
     SFE_HIP(hipMemcpyAsync(f->d_blk_in, f->h_buf, in_b, hipMemcpyHostToDevice, f->stream));
@@ -674,7 +724,7 @@ int sfe_dsp_fir_process_block(sfe_fir_t h)
 int sfe_dsp_fir_process_stream(sfe_fir_t h, const void *d_in, void *d_out, size_t n,
                                size_t in_stride, size_t out_stride, sfe_stream_t stream)
 {
-    Fir *f = static_cast<Fir *>(h);
+    Fir *f = as_fir(h);
     if (!f || (n && (!d_in || !d_out))) {
         set_error("fir_process_stream: null handle or buffer");
         return SFE_EINVAL;
@@ -691,13 +741,13 @@ int sfe_dsp_fir_process_stream(sfe_fir_t h, const void *d_in, void *d_out, size_
         set_error("fir_process_stream: buffers must be 8-byte aligned (2-byte for u8 input)");
         return SFE_EINVAL;
     }
-    SFE_HIP(hipSetDevice(f->device));
+    SFE_ON_DEVICE(f->device);
     return fir_run(f, d_in, d_out, n, in_stride, out_stride, (hipStream_t)stream);
 }
 
 int sfe_dsp_fir_process_host(sfe_fir_t h, const void *in, void *out, size_t n)
 {
-    Fir *f = static_cast<Fir *>(h);
+    Fir *f = as_fir(h);
     if (!f || (n && (!in || !out))) {
         set_error("fir_process_host: null handle or buffer");
         return SFE_EINVAL;
@@ -706,7 +756,7 @@ int sfe_dsp_fir_process_host(sfe_fir_t h, const void *in, void *out, size_t n)
         set_error("fir_process_host: single-channel handles only");
         return SFE_EINVAL;
     }
-    SFE_HIP(hipSetDevice(f->device));
+    SFE_ON_DEVICE(f->device);
     const size_t in_e = f->data_complex ? 8 : 4, out_e = f->out_complex ? 8 : 4;
     const size_t CH = (size_t)1 << 20;            // samples per staged chunk
     if (!f->h_stage) {
@@ -732,7 +782,7 @@ int sfe_dsp_fir_process_host(sfe_fir_t h, const void *in, void *out, size_t n)
 
 int sfe_dsp_fir_set_input_format(sfe_fir_t h, int fmt)
 {
-    Fir *f = static_cast<Fir *>(h);
+    Fir *f = as_fir(h);
     if (!f || (fmt != SFE_FMT_F32 && fmt != SFE_FMT_U8)) return SFE_EINVAL;
     if (fmt == SFE_FMT_U8 && (!f->fft_ok || f->taps_complex)) {
         set_error("fir_set_input_format: u8 input needs the FFT kernel with real taps");
@@ -744,7 +794,7 @@ int sfe_dsp_fir_set_input_format(sfe_fir_t h, int fmt)
 
 int sfe_dsp_fir_set_algo(sfe_fir_t h, int algo)
 {
-    Fir *f = static_cast<Fir *>(h);
+    Fir *f = as_fir(h);
     if (!f || algo < SFE_FIR_ALGO_AUTO || algo > SFE_FIR_ALGO_FFT) return SFE_EINVAL;
     f->algo = algo;
     return SFE_OK;
@@ -752,9 +802,9 @@ int sfe_dsp_fir_set_algo(sfe_fir_t h, int algo)
 
 int sfe_dsp_fir_reset(sfe_fir_t h)
 {
-    Fir *f = static_cast<Fir *>(h);
+    Fir *f = as_fir(h);
     if (!f) return SFE_EINVAL;
-    SFE_HIP(hipSetDevice(f->device));
+    SFE_ON_DEVICE(f->device);
     SFE_HIP(hipDeviceSynchronize());
     for (int i = 0; i < 2; i++) SFE_HIP(hipMemset(f->d_hist[i], 0, f->hist_bytes()));
     return SFE_OK;
@@ -762,9 +812,9 @@ int sfe_dsp_fir_reset(sfe_fir_t h)
 
 int sfe_dsp_fir_destroy(sfe_fir_t h)
 {
-    Fir *f = static_cast<Fir *>(h);
+    Fir *f = as_fir(h);
     if (!f) return SFE_OK;
-    (void)hipSetDevice(f->device);
+    DeviceGuard g(f->device);
     (void)hipDeviceSynchronize();
     fir_free(f);
     return SFE_OK;
@@ -797,8 +847,11 @@ int sfe_dsp_rs_create(const float *taps, int n_taps, int upsample, int blksize, 
         set_error("rs_create: bad arguments");
         return SFE_EINVAL;
     }
+    int prev_dev = -1;
+    (void)hipGetDevice(&prev_dev);
     int rc = use_device(device);
     if (rc != SFE_OK) return rc;
+    struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore__{prev_dev};
     Rs *r = new (std::nothrow) Rs;
     if (!r) return SFE_ENOMEM;
     r->U = upsample;
@@ -840,7 +893,7 @@ int sfe_dsp_rs_create(const float *taps, int n_taps, int upsample, int blksize, 
 int sfe_dsp_rs_process(sfe_rs_t h, const float *in, int n_in, float *out, int out_len, float rate,
                        int *n_out)
 {
-    Rs *r = static_cast<Rs *>(h);
+    Rs *r = as_rs(h);
     if (!r || !n_out) return SFE_EINVAL;
     *n_out = 0;
     if (r->n_channels != 1) {
@@ -868,7 +921,7 @@ int sfe_dsp_rs_process(sfe_rs_t h, const float *in, int n_in, float *out, int ou
         return SFE_OK;
     }
     if (n_in < 0 || out_len < 0 || (n_in && !in) || (out_len && !out)) return SFE_EINVAL;
-    SFE_HIP(hipSetDevice(r->device));
+    SFE_ON_DEVICE(r->device);
 
     int rc = rs_ensure_sched(r, (size_t)out_len + 1);
     if (rc != SFE_OK) return rc;
@@ -925,7 +978,7 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
                               void *d_out, size_t out_cap, size_t out_stride, float rate,
                               size_t *n_out, sfe_stream_t stream)
 {
-    Rs *r = static_cast<Rs *>(h);
+    Rs *r = as_rs(h);
     if (!r || !n_out) return SFE_EINVAL;
     *n_out = 0;
     if (r->mode == SFE_RS_RESAMPLE ? (rate < 1.0 / r->U) : (rate < 1.0)) {
@@ -937,7 +990,7 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         set_error("rs_process_stream: null or aliased buffers");
         return SFE_EINVAL;
     }
-    SFE_HIP(hipSetDevice(r->device));
+    SFE_ON_DEVICE(r->device);
     hipStream_t s = (hipStream_t)stream;
     const float stepf = rate * (float)r->U;
     const bool int_step = stepf >= 1.0f && stepf == floorf(stepf) && stepf < 1.0e6f && r->ts.mu == 0.0f &&
@@ -1139,7 +1192,7 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
 
 int sfe_dsp_rs_set_input_format(sfe_rs_t h, int fmt)
 {
-    Rs *r = static_cast<Rs *>(h);
+    Rs *r = as_rs(h);
     if (!r || (fmt != SFE_FMT_F32 && fmt != SFE_FMT_U8)) return SFE_EINVAL;
     r->in_u8 = fmt == SFE_FMT_U8;
     return SFE_OK;
@@ -1147,7 +1200,7 @@ int sfe_dsp_rs_set_input_format(sfe_rs_t h, int fmt)
 
 int sfe_dsp_rs_set_exact(sfe_rs_t h, int exact)
 {
-    Rs *r = static_cast<Rs *>(h);
+    Rs *r = as_rs(h);
     if (!r) return SFE_EINVAL;
     r->exact_stream = exact ? 1 : 0;
     return SFE_OK;
@@ -1155,9 +1208,9 @@ int sfe_dsp_rs_set_exact(sfe_rs_t h, int exact)
 
 int sfe_dsp_rs_reset(sfe_rs_t h)
 {
-    Rs *r = static_cast<Rs *>(h);
+    Rs *r = as_rs(h);
     if (!r) return SFE_EINVAL;
-    SFE_HIP(hipSetDevice(r->device));
+    SFE_ON_DEVICE(r->device);
     SFE_HIP(hipDeviceSynchronize());
     const size_t hb = (size_t)r->n_channels * r->hl * r->esz();
     for (int i = 0; i < 2; i++) SFE_HIP(hipMemset(r->d_hist[i], 0, hb));
@@ -1169,9 +1222,9 @@ int sfe_dsp_rs_reset(sfe_rs_t h)
 
 int sfe_dsp_rs_destroy(sfe_rs_t h)
 {
-    Rs *r = static_cast<Rs *>(h);
+    Rs *r = as_rs(h);
     if (!r) return SFE_OK;
-    (void)hipSetDevice(r->device);
+    DeviceGuard g(r->device);
     (void)hipDeviceSynchronize();
     rs_free(r);
     return SFE_OK;

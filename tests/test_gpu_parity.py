@@ -444,3 +444,16 @@ def test_misuse_is_reported_not_crashed(api, L):
     fc.set_algo(L.FIR_ALGO_DIRECT)
     with pytest.raises(api.SfeError):               # complex taps need the FFT kernel
         fc.filter(synth.synth_cf32(1000))
+
+
+def test_stale_handle_is_rejected(api, L):
+    """A destroyed (or foreign) handle is reported, not dereferenced blindly."""
+    import ctypes as C
+    f = api.Fir(synth.taps_cfg2(), data_complex=True)
+    h = f._h
+    f.close()
+    lib = L.load()
+    buf = (C.c_char * 256)()              # a live allocation that is not a handle
+    rc = lib.sfe_dsp_fir_reset(C.cast(buf, C.c_void_p))
+    assert rc == L.SFE_EINVAL
+    assert h is not None
