@@ -138,6 +138,10 @@ class Fir:
         """lib.FMT_U8: process_stream reads u8 offset-binary samples (fused RX converter)."""
         check(self._L.sfe_dsp_fir_set_input_format(self._h, fmt))
 
+    def set_output_format(self, fmt):
+        """lib.FMT_TX10: process_stream writes 10-bit packed bytes (fused TX converter, real streams)."""
+        check(self._L.sfe_dsp_fir_set_output_format(self._h, fmt))
+
     def reset(self):
         check(self._L.sfe_dsp_fir_reset(self._h))
 

@@ -223,7 +223,7 @@ static const PolyMfmaPlan *get_mfma_plan(MfmaCache &cache, const std::vector<flo
 struct Fir {
     uint32_t magic = 0x46495231u;   // 'FIR1': catches stale or foreign handles
     int n_taps = 0, taps_complex = 0, data_complex = 0, out_complex = 0, n_channels = 1;
-    int device = 0, algo = SFE_FIR_ALGO_AUTO, in_u8 = 0;
+    int device = 0, algo = SFE_FIR_ALGO_AUTO, in_u8 = 0, out_tx10 = 0;
     int blk = 0, block_hint = 0;
     int hl = 0;                 // carried history per channel, samples (multiple of 256)
     bool fft_ok = false;
@@ -356,10 +356,10 @@ static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_st
         a.hl = f->hl;
         a.advance = FFT_N - f->hl;
         a.nblk = ((long long)n + a.advance - 1) / a.advance;
-        rc = launch_fir_fft(a, f->data_complex, f->out_complex, f->in_u8, f->n_channels, s);
+        rc = launch_fir_fft(a, f->data_complex, f->out_complex, f->in_u8, f->out_tx10, f->n_channels, s);
     } else {
-        if (f->taps_complex || f->in_u8) {
-            set_error("fir: the direct kernel takes real taps and float input; use SFE_FIR_ALGO_FFT");
+        if (f->taps_complex || f->in_u8 || f->out_tx10) {
+            set_error("fir: the direct kernel takes real taps and float input/output; use SFE_FIR_ALGO_FFT");
             return SFE_EINVAL;
         }
         const PolyTiledPlan *pl = get_tiled_plan(f->plans, f->h_taps, 1, f->n_taps, 1, 0, &rc);
@@ -789,6 +789,18 @@ int sfe_dsp_fir_set_input_format(sfe_fir_t h, int fmt)
         return SFE_ESTATE;
     }
     f->in_u8 = fmt == SFE_FMT_U8;
+    return SFE_OK;
+}
+
+int sfe_dsp_fir_set_output_format(sfe_fir_t h, int fmt)
+{
+    Fir *f = as_fir(h);
+    if (!f || (fmt != SFE_FMT_F32 && fmt != SFE_FMT_TX10)) return SFE_EINVAL;
+    if (fmt == SFE_FMT_TX10 && (!f->fft_ok || f->taps_complex || f->data_complex)) {
+        set_error("fir_set_output_format: 10-bit output needs a real stream, real taps and the FFT kernel");
+        return SFE_ESTATE;
+    }
+    f->out_tx10 = fmt == SFE_FMT_TX10;
     return SFE_OK;
 }
 

@@ -57,7 +57,8 @@ struct FirFftArgs {
 // in_u8: the input stream is the device wire format, u8 offset binary (one byte per real sample,
 // an (I, Q) byte pair per complex sample); it is converted on load, (b - 128) * (1/127)
 // (gr-simplefe/lib/source_c_impl.cc:121-132).  History stays float32.
-int launch_fir_fft(const FirFftArgs &a, int in_complex, int out_complex, int in_u8, int n_channels,
+// out_tx10: real output packed as 10-bit offset binary, 4 samples in 5 bytes (sink_f_impl.cc:117-143)
+int launch_fir_fft(const FirFftArgs &a, int in_complex, int out_complex, int in_u8, int out_tx10, int n_channels,
                    hipStream_t s);
 
 struct PolyArgs {

@@ -54,7 +54,11 @@ __device__ __forceinline__ v2f load_sample(const void *p, unsigned lane)
 // PAIR (real data, real taps only): the real and imaginary parts of one transform carry two
 // CONSECUTIVE real segments of the stream (z = x_A + j x_B; real taps keep them apart), so a real
 // stream costs what a complex one does per sample instead of twice as much.
-template <bool IN_C, bool OUT_C, int WAVES, bool PREFETCH, bool SWZ, bool HREG = false, bool IN_U8 = false, bool PAIR = false>
+// OUT_TX10 (with PAIR): the real output is written in the device's transmit wire format, 10-bit
+// offset binary, 4 samples in 5 bytes -- ((short)(x*511)+512)&0x3FF, packed as
+// gr-simplefe/lib/sink_f_impl.cc:117-143 / examples/bpsk/bpsk.cxx:76-101 do on the host.
+template <bool IN_C, bool OUT_C, int WAVES, bool PREFETCH, bool SWZ, bool HREG = false, bool IN_U8 = false, bool PAIR = false,
+          bool OUT_TX10 = false>
 __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 {
     __shared__ v2f lds[FFT_ROWS * LDS_K2_STRIDE];
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 
     constexpr int ISZ = IN_U8 ? (IN_C ? 2 : 1) : (IN_C ? 8 : 4);   // bytes per input sample
     const char *in_c = static_cast<const char *>(a.in) + (size_t)ch * a.in_stride * ISZ;
-    char *out_c = static_cast<char *>(a.out) + (size_t)ch * a.out_stride * (OUT_C ? 8 : 4);
+    char *out_c = static_cast<char *>(a.out) + (OUT_TX10 ? (size_t)ch * (a.out_stride / 4) * 5 : (size_t)ch * a.out_stride * (OUT_C ? 8 : 4));
     const char *hist_c = static_cast<const char *>(a.hist) + (size_t)ch * a.hl * (IN_C ? 8 : 4);
 
     // Per-thread twiddle bases, resident for the whole launch.  A twiddle with exponent
@@ -246,10 +250,32 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             for (int r = 0; r < 16; r++) {
                 if (r < row0) continue;
                 const v2f y = v[P16(r)];
+                if constexpr (OUT_TX10) {
+                    // lanes 4g..4g+3 hold 4 consecutive samples: quantise in place, gather the four
+                    // 10-bit codes into lane 4g, which writes the 5 bytes of group (row + t)/4
+                    const int lane = (int)(t & 63u);
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const long long o = (q ? oB : oA) + 256 * r;                 // multiple of 256
+                        const unsigned u = (unsigned)((int)(short)(int)((q ? y.y : y.x) * 511.0f) + 512) & 0x3FFu;
+                        const unsigned u0 = __shfl(u, lane & ~3), u1 = __shfl(u, (lane & ~3) + 1);
+                        const unsigned u2 = __shfl(u, (lane & ~3) + 2), u3 = __shfl(u, (lane & ~3) + 3);
+                        // only whole groups of 4 are emitted (the reference's loop steps by 4)
+                        if ((t & 3u) == 0 && o + (long long)t + 3 < a.n) {
+                            unsigned char *d = reinterpret_cast<unsigned char *>(out_c) + ((o + (long long)t) >> 2) * 5;
+                            d[0] = (unsigned char)((u0 >> 8) | ((u1 >> 8) << 2) | ((u2 >> 8) << 4) | ((u3 >> 8) << 6));
+                            d[1] = (unsigned char)u0;
+                            d[2] = (unsigned char)u1;
+                            d[3] = (unsigned char)u2;
+                            d[4] = (unsigned char)u3;
+                        }
+                    }
+                } else {
                 if (wholeA || oA + 256 * r + (long long)t < a.n)
                     __builtin_nontemporal_store(y.x, reinterpret_cast<float *>(out_c + (oA + 256 * r) * 4) + t);
                 if (wholeB || oB + 256 * r + (long long)t < a.n)
                     __builtin_nontemporal_store(y.y, reinterpret_cast<float *>(out_c + (oB + 256 * r) * 4) + t);
+                }
             }
             continue;
         }
@@ -339,7 +365,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_copy_pattern_nt_kernel(FirFftA
 
 }  // namespace
 
-int launch_fir_fft(const FirFftArgs &a, int in_complex, int out_complex, int in_u8, int n_channels,
+int launch_fir_fft(const FirFftArgs &a, int in_complex, int out_complex, int in_u8, int out_tx10, int n_channels,
                    hipStream_t s)
 {
     if (a.nblk <= 0) return SFE_OK;
@@ -381,13 +407,23 @@ int launch_fir_fft(const FirFftArgs &a, int in_complex, int out_complex, int in_
     case 7: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, true, false>), grid, block, 0, s, a); break; \
     default: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 4, false, false, true>), grid, block, 0, s, a); break; \
     }
-    if (!in_complex && !out_complex && !copy_only && !(ev && ev[0] >= '2' && ev[0] <= '4')) {
+    if (out_tx10 && (in_complex || out_complex)) {
+        set_error("fir_fft: 10-bit output is built for real streams (the bpsk transmit chain)");
+        return SFE_EINVAL;
+    }
+    if (!in_complex && !out_complex && !copy_only && (out_tx10 || !(ev && ev[0] >= '2' && ev[0] <= '4'))) {
         // real stream, real taps: two segments per transform (PAIR); a.nblk counts transforms
         FirFftArgs b = a;
         b.nblk = (a.nblk + 1) / 2;
         long long g2 = b.nblk < gx ? b.nblk : gx;
         dim3 grid2((unsigned)(g2 < 1 ? 1 : g2), (unsigned)n_channels);
-        if (in_u8) hipLaunchKernelGGL((fir_fft4096_kernel<false, false, 4, false, false, true, true, true>), grid2, block, 0, s, b);
+        if (out_tx10) {
+            if (in_u8) {
+                set_error("fir_fft: u8 input together with 10-bit output is not built");
+                return SFE_EINVAL;
+            }
+            hipLaunchKernelGGL((fir_fft4096_kernel<false, false, 4, false, false, true, false, true, true>), grid2, block, 0, s, b);
+        } else if (in_u8) hipLaunchKernelGGL((fir_fft4096_kernel<false, false, 4, false, false, true, true, true>), grid2, block, 0, s, b);
         else hipLaunchKernelGGL((fir_fft4096_kernel<false, false, 4, false, false, true, false, true>), grid2, block, 0, s, b);
     } else if (in_u8) {   // wire-format input: default kernel shape only
         if (in_complex && out_complex) hipLaunchKernelGGL((fir_fft4096_kernel<true, true, 4, false, false, true, true>), grid, block, 0, s, a);

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "libsfe_dsp.so")
 SFE_OK, SFE_EINVAL, SFE_ENOMEM, SFE_EHIP, SFE_ENODEV, SFE_ESTATE, SFE_ERANGE = 0, -1, -2, -3, -4, -5, -6
 FIR_ALGO_AUTO, FIR_ALGO_DIRECT, FIR_ALGO_FFT = 0, 1, 2
 RS_RESAMPLE, RS_DECIMATE = 0, 1
-FMT_F32, FMT_U8 = 0, 1
+FMT_F32, FMT_U8, FMT_TX10 = 0, 1, 2
 
 
 class TimeState(C.Structure):
@@ -50,6 +50,7 @@ SIGNATURES = {
     "sfe_dsp_fir_process_host": (i32, [vp, vp, vp, sz]),
     "sfe_dsp_fir_set_algo": (i32, [vp, i32]),
     "sfe_dsp_fir_set_input_format": (i32, [vp, i32]),
+    "sfe_dsp_fir_set_output_format": (i32, [vp, i32]),
     "sfe_dsp_rs_set_input_format": (i32, [vp, i32]),
     "sfe_dsp_fir_reset": (i32, [vp]),
     "sfe_dsp_fir_destroy": (i32, [vp]),

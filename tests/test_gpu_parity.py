@@ -457,3 +457,38 @@ def test_stale_handle_is_rejected(api, L):
     rc = lib.sfe_dsp_fir_reset(C.cast(buf, C.c_void_p))
     assert rc == L.SFE_EINVAL
     assert h is not None
+
+
+def test_fir_tx10_output_fused(api, L, orc):
+    """Pulse-shaping chain with the transmit converter fused into the store: the packed bytes
+    equal oracle.tx_f32_to_10bit applied to the float output of the same kernel, bit for bit
+    (sink_f_impl.cc:117-143), over chunked calls; only whole groups of 4 samples are emitted."""
+    taps = synth.lowpass_taps(111, 0.2)
+    n = 40000 + 3                                     # 3 trailing samples form no group
+    x = (0.6 * synth.synth_f32(n)).astype(np.float32)
+    yf = api.Fir(taps, data_complex=False, algo=L.FIR_ALGO_FFT).filter(x)[0]
+    want = orc.tx_f32_to_10bit(yf)
+    f = api.Fir(taps, data_complex=False, algo=L.FIR_ALGO_FFT)
+    f.set_output_format(L.FMT_TX10)
+    d_in = api.DeviceArray.from_numpy(x)
+    d_out = api.DeviceArray(n // 4 * 5 // 4 + 8)
+    d_out.zero()
+    f.process_stream(d_in, d_out, n)
+    got = d_out.to_numpy().view(np.uint8)[: n // 4 * 5]
+    assert len(want) == n // 4 * 5 and np.array_equal(got, want)
+    # chunked, chunk sizes multiples of 4 so groups line up across calls
+    f.reset()
+    outs = []
+    for a, b in ((0, 4000), (4000, 4004), (4004, 20000), (20000, 40000)):
+        d_i = api.DeviceArray.from_numpy(x[a:b])
+        d_o = api.DeviceArray((b - a) // 4 * 5 // 4 + 8)
+        f.process_stream(d_i, d_o, b - a)
+        outs.append(d_o.to_numpy().view(np.uint8)[: (b - a) // 4 * 5])
+    got2 = np.concatenate(outs)
+    # chunk seams move transform boundaries: codes may differ by 1 LSB where a sample sits on a step
+    b5a, b5b = got2.reshape(-1, 5).astype(np.int32), want[: len(got2)].reshape(-1, 5).astype(np.int32)
+    va = np.stack([((b5a[:, 0] >> (2 * k)) & 3) << 8 | b5a[:, 1 + k] for k in range(4)], 1)
+    vb = np.stack([((b5b[:, 0] >> (2 * k)) & 3) << 8 | b5b[:, 1 + k] for k in range(4)], 1)
+    assert np.abs(va - vb).max() <= 1 and np.count_nonzero(va != vb) <= 0.002 * va.size
+    with pytest.raises(api.SfeError):                 # complex streams: not built
+        api.Fir(taps, data_complex=True).set_output_format(L.FMT_TX10)
