@@ -14,21 +14,73 @@ namespace sfe {
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // a * w
+// (each primitive is ONE asm statement: hipcc pads an s_nop after every asm statement whose
+// result the next instruction reads, so two statements per complex multiply cost two pads)
 __device__ __forceinline__ v2f cmul(v2f a, v2f w)
 {
     v2f t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));               // (ax wx, ay wx)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"        // (-ay wy, ax wy) + t
-        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    asm("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[1,0]\n\t"                                        // t = (ax wx, ay wx)
+        "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"        // (-ay wy, ax wy) + t
+        : "=v"(r), "=&v"(t) : "v"(a), "v"(w));
     return r;
 }
 // a * conj(w)
 __device__ __forceinline__ v2f cmul_conj(v2f a, v2f w)
 {
     v2f t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"        // (ay wy, -ax wy) + t
-        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    asm("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"        // (ay wy, -ax wy) + t
+        : "=v"(r), "=&v"(t) : "v"(a), "v"(w));
+    return r;
+}
+// (a * q) * p and (a * conj q) * conj p: the factored twiddles, four instructions, one statement
+__device__ __forceinline__ v2f cmul2(v2f a, v2f q, v2f p)
+{
+    v2f t, u, r;
+    asm("v_pk_mul_f32 %1, %3, %4 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %2, %3, %4, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_mul_f32 %1, %2, %5 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %2, %5, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+        : "=v"(r), "=&v"(t), "=&v"(u) : "v"(a), "v"(q), "v"(p));
+    return r;
+}
+__device__ __forceinline__ v2f cmul2_conj(v2f a, v2f q, v2f p)
+{
+    v2f t, u, r;
+    asm("v_pk_mul_f32 %1, %3, %4 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %2, %3, %4, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]\n\t"
+        "v_pk_mul_f32 %1, %2, %5 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %2, %5, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+        : "=v"(r), "=&v"(t), "=&v"(u) : "v"(a), "v"(q), "v"(p));
+    return r;
+}
+// s (a -+ j a), then optionally rotated by -+j: the W16^2 / W16^6 multiplies in two instructions
+__device__ __forceinline__ v2f w16_2_fwd(v2f a, v2f s)    // s (ax+ay, ay-ax)
+{
+    v2f t, r;
+    asm("v_pk_add_f32 %1, %2, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %0, %1, %3 op_sel_hi:[1,0]" : "=v"(r), "=&v"(t) : "v"(a), "v"(s));
+    return r;
+}
+__device__ __forceinline__ v2f w16_2_inv(v2f a, v2f s)    // s (ax-ay, ay+ax)
+{
+    v2f t, r;
+    asm("v_pk_add_f32 %1, %2, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+        "v_pk_mul_f32 %0, %1, %3 op_sel_hi:[1,0]" : "=v"(r), "=&v"(t) : "v"(a), "v"(s));
+    return r;
+}
+__device__ __forceinline__ v2f w16_6_fwd(v2f a, v2f s)    // -j * s (ax+ay, ay-ax)
+{
+    v2f t, r;
+    asm("v_pk_add_f32 %1, %2, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %0, %1, %3 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r), "=&v"(t) : "v"(a), "v"(s));
+    return r;
+}
+__device__ __forceinline__ v2f w16_6_inv(v2f a, v2f s)    // +j * s (ax-ay, ay+ax)
+{
+    v2f t, r;
+    asm("v_pk_add_f32 %1, %2, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+        "v_pk_mul_f32 %0, %1, %3 op_sel:[1,0] op_sel_hi:[0,0] neg_lo:[1,0]" : "=v"(r), "=&v"(t) : "v"(a), "v"(s));
     return r;
 }
 // a - j b = (ax + by, ay - bx)
@@ -87,9 +139,16 @@ __host__ __device__ __forceinline__ v2f rot_pj(v2f a) { return (v2f){-a.y, a.x};
 __host__ __device__ __forceinline__ v2f scale(v2f a, v2f s) { return (v2f){a.x * s.x, a.y * s.x}; }
 __host__ __device__ __forceinline__ v2f scale_mj(v2f a, v2f s) { return (v2f){a.y * s.x, -a.x * s.x}; }
 __host__ __device__ __forceinline__ v2f scale_pj(v2f a, v2f s) { return (v2f){-a.y * s.x, a.x * s.x}; }
+__host__ __device__ __forceinline__ v2f cmul2(v2f a, v2f q, v2f p) { return cmul(cmul(a, q), p); }
+__host__ __device__ __forceinline__ v2f cmul2_conj(v2f a, v2f q, v2f p) { return cmul_conj(cmul_conj(a, q), p); }
+__host__ __device__ __forceinline__ v2f w16_2_fwd(v2f a, v2f s) { return scale(add_mj(a, a), s); }
+__host__ __device__ __forceinline__ v2f w16_2_inv(v2f a, v2f s) { return scale(add_pj(a, a), s); }
+__host__ __device__ __forceinline__ v2f w16_6_fwd(v2f a, v2f s) { return scale_mj(add_mj(a, a), s); }
+__host__ __device__ __forceinline__ v2f w16_6_inv(v2f a, v2f s) { return scale_pj(add_pj(a, a), s); }
 #endif
 
-// radix-4 butterfly, DIR = -1 forward (W4 = -j), +1 inverse: 8 packed adds
+// radix-4 butterfly, DIR = -1 forward (W4 = -j), +1 inverse: 8 packed adds.  (Written as one
+// in-place asm statement it costs MORE: the "+v" ties make hipcc copy registers around it.)
 template <int DIR>
 __host__ __device__ __forceinline__ void dft4(v2f &a0, v2f &a1, v2f &a2, v2f &a3)
 {
@@ -110,9 +169,9 @@ __host__ __device__ __forceinline__ v2f tw16(v2f a)
     if constexpr (M == 0) return a;
     else if constexpr (M == 4) return DIR < 0 ? rot_mj(a) : rot_pj(a);
     else if constexpr (M == 2)   // R(1 -+ j) a = R (a -+ j a)
-        return scale(DIR < 0 ? add_mj(a, a) : add_pj(a, a), (v2f){R, R});
+        return DIR < 0 ? w16_2_fwd(a, (v2f){R, R}) : w16_2_inv(a, (v2f){R, R});
     else if constexpr (M == 6)   // W^6 = -+j W^2
-        return DIR < 0 ? scale_mj(add_mj(a, a), (v2f){R, R}) : scale_pj(add_pj(a, a), (v2f){R, R});
+        return DIR < 0 ? w16_6_fwd(a, (v2f){R, R}) : w16_6_inv(a, (v2f){R, R});
     else if constexpr (M == 1) return cmul(a, (v2f){C1, sg * S1});
     else if constexpr (M == 3) return cmul(a, (v2f){S1, sg * C1});
     else /* M == 9 */ return cmul(a, (v2f){-C1, -sg * S1});

@@ -175,8 +175,9 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             v2f x = nx[P16(k)];
-            if (k >> 2) x = cmul(x, q1[k >> 2]);
-            if (k & 3) x = cmul(x, p1[k & 3]);
+            if ((k >> 2) && (k & 3)) x = cmul2(x, q1[k >> 2], p1[k & 3]);
+            else if (k >> 2) x = cmul(x, q1[k >> 2]);
+            else if (k & 3) x = cmul(x, p1[k & 3]);
             lds[base_a + k * LDS_K2_STRIDE] = x;
         }
         lds_barrier();
@@ -191,8 +192,9 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             v2f x = v[P16(k)];
-            if (k >> 2) x = cmul(x, q2[k >> 2]);
-            if (k & 3) x = cmul(x, p2[k & 3]);
+            if ((k >> 2) && (k & 3)) x = cmul2(x, q2[k >> 2], p2[k & 3]);
+            else if (k >> 2) x = cmul(x, q2[k >> 2]);
+            else if (k & 3) x = cmul(x, p2[k & 3]);
             lds[cell_b2(k)] = x;
         }
         lds_barrier();
@@ -220,8 +222,9 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             v2f x = lds[cell_b2(r)];
-            if (r >> 2) x = cmul_conj(x, q2[r >> 2]);
-            if (r & 3) x = cmul_conj(x, p2[r & 3]);
+            if ((r >> 2) && (r & 3)) x = cmul2_conj(x, q2[r >> 2], p2[r & 3]);
+            else if (r >> 2) x = cmul_conj(x, q2[r >> 2]);
+            else if (r & 3) x = cmul_conj(x, p2[r & 3]);
             v[r] = x;
         }
         dft16<+1>(v);
@@ -235,8 +238,9 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             v2f x = lds[base_a + r * LDS_K2_STRIDE];
-            if (r >> 2) x = cmul_conj(x, q1[r >> 2]);
-            if (r & 3) x = cmul_conj(x, p1[r & 3]);
+            if ((r >> 2) && (r & 3)) x = cmul2_conj(x, q1[r >> 2], p1[r & 3]);
+            else if (r >> 2) x = cmul_conj(x, q1[r >> 2]);
+            else if (r & 3) x = cmul_conj(x, p1[r & 3]);
             v[r] = x;
         }
         dft16<+1>(v);
