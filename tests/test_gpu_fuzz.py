@@ -1,0 +1,91 @@
+"""Randomised parity sweep on the GPU (fixed seeds): many small random shapes through the C ABI
+against the oracle -- ragged lengths, odd chunkings, channel strides, tap counts around the
+kernel's internal boundaries (256/257 taps: one vs two overlap rows; 3840-sample transform
+advance; 512-m polyphase tiles).  `-m gpu`."""
+import numpy as np
+import pytest
+
+from simplefe_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    from simplefe_amd import api as a
+    return a
+
+
+@pytest.fixture(scope="module")
+def L():
+    from simplefe_amd import lib
+    return lib
+
+
+def _cuts(rng, n, k):
+    c = sorted(set([0, n] + [int(v) for v in rng.integers(1, max(n, 2), size=k)]))
+    return [(a, b) for a, b in zip(c[:-1], c[1:]) if b > a]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fir_random_shapes(api, L, seed):
+    rng = np.random.default_rng(1000 + seed)
+    n_taps = int(rng.choice([1, 2, 31, 63, 111, 255, 256, 257, 258, 511, 513, 1000, 2049, 3841]))
+    cplx = bool(rng.integers(0, 2))
+    ctaps = cplx and bool(rng.integers(0, 2))
+    nch = int(rng.choice([1, 1, 2, 3]))
+    n = int(rng.choice([1, 7, 255, 3839, 3840, 3841, 7680, 7681, 12001, 20000, 50001]))
+    stride = n + int(rng.integers(0, 50))
+    taps = (rng.standard_normal(n_taps) / np.sqrt(n_taps)).astype(np.float32)
+    if ctaps:
+        taps = (taps + 1j * (rng.standard_normal(n_taps) / np.sqrt(n_taps))).astype(np.complex64)
+    w = 2 if cplx else 1
+    x = np.zeros((nch, w * stride), np.float32)
+    for c in range(nch):
+        x[c, : w * n] = synth.synth_f32(w * n, ch=seed * 8 + c)
+    f = api.Fir(taps, data_complex=cplx, n_channels=nch)
+    wo = 2 if (cplx or ctaps) else 1
+    y = np.zeros((nch, wo * n), np.float32)
+    for a, b in _cuts(rng, n, int(rng.integers(0, 4))):
+        m = b - a
+        d_in = api.DeviceArray.from_numpy(np.ascontiguousarray(x[:, w * a: w * a + w * stride - w * a][:, : w * (stride - a)]))
+        d_out = api.DeviceArray(nch * wo * (m + 3))
+        f.process_stream(d_in, d_out, m, in_stride=stride - a, out_stride=m + 3)
+        y[:, wo * a: wo * b] = d_out.to_numpy().reshape(nch, wo * (m + 3))[:, : wo * m]
+    from scipy.signal import fftconvolve
+    for c in range(nch):
+        xc = x[c, : w * n].astype(np.float64)
+        xz = xc[0::2] + 1j * xc[1::2] if cplx else xc
+        ref = fftconvolve(xz, taps.astype(np.complex128 if ctaps else np.float64))[:n]
+        got = y[c].astype(np.float64)
+        gz = got[0::2] + 1j * got[1::2] if wo == 2 else got
+        err = np.sqrt(np.sum(np.abs(gz - ref) ** 2) / max(np.sum(np.abs(ref) ** 2), 1e-30))
+        assert err <= 1e-5, (seed, n_taps, cplx, ctaps, nch, n, c, err)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_rs_random_shapes_bit_exact(api, L, orc, seed):
+    """Exact mode against the oracle (itself bit-exact with the compiled reference): random
+    upsample / taps / rate (integer-valued and not) / chunkings, real and complex."""
+    rng = np.random.default_rng(2000 + seed)
+    U = int(rng.integers(1, 6))
+    n_taps = int(rng.integers(U, 200))
+    B = int(rng.choice([128, 1000, 1001, 4096]))
+    if (n_taps + U - 1) // U > B:
+        n_taps = U * (B // 2)
+    taps = rng.standard_normal(n_taps).astype(np.float32)
+    S = int(rng.integers(max(1, U), 4 * U + 2))
+    rate = float(np.float32(S) / np.float32(U)) if seed % 2 == 0 else float(np.float32(rng.uniform(1.0, 5.0)))
+    cplx = bool(rng.integers(0, 2))
+    w = 2 if cplx else 1
+    n = int(rng.choice([500, 4096, 9999, 30000]))
+    x = synth.synth_f32(w * n, ch=100 + seed)
+    r = api.Rs(taps, U, B, mode=L.RS_RESAMPLE, data_complex=cplx)
+    r.set_exact(True)
+    chunk = None if seed % 3 else int(rng.integers(1, 40)) * B       # bulk calls of whole blksize multiples
+    y = r.resample_array(x, rate, chunk=chunk)[0]
+    for part in range(w):
+        ref, _ = orc.Resample(taps, U, B).stream(x[part::w], rate)
+        got = y[part::w]
+        assert len(ref) - len(got) in (0, 1), (seed, U, n_taps, B, rate, len(ref), len(got))
+        assert np.array_equal(got, ref[: len(got)]), (seed, U, n_taps, B, rate, cplx, chunk)
