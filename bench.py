@@ -204,7 +204,8 @@ def main():
         obj = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE if wl == "resample" else lib.RS_DECIMATE,
                      data_complex=True, n_channels=nch, device=local_rank)
         n_out_box = [0]
-        kernel = "poly_tiled_kernel"
+        # the library picks the transform-domain kernel for long filters on cf32 streams (api.hip: get_fft_plan)
+        kernel = "poly_fft256_kernel" if wl == "resample" and os.environ.get("SFE_RS_FFT", "") != "0" else "poly_tiled_kernel"
         src = x
         if args.input == "u8":
             obj.set_input_format(lib.FMT_U8)

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 KEYS = {"fir": ("fir256_cf32_2p28", "fir_fft4096", 16 * 2 ** 28),
         "decimate": ("decimate8_cf32_2p30", "poly_tiled", 9 * 2 ** 30),
-        "resample": ("resample5o3_cf32_2p28", "poly_tiled", None)}
+        "resample": ("resample5o3_cf32_2p28", "poly_fft256", None)}
 os.makedirs(os.path.join(ROOT, "profiles", tag), exist_ok=True)
 for wl, (key, ksub, alg) in KEYS.items():
     d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{wl}")

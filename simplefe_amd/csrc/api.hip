@@ -92,6 +92,50 @@ static long long floordiv_ll(long long a, long long b)
     return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q;
 }
 
+// Folds (U, step, pos0) into UP zero-padded tap rows of equal length Lp (a multiple of `quantum`):
+// output UP*m + r = sum_q G[r][q] x[SP*m + e_max - Lp + 1 + q].
+struct FoldedRows {
+    int SP = 0, UP = 0, Lp = 0, e_max = 0;
+    std::vector<float> G;
+};
+static FoldedRows fold_rows(const std::vector<float> &taps_pm, int U, int plen, int step, long long pos0,
+                            int quantum_in_SP)
+{
+    FoldedRows f;
+    const int g = std::gcd(step, U);
+    f.SP = step / g;
+    f.UP = U / g;
+    // drop trailing all-zero taps (decimate's odd-izing zero, resample's last-phase padding)
+    int plen_eff = plen;
+    while (plen_eff > 1) {
+        bool any = false;
+        for (int ph = 0; ph < U; ph++) any = any || taps_pm[(size_t)ph * plen + plen_eff - 1] != 0.0f;
+        if (any) break;
+        plen_eff--;
+    }
+    std::vector<long long> o(f.UP);
+    std::vector<int> ph(f.UP);
+    long long e_max = -(1LL << 60), e_min = (1LL << 60);
+    for (int r = 0; r < f.UP; r++) {
+        const long long A = pos0 + (long long)r * step;
+        o[r] = floordiv_ll(A, U);
+        ph[r] = (int)(A - o[r] * U);
+        e_max = o[r] > e_max ? o[r] : e_max;
+        e_min = o[r] < e_min ? o[r] : e_min;
+    }
+    const int L = plen_eff + (int)(e_max - e_min);
+    const int quantum = quantum_in_SP * f.SP;
+    f.Lp = ((L + quantum - 1) / quantum) * quantum;
+    f.e_max = (int)e_max;
+    f.G.assign((size_t)f.UP * f.Lp, 0.0f);
+    for (int r = 0; r < f.UP; r++)
+        for (int q = 0; q < f.Lp; q++) {
+            const long long j = o[r] - e_max + f.Lp - 1 - q;     // tap index met at local time q
+            if (j >= 0 && j < plen_eff) f.G[(size_t)r * f.Lp + q] = taps_pm[(size_t)ph[r] * plen + j];
+        }
+    return f;
+}
+
 // returns nullptr when the shape has no tiled kernel (caller uses the generic one)
 static const PolyTiledPlan *get_tiled_plan(PlanCache &cache, const std::vector<float> &taps_pm, int U, int plen,
                                            int step, long long pos0, int *rc)
@@ -101,44 +145,95 @@ static const PolyTiledPlan *get_tiled_plan(PlanCache &cache, const std::vector<f
     auto it = cache.plans.find(key);
     if (it != cache.plans.end()) return it->second.d_G ? &it->second : nullptr;
     PolyTiledPlan pl;
-    const int g = std::gcd(step, U);
-    pl.SP = step / g;
-    pl.UP = U / g;
-    // drop trailing all-zero taps (decimate's odd-izing zero, resample's last-phase padding)
-    int plen_eff = plen;
-    while (plen_eff > 1) {
-        bool any = false;
-        for (int ph = 0; ph < U; ph++) any = any || taps_pm[(size_t)ph * plen + plen_eff - 1] != 0.0f;
-        if (any) break;
-        plen_eff--;
-    }
-    std::vector<long long> o(pl.UP);
-    std::vector<int> ph(pl.UP);
-    long long e_max = -(1LL << 60), e_min = (1LL << 60);
-    for (int r = 0; r < pl.UP; r++) {
-        const long long A = pos0 + (long long)r * step;
-        o[r] = floordiv_ll(A, U);
-        ph[r] = (int)(A - o[r] * U);
-        e_max = o[r] > e_max ? o[r] : e_max;
-        e_min = o[r] < e_min ? o[r] : e_min;
-    }
-    const int L = plen_eff + (int)(e_max - e_min);
-    pl.Lp = ((L + 2 * pl.SP - 1) / (2 * pl.SP)) * (2 * pl.SP);   // whole pairs of SP-sample chunks
-    pl.e_max = (int)e_max;
+    const FoldedRows f = fold_rows(taps_pm, U, plen, step, pos0, 2);   // whole pairs of SP-sample chunks
+    pl.SP = f.SP;
+    pl.UP = f.UP;
+    pl.Lp = f.Lp;
+    pl.e_max = f.e_max;
     if (!poly_tiled_supported(pl.SP, pl.UP, pl.Lp)) {
         cache.plans[key] = pl;          // d_G == nullptr marks "unsupported"
         return nullptr;
     }
-    std::vector<float> G((size_t)pl.UP * pl.Lp, 0.0f);
-    for (int r = 0; r < pl.UP; r++)
-        for (int q = 0; q < pl.Lp; q++) {
-            const long long j = o[r] - e_max + pl.Lp - 1 - q;     // tap index met at local time q
-            if (j >= 0 && j < plen_eff) G[(size_t)r * pl.Lp + q] = taps_pm[(size_t)ph[r] * plen + j];
-        }
-    hipError_t e = hipMalloc(&pl.d_G, G.size() * sizeof(float));
-    if (e == hipSuccess) e = hipMemcpy(pl.d_G, G.data(), G.size() * sizeof(float), hipMemcpyHostToDevice);
+    hipError_t e = hipMalloc(&pl.d_G, f.G.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(pl.d_G, f.G.data(), f.G.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         *rc = hip_fail(e, "tiled plan upload");
+        return nullptr;
+    }
+    auto ins = cache.plans.emplace(key, pl);
+    return &ins.first->second;
+}
+
+// ---- transform-domain plans (common.h: PolyFftPlan) -----------------------------------
+struct FftPlanCache {
+    std::map<std::pair<int, long long>, PolyFftPlan> plans;
+    void clear()
+    {
+        for (auto &kv : plans) {
+            if (kv.second.d_H) (void)hipFree(kv.second.d_H);
+            if (kv.second.d_tw) (void)hipFree(kv.second.d_tw);
+        }
+        plans.clear();
+    }
+};
+
+// nullptr when the shape is not worth (or not instantiated for) the transform-domain kernel
+static const PolyFftPlan *get_fft_plan(FftPlanCache &cache, const std::vector<float> &taps_pm, int U, int plen,
+                                       int step, long long pos0, int *rc)
+{
+    *rc = SFE_OK;
+    auto key = std::make_pair(step, pos0);
+    auto it = cache.plans.find(key);
+    if (it != cache.plans.end()) return it->second.d_H ? &it->second : nullptr;
+    PolyFftPlan pl;
+    const FoldedRows f = fold_rows(taps_pm, U, plen, step, pos0, 1);
+    pl.SP = f.SP;
+    pl.UP = f.UP;
+    pl.R = poly_fft_segments(f.SP, f.UP);
+    pl.Li = f.Lp / f.SP;
+    pl.e_max = f.e_max;
+    // worth it when the direct form spends more multiply-adds per input sample than the transforms
+    // do (~100 flop per sample at 256 points), and the overlap does not eat the block
+    const double direct_flops = 2.0 * 2.0 * f.Lp * f.UP / f.SP;    // cf32 x real taps, per input sample
+    const char *env = getenv("SFE_RS_FFT");
+    const bool forced = env && env[0] == '1';
+    if (!pl.R || pl.Li > 96 || (env && env[0] == '0') || (!forced && direct_flops < 200.0)) {
+        cache.plans[key] = pl;
+        return nullptr;
+    }
+    const int M = 256, SP = f.SP, UP = f.UP;
+    std::vector<float> H((size_t)UP * SP * M * 2);
+    const double w0 = -2.0 * M_PI / M;
+    for (int r = 0; r < UP; r++)
+        for (int cp = 0; cp < SP; cp++) {
+            const int c = SP - 1 - cp;
+            for (int b = 0; b < M; b++) {
+                double re = 0.0, im = 0.0;
+                for (int i = 0; i < pl.Li; i++) {
+                    const double h = f.G[(size_t)r * f.Lp + (f.Lp - 1 - SP * i - c)];
+                    const double ang = w0 * (double)((b * i) % M);
+                    re += h * cos(ang);
+                    im += h * sin(ang);
+                }
+                H[((size_t)(r * SP + cp) * M + b) * 2 + 0] = (float)(re / M);
+                H[((size_t)(r * SP + cp) * M + b) * 2 + 1] = (float)(im / M);
+            }
+        }
+    std::vector<float> tw(6 * 16 * 2);
+    for (int k = 1; k < 4; k++)
+        for (int l = 0; l < 16; l++) {
+            const double a1 = w0 * (l * k), a4 = w0 * (4 * l * k);
+            tw[((k - 1) * 16 + l) * 2 + 0] = (float)cos(a1);
+            tw[((k - 1) * 16 + l) * 2 + 1] = (float)sin(a1);
+            tw[((k + 2) * 16 + l) * 2 + 0] = (float)cos(a4);
+            tw[((k + 2) * 16 + l) * 2 + 1] = (float)sin(a4);
+        }
+    hipError_t e = hipMalloc(&pl.d_H, H.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&pl.d_tw, tw.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(pl.d_H, H.data(), H.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(pl.d_tw, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        *rc = hip_fail(e, "transform-domain plan upload");
         return nullptr;
     }
     auto ins = cache.plans.emplace(key, pl);
@@ -417,6 +512,7 @@ struct Rs {
     std::vector<float> h_taps_pm;          // host copy of the same (tiled plans)
     PlanCache plans;
     MfmaCache mfma_plans;
+    FftPlanCache fft_plans;
     void *d_hist[2] = {nullptr, nullptr};
     int cur = 0;
     sfe_rs_timestate ts = {0, 0.0f, 0};
@@ -453,6 +549,7 @@ static void rs_free(Rs *r)
     if (r->d_taps) (void)hipFree(r->d_taps);
     r->plans.clear();
     r->mfma_plans.clear();
+    r->fft_plans.clear();
     for (int i = 0; i < 2; i++)
         if (r->d_hist[i]) (void)hipFree(r->d_hist[i]);
     if (r->d_in) (void)hipFree(r->d_in);
@@ -1044,9 +1141,32 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
                 if (rc != SFE_OK) return rc;
             }
         }
-        const PolyTiledPlan *pl = mp ? nullptr : get_tiled_plan(r->plans, r->h_taps_pm, r->U, r->plen, (int)S, pos0, &rc);
+        // transform-domain form (fused numerics, cf32): long filters on streams long enough to fill the chip
+        const PolyFftPlan *fp = nullptr;
+        if (!mp && !r->exact_stream && r->data_complex && K >= 4096) {
+            fp = get_fft_plan(r->fft_plans, r->h_taps_pm, r->U, r->plen, (int)S, pos0, &rc);
+            if (rc != SFE_OK) return rc;
+        }
+        const PolyTiledPlan *pl = (mp || fp) ? nullptr : get_tiled_plan(r->plans, r->h_taps_pm, r->U, r->plen, (int)S, pos0, &rc);
         if (rc != SFE_OK) return rc;
-        if (mp) {
+        if (fp) {
+            PolyFftArgs fa;
+            memset(&fa, 0, sizeof(fa));
+            fa.in = d_in;
+            fa.out = d_out;
+            fa.hist = r->d_hist[r->cur];
+            fa.H = fp->d_H;
+            fa.tw = fp->d_tw;
+            fa.n_in = (long long)n_in;
+            fa.in_stride = (long long)in_stride;
+            fa.out_stride = (long long)out_stride;
+            fa.n_out = K;
+            fa.hl = r->hl;
+            fa.e_max = fp->e_max;
+            fa.ovl = fp->Li - 1;
+            fa.V = 256 - fa.ovl;
+            rc = launch_poly_fft(*fp, fa, r->in_u8, r->n_channels, s);
+        } else if (mp) {
             PolyMfmaArgs ma;
             memset(&ma, 0, sizeof(ma));
             ma.in = d_in;

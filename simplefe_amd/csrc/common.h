@@ -127,6 +127,29 @@ struct PolyMfmaArgs {
 };
 int launch_poly_mfma(const PolyMfmaArgs &a, int n_channels, hipStream_t s);   // cf32 data only
 bool poly_mfma_fits(int GS, int RG, int Kp);
+// Transform-domain form of the integer-step law (cf32 data, fused numerics): the UP output phases
+// are UP filters on the SP input polyphase components, all at the low (1/SP) rate, so a block of
+// 256 low-rate points costs SP forward and UP inverse 256-point FFTs plus UP*SP multiplies per
+// bin -- ~100 flop per input sample for the 5/3, 381-tap headline shape instead of ~300 for the
+// direct dot products, which takes that shape from VALU-bound to HBM-bound (poly_fft.hip).
+struct PolyFftPlan {
+    int    SP = 0, UP = 0, R = 0, Li = 0, e_max = 0;
+    float *d_H = nullptr;        // [UP][SP][256] complex: spectra of the sub-filters, / 256
+    float *d_tw = nullptr;       // [6][16] complex: W_256^(l k), k=1..3 and W_256^(4 l k), k=1..3
+};
+struct PolyFftArgs {
+    const void *in;
+    void       *out;
+    const void *hist;
+    const float *H, *tw;
+    long long   n_in, in_stride, out_stride, n_out;
+    long long   n_pass;          // set by the launcher: passes of R segments
+    int         hl, e_max, ovl, V;
+};
+// returns SFE_ESTATE when (SP, UP) has no instantiation
+int launch_poly_fft(const PolyFftPlan &plan, const PolyFftArgs &a, int in_u8, int n_channels, hipStream_t s);
+// segments per pass for (SP, UP), 0 when the shape has no instantiation
+int poly_fft_segments(int SP, int UP);
 int launch_poly_sched(const PolyArgs &a, int data_complex, int exact, int n_channels,
                       hipStream_t s);
 

@@ -24,6 +24,15 @@ __device__ __forceinline__ v2f cmul(v2f a, v2f w)
         : "=v"(r), "=&v"(t) : "v"(a), "v"(w));
     return r;
 }
+// acc + a * w
+__device__ __forceinline__ v2f cmac(v2f acc, v2f a, v2f w)
+{
+    v2f t, r;
+    asm("v_pk_fma_f32 %1, %3, %4, %2 op_sel_hi:[1,0,1]\n\t"                                 // t = (ax wx, ay wx) + acc
+        "v_pk_fma_f32 %0, %3, %4, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"        // (-ay wy, ax wy) + t
+        : "=v"(r), "=&v"(t) : "v"(acc), "v"(a), "v"(w));
+    return r;
+}
 // a * conj(w)
 __device__ __forceinline__ v2f cmul_conj(v2f a, v2f w)
 {
@@ -132,6 +141,7 @@ __device__ __forceinline__ v2f scale_pj(v2f a, v2f s)     // s * (-ay, ax)
 #else
 __host__ __device__ __forceinline__ v2f cmul(v2f a, v2f w) { return (v2f){a.x * w.x - a.y * w.y, a.y * w.x + a.x * w.y}; }
 __host__ __device__ __forceinline__ v2f cmul_conj(v2f a, v2f w) { return (v2f){a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y}; }
+__host__ __device__ __forceinline__ v2f cmac(v2f acc, v2f a, v2f w) { return (v2f){acc.x + a.x * w.x - a.y * w.y, acc.y + a.y * w.x + a.x * w.y}; }
 __host__ __device__ __forceinline__ v2f add_mj(v2f a, v2f b) { return (v2f){a.x + b.y, a.y - b.x}; }
 __host__ __device__ __forceinline__ v2f add_pj(v2f a, v2f b) { return (v2f){a.x - b.y, a.y + b.x}; }
 __host__ __device__ __forceinline__ v2f rot_mj(v2f a) { return (v2f){a.y, -a.x}; }

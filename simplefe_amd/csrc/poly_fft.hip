@@ -1,0 +1,271 @@
+// poly_fft.hip -- rational resampling / decimation by an integer step, in the transform domain.
+//
+// The law (libdsp/resample.cxx:119-150, integer-valued step, mu == 0) in the tiled form of
+// polyphase.hip: output UP*m + r = sum_d g_r[d] x[SP*m + e_max - d], d < Lp.  Split d = SP*i + c:
+//     y_r[m] = sum_c (h_rc * u_c)[m],   u_c[m] = x[SP*m + e_max - c],   h_rc[i] = g_r[SP*i + c]
+// -- UP*SP short filters (Li = Lp/SP taps) running at the LOW rate.  Overlap-save with 256-point
+// transforms: per segment of V = 257 - Li low-rate points, SP forward FFTs (one per input polyphase
+// component), a UP x SP matrix multiply per bin, UP inverse FFTs.  For the 5/3, 381-tap shape that
+// is ~100 flop per input sample against ~300 for the direct dot products: the kernel is bound by
+// the sample stream, not by the vector ALU.
+//
+// Mapping.  A 256-point FFT is 16 x 16: sixteen lanes with 16 complex registers each and ONE
+// exchange through LDS that stays inside the wave (no workgroup barrier).  A workgroup is 16 such
+// lane groups and processes a PASS of R segments: R*SP groups run forward transforms of this
+// pass's segments while R*UP groups run the inverse transforms of the previous pass's segments
+// (software pipeline), all executing the same forward-FFT instruction stream -- the inverse is
+// the forward transform read out at index (256 - n) mod 256, so it costs no arithmetic.  Between
+// the two, thread b of the workgroup owns bin b: it holds the UP*SP spectra H_rc[b]/256 in
+// registers for the life of the (persistent) workgroup and turns the R*SP forward results into
+// R*UP inverse inputs.
+//   S0  all threads: coalesced loads of the pass's R*SP*256 input samples, scattered into the
+//       forward groups' LDS areas by polyphase component (the transpose happens on the LDS write)
+//   S1  every group: 16 reads of its area, DFT16, twiddle, exchange, DFT16
+//   S2  forward groups: spectrum -> own area;   inverse groups: store y_r[m] (interleaved by r)
+//   S3  bin owners: Y_r = sum_c H_rc X_c for the pass's segments -> inverse groups' areas
+// Three workgroup barriers per pass; 34 KiB LDS, <= 128 VGPRs -> 4 workgroups per CU.
+#include <stdlib.h>
+
+#include "common.h"
+#include "fft16.h"
+
+namespace sfe {
+namespace {
+
+constexpr int PF_M = 256;
+constexpr int PF_AREA = 272;      // cells per lane group: 16 rows of 17 (exchange), 256 used otherwise
+
+// staged-sample swizzle: sample k of component c sits in its group's area at cell k ^ pf_swz(c).
+// ds_write_b64 is banked per 16 lanes over 32 banks and area bases are multiples of 32 banks, so
+// without it the scatter of S0 (16 consecutive lanes = 5 components x 3-4 consecutive k) lands
+// 3-4 deep on the same banks.  Only the low four bits move, i.e. a sample stays in its row of 16:
+// the group's row reads (ds_read_b64, 32 lanes = two groups, 64 banks) stay conflict-free.
+__host__ __device__ constexpr unsigned pf_swz(unsigned c) { return c < 4 ? 4u * c : 2u + 4u * (c - 4); }
+
+template <int SP, int UP, int R, bool IN_U8>
+__global__ __launch_bounds__(256, 4) void poly_fft256_kernel(PolyFftArgs a)
+{
+    constexpr int F = R * SP, I = R * UP;
+    static_assert(F + I <= 16, "one lane group per transform");
+    __shared__ v2f lds[16 * PF_AREA + 96];     // 16 group areas + the six twiddle bases per lane
+    const unsigned t = threadIdx.x, l = t & 15u, g = t >> 4;
+    const int ch = blockIdx.y;
+    const bool is_fwd = g < (unsigned)F, is_inv = !is_fwd && g < (unsigned)(F + I);
+    const unsigned seg = is_fwd ? g / SP : (g - F) / UP;     // segment of the pass this group works on
+    const unsigned comp = is_fwd ? g % SP : (g - F) % UP;    // input component c' / output phase r
+    unsigned cell0 = g * PF_AREA + l;                        // this lane's column of its group's area
+    unsigned cell_in = g * PF_AREA + (l ^ (is_fwd ? pf_swz(comp) : 0u));
+
+    constexpr int ISZ = IN_U8 ? 2 : 8;                       // bytes per input sample
+    const char *in_c = static_cast<const char *>(a.in) + (size_t)ch * a.in_stride * ISZ;
+    v2f *out_c = static_cast<v2f *>(a.out) + (size_t)ch * a.out_stride;
+    const v2f *hist_c = static_cast<const v2f *>(a.hist) + (size_t)ch * a.hl;
+
+    const v2f *tw = reinterpret_cast<const v2f *>(a.tw);
+    // the six twiddle bases per lane W_256^(l k), W_256^(4 l k) sit in LDS and are re-read every
+    // pass (6 ds_read_b64): 12 VGPRs the prefetched samples need more (measured +4 % over
+    // registers, which spill at <= 128 VGPRs)
+    if (t < 96) lds[16 * PF_AREA + t] = tw[t];
+    v2f G[UP][SP];     // this thread's bin of every sub-filter spectrum
+#pragma unroll
+    for (int r = 0; r < UP; r++)
+#pragma unroll
+        for (int c = 0; c < SP; c++) {
+            G[r][c] = reinterpret_cast<const v2f *>(a.H)[(r * SP + c) * PF_M + t];
+            asm volatile("" : "+v"(G[r][c]));
+        }
+
+    auto load_in = [&](const char *p, unsigned lane) -> v2f {
+        if constexpr (IN_U8) {   // wire format: (b - 128) / 127 on load (gr-simplefe/lib/source_c_impl.cc:121-132)
+            const unsigned w = __builtin_nontemporal_load(reinterpret_cast<const unsigned short *>(p) + lane);
+            return (v2f){u8_to_f32(w & 0xFFu), u8_to_f32(w >> 8)};
+        } else {
+            return __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p) + lane);
+        }
+    };
+    // the R*SP*256 staged samples of a pass, thread t: sample t + 256 i of each segment
+    auto load_pass = [&](v2f (&s)[R * SP], long long pass) {
+#pragma unroll
+        for (int sg = 0; sg < R; sg++) {
+            // stream index of the segment's staged sample 0 (uniform)
+            const long long start = ((pass * R + sg) * a.V - a.ovl) * SP + a.e_max - (SP - 1);
+            if (start >= 0 && start + (long long)PF_M * SP <= a.n_in) {
+                const char *p = in_c + start * ISZ;
+#pragma unroll
+                for (int i = 0; i < SP; i++) s[sg * SP + i] = load_in(p, t + 256u * i);
+            } else {
+#pragma unroll
+                for (int i = 0; i < SP; i++) {
+                    const long long idx = start + (long long)(t + 256u * i);
+                    v2f x = (v2f){0.0f, 0.0f};
+                    if (idx >= 0) {
+                        if (idx < a.n_in) x = load_in(in_c + idx * ISZ, 0u);
+                    } else if (idx + a.hl >= 0) {
+                        x = hist_c[idx + a.hl];
+                    }
+                    s[sg * SP + i] = x;
+                }
+            }
+        }
+    };
+
+    long long prev = -1;       // pass whose inverse transforms run in this iteration
+    v2f s[R * SP];
+    // passes are dealt round-robin (blockIdx.x, + gridDim.x, ...): at any moment the resident
+    // workgroups read one compact window of the stream.  Giving each workgroup a contiguous run of
+    // passes instead (so the overlap re-read hits L2) measured 8 % SLOWER: a thousand separate
+    // read/write streams cost HBM more than the 5 % of re-read bytes they save.
+    if ((long long)blockIdx.x < a.n_pass) load_pass(s, blockIdx.x);
+    for (long long pass = blockIdx.x;; pass += gridDim.x) {
+        const bool cur = pass < a.n_pass;
+        if (!cur && prev < 0) break;
+        // ---- S0: stage this pass's input (requested during the last iteration's S3), transposed by component
+        if (cur) {
+            unsigned tt = t;
+            asm volatile("" : "+v"(tt));      // recompute the scatter cells here instead of keeping R*SP of them live
+#pragma unroll
+            for (int sg = 0; sg < R; sg++)
+#pragma unroll
+                for (int i = 0; i < SP; i++) {
+                    const unsigned j = tt + 256u * i, c = j % SP, k = j / SP;
+                    lds[(sg * SP + c) * PF_AREA + (k ^ pf_swz(c))] = s[sg * SP + i];
+                }
+        }
+        lds_barrier();
+        // ---- S1: the transform (forward groups: staged samples; inverse groups: Y of the last pass)
+        v2f v[16];
+        asm volatile("" : "+v"(cell_in), "+v"(cell0));
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = lds[cell_in + 16u * r];
+        dft16<-1>(v);
+        v2f p2[4], q2[4];
+        {
+            unsigned tl = 16 * PF_AREA + l;
+            asm volatile("" : "+v"(tl));
+#pragma unroll
+            for (int k = 1; k < 4; k++) {
+                p2[k] = lds[tl + (k - 1) * 16];
+                q2[k] = lds[tl + (k + 2) * 16];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            v2f x = v[P16(k)];
+            if ((k >> 2) && (k & 3)) x = cmul2(x, q2[k >> 2], p2[k & 3]);
+            else if (k >> 2) x = cmul(x, q2[k >> 2]);
+            else if (k & 3) x = cmul(x, p2[k & 3]);
+            lds[cell0 + 17u * k] = x;
+        }
+        // the exchange stays inside this wave: program order + the compiler's waitcnt suffice
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = lds[cell0 + 16u * l + r];
+        dft16<-1>(v);                       // bin l + 16 k0 is in v[P16(k0)]
+        // ---- S2
+        if (is_fwd) {
+#pragma unroll
+            for (int k0 = 0; k0 < 16; k0++) lds[cell0 + 16u * k0] = v[P16(k0)];
+        } else if (is_inv && prev >= 0) {
+            // forward transform of Y, read backwards: y[n] = FFT(Y)[(256 - n) mod 256]
+            // output index of this group's n = 0: uniform part + per-thread part (32-bit)
+            const long long ku = ((prev * R) * a.V - a.ovl) * UP;
+            const int koff = (int)(seg * (unsigned)a.V * UP + comp);
+            // outputs of this group exist for ovl <= n and ku + koff + UP n < n_out
+            const long long remu = a.n_out - ku;
+            const int rem = (remu > (1 << 30) ? (1 << 30) : (int)remu) - koff;
+            const long long ko0 = ku + koff;
+            const int lim = rem > 256 * UP ? 256 * UP : rem;           // UP n < lim; n < 256
+            int nu = (256 - (int)l) * UP;                              // UP n for k0 = 0 (n = 256 - l; lane 0: n = 256 is bin 0 = sample 0, below)
+            asm volatile("" : "+v"(nu));                               // keep the 16 offsets immediates off this, not 16 registers
+            const int ovu = a.ovl * UP;
+            // ovu <= x < lim as ONE unsigned compare per store: (x - ovu) < (lim - ovu)
+            const unsigned span = lim > ovu ? (unsigned)(lim - ovu) : 0u;
+            const unsigned xb = (unsigned)(nu - ovu);
+            char *op = reinterpret_cast<char *>(out_c + ko0) + (long long)nu * 8;
+#pragma unroll
+            for (int k0 = 0; k0 < 16; k0++)
+                if (xb - (unsigned)(16 * UP * k0) < span) *reinterpret_cast<v2f *>(op - 16 * UP * 8 * k0) = v[P16(k0)];
+            if (l == 0 && a.ovl == 0 && lim > 0) out_c[ko0] = v[P16(0)];
+        }
+        lds_barrier();
+        // request the next pass's samples now: v[] is dead, they land while S3 and the barrier run
+        // (requesting them a whole pass ahead instead measured the same: latency is not what binds)
+        if (pass + gridDim.x < a.n_pass) load_pass(s, pass + gridDim.x);
+        // ---- S3: bin t of every segment of this pass
+        if (cur) {
+#pragma unroll
+            for (int sg = 0; sg < R; sg++) {
+                v2f acc[UP];
+#pragma unroll
+                for (int c = 0; c < SP; c++) {
+                    const v2f x = lds[(sg * SP + c) * PF_AREA + t];
+#pragma unroll
+                    for (int r = 0; r < UP; r++) acc[r] = c ? cmac(acc[r], x, G[r][c]) : cmul(x, G[r][c]);
+                }
+#pragma unroll
+                for (int r = 0; r < UP; r++) lds[(F + sg * UP + r) * PF_AREA + t] = acc[r];
+            }
+        }
+        lds_barrier();
+        prev = cur ? pass : -1;
+    }
+}
+
+template <int SP, int UP, int R, bool IN_U8>
+int launch_one(const PolyFftArgs &a, int n_channels, hipStream_t s)
+{
+    static int resident = 0;
+    if (!resident) {
+        int dev = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, poly_fft256_kernel<SP, UP, R, IN_U8>, 256, 0) != hipSuccess || per_cu < 1)
+            return hip_fail(hipGetLastError(), "poly_fft occupancy");
+        resident = cus * per_cu;
+    }
+    // persistent workgroups, two per resident slot (1, 2, 3, 4, 8 measured within noise of each other)
+    const long long cap = 2LL * resident;
+    dim3 grid((unsigned)(a.n_pass < cap ? a.n_pass : cap), (unsigned)n_channels);
+    hipLaunchKernelGGL((poly_fft256_kernel<SP, UP, R, IN_U8>), grid, dim3(256), 0, s, a);
+    hipError_t err = hipGetLastError();
+    return err == hipSuccess ? SFE_OK : hip_fail(err, "poly_fft launch");
+}
+
+}  // namespace
+
+int poly_fft_segments(int SP, int UP)
+{
+    if (SP == 5 && UP == 3) return 2;
+    if (SP == 3 && UP == 2) return 3;
+    if (SP == 5 && UP == 2) return 2;
+    if (SP == 4 && UP == 3) return 2;
+    if (SP == 2 && UP == 1) return 5;
+    if (SP == 3 && UP == 1) return 4;
+    if (SP == 4 && UP == 1) return 3;
+    if (SP == 5 && UP == 1) return 2;
+    return 0;
+}
+
+int launch_poly_fft(const PolyFftPlan &plan, const PolyFftArgs &a0, int in_u8, int n_channels, hipStream_t s)
+{
+    PolyFftArgs a = a0;
+    const int R = poly_fft_segments(plan.SP, plan.UP);
+    if (!R || a.n_out <= 0) return SFE_ESTATE;
+    const long long m_count = (a.n_out + plan.UP - 1) / plan.UP;
+    const long long n_seg = (m_count + a.V - 1) / a.V;
+    a.n_pass = (n_seg + R - 1) / R;
+#define SFE_PF(sp, up, r)                                                                         \
+    if (plan.SP == sp && plan.UP == up)                                                           \
+        return in_u8 ? launch_one<sp, up, r, true>(a, n_channels, s) : launch_one<sp, up, r, false>(a, n_channels, s)
+    SFE_PF(5, 3, 2);
+    SFE_PF(3, 2, 3);
+    SFE_PF(5, 2, 2);
+    SFE_PF(4, 3, 2);
+    SFE_PF(2, 1, 5);
+    SFE_PF(3, 1, 4);
+    SFE_PF(4, 1, 3);
+    SFE_PF(5, 1, 2);
+#undef SFE_PF
+    return SFE_ESTATE;
+}
+
+}  // namespace sfe

@@ -325,6 +325,53 @@ def test_rs_bulk_mfma_path_cf32(api, L, orc, g5, monkeypatch, name, force, chunk
             assert synth.rel_rms(got, ref[: len(got)]) <= TOL, (c, part)
 
 
+# ------------------------------------------------- transform-domain polyphase path (poly_fft.hip)
+@pytest.mark.parametrize("U,S,n_taps,n,nch,chunk", [
+    (3, 5, 381, 100000, 1, None), (3, 5, 381, 250001, 2, 65536), (2, 3, 200, 90000, 1, None),
+    (2, 5, 301, 90000, 3, 40000), (3, 4, 255, 120000, 1, None), (1, 2, 128, 80000, 1, 30000),
+    (1, 3, 200, 80000, 1, None), (1, 4, 256, 80000, 2, None), (1, 5, 333, 80000, 1, 20001),
+    (3, 5, 30, 60000, 1, None), (3, 5, 1000, 200000, 1, 70000), (6, 10, 762, 100000, 1, None),
+    (3, 5, 381, 8000, 1, None), (3, 5, 1420, 50000, 1, None)])
+def test_rs_bulk_fft_path_cf32(api, L, orc, monkeypatch, U, S, n_taps, n, nch, chunk):
+    """Every instantiated (SP, UP) of the 256-point transform-domain kernel, forced on
+    (SFE_RS_FFT=1), against the oracle with I and Q as two real passes: ragged ends, chunked calls
+    (carried history and pos0), channel strides, a filter too short to need it, one whose overlap
+    (Li = 96 low-rate taps) is the longest it accepts, and a stream of few segments."""
+    monkeypatch.setenv("SFE_RS_FFT", "1")
+    rng = np.random.default_rng(U * 100 + S)
+    taps = (rng.standard_normal(n_taps) / np.sqrt(n_taps)).astype(np.float32)
+    x = np.stack([synth.synth_cf32(n, ch=10 + c) for c in range(nch)])
+    r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=True, n_channels=nch)
+    y = r.resample_array(x, float(np.float32(S) / np.float32(U)), chunk=chunk)
+    for c in range(nch):
+        for part in (0, 1):
+            ref, _ = orc.Resample(taps, U, 4096).stream(x[c, part::2], float(np.float32(S) / np.float32(U)))
+            got = y[c, part::2]
+            assert 0 <= len(ref) - len(got) <= 1
+            assert synth.rel_rms(got, ref[: len(got)]) <= TOL, (c, part)
+
+
+def test_rs_fft_path_is_the_default_for_long_filters(api, L, g5, monkeypatch):
+    """cfg3 (5/3, 381 taps) takes the transform-domain kernel by default and the direct kernel
+    with SFE_RS_FFT=0 or in exact mode; the two agree to float32 rounding and the exact one is
+    bit-identical with the oracle's law (checked elsewhere), so the default is within tolerance."""
+    taps, U, rate = g5["cfg3_taps"], 3, float(g5["cfg3_rate"])
+    x = synth.synth_cf32(300000, ch=3)[None, :]
+    ys = []
+    for env, exact in (("", False), ("0", False), ("", True)):
+        if env:
+            monkeypatch.setenv("SFE_RS_FFT", env)
+        else:
+            monkeypatch.delenv("SFE_RS_FFT", raising=False)
+        r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=True)
+        r.set_exact(exact)
+        ys.append(r.resample_array(x, rate)[0])
+        r.close()
+    assert ys[0].shape == ys[1].shape == ys[2].shape
+    assert not np.array_equal(ys[0], ys[1])            # different kernels, different rounding
+    assert synth.rel_rms(ys[0], ys[2]) <= TOL and synth.rel_rms(ys[1], ys[2]) <= TOL
+
+
 # ------------------------------------------------ fused receive converter (u8 wire format, N2)
 def _u8_stream(n_bytes, seed):
     return np.random.default_rng(seed).integers(0, 256, size=n_bytes, dtype=np.uint8)
@@ -364,17 +411,19 @@ def test_fir_u8_input_fused(api, L, orc):
 @pytest.mark.parametrize("chunk", [None, 4099, 1001])
 def test_rs_u8_input_fused(api, L, orc, g5, name, cplx, chunk):
     """decimate/8 and resample 5/3 reading u8 samples directly: bit-identical to the float path
-    fed the converted samples (fused numerics), any call chunking (odd chunks exercise the
-    8-byte alignment fix-up), and within tolerance of converter -> oracle."""
+    fed the converted samples in the same calls (fused numerics; long calls of the 5/3 shape take
+    the transform-domain kernel, short ones the direct kernel -- odd chunks exercise its 8-byte
+    alignment fix-up), and within tolerance of converter -> oracle."""
     taps, U, rate = g5[f"{name}_taps"], int(g5[f"{name}_U"]), float(g5[f"{name}_rate"])
     n = 30000
     w = 2 if cplx else 1
     b = _u8_stream(w * n, 2)
     xf = orc.rx_u8_to_f32(b)
-    ref_gpu = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=cplx).resample_array(xf, rate)[0]
+    chunk = chunk or n
+    # same chunking for the float path: which kernel serves a call depends on its length
+    ref_gpu = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=cplx).resample_array(xf, rate, chunk=chunk)[0]
     r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=cplx)
     r.set_input_format(L.FMT_U8)
-    chunk = chunk or n
     outs = []
     for off in range(0, n, chunk):
         m = min(chunk, n - off)
