@@ -35,8 +35,8 @@ HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)   # ~0.2 s of GPU time; a 20-step run sits on the DVFS transient
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="fir", choices=["fir", "resample", "decimate"])
     ap.add_argument("--log2n", type=int, default=None, help="samples per GPU = 2^log2n (default per workload)")
     ap.add_argument("--algo", default="auto", choices=["auto", "fft", "direct"])

@@ -8,7 +8,7 @@ cd /tmp; export TMPDIR=/tmp
 for WL in fir decimate resample; do
   O=$R/gpurun_out/prof_${TAG}_${WL}
   mkdir -p $O
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --workload $WL --steps 20 --warmup 3 --no-cpu > $O/kt.log 2>&1 || exit 1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --workload $WL --no-cpu > $O/kt.log 2>&1 || exit 1
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu > $O/fetch.log 2>&1 || exit 1
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu > $O/write.log 2>&1 || exit 1
   tail -1 $O/kt.log | cut -c1-160
