@@ -119,13 +119,15 @@ int sfe_dsp_fir_set_algo(sfe_fir_t h, int algo);
 #define SFE_FMT_F32 0
 #define SFE_FMT_U8  1
 int sfe_dsp_fir_set_input_format(sfe_fir_t h, int fmt);
-/* Fused transmit converter: with SFE_FMT_TX10 the bulk call on a REAL stream writes the device's
- * transmit wire format instead of floats -- ((short)(x*511)+512)&0x3FF, 4 samples packed in 5
- * bytes exactly as fill_tx_buffer / convert_samples_to_bytes do on the host
- * (gr-simplefe/lib/sink_f_impl.cc:117-143, examples/bpsk/bpsk.cxx:76-101): d_out receives
- * (n/4)*5 bytes per channel (whole groups of 4 samples, as the reference emits), channel c at
- * byte offset c*(out_stride/4)*5.  The pulse-shaping chain of examples/bpsk then leaves the GPU
- * at 1.25 instead of 4 bytes per sample. */
+/* Fused transmit converter: with SFE_FMT_TX10 the bulk call writes the device's transmit wire
+ * format instead of floats -- ((short)(x*511)+512)&0x3FF, 4 floats packed in 5 bytes exactly as
+ * fill_tx_buffer / convert_samples_to_bytes do on the host (gr-simplefe/lib/sink_f_impl.cc:117-143,
+ * sink_c_impl.cc:118-144, examples/bpsk/bpsk.cxx:76-101).  Real stream (real taps): 4 samples per
+ * group, d_out receives (n/4)*5 bytes per channel, channel c at byte offset c*(out_stride/4)*5.
+ * Complex stream: a group is 2 samples (re, im, re, im), d_out receives (n/2)*5 bytes per
+ * channel, channel c at byte offset c*(out_stride/2)*5.  Only whole groups are emitted, as the
+ * reference does.  The stream leaves the GPU at 1.25 (real) / 2.5 (complex) instead of 4 / 8
+ * bytes per sample. */
 #define SFE_FMT_TX10 2
 int sfe_dsp_fir_set_output_format(sfe_fir_t h, int fmt);
 /* Zero the carried state (a fresh blkconv object: blkconv.cxx:52-55). */

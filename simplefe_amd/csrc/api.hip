@@ -893,8 +893,8 @@ int sfe_dsp_fir_set_output_format(sfe_fir_t h, int fmt)
 {
     Fir *f = as_fir(h);
     if (!f || (fmt != SFE_FMT_F32 && fmt != SFE_FMT_TX10)) return SFE_EINVAL;
-    if (fmt == SFE_FMT_TX10 && (!f->fft_ok || f->taps_complex || f->data_complex)) {
-        set_error("fir_set_output_format: 10-bit output needs a real stream, real taps and the FFT kernel");
+    if (fmt == SFE_FMT_TX10 && (!f->fft_ok || f->data_complex != f->out_complex)) {
+        set_error("fir_set_output_format: 10-bit output needs the FFT kernel and a real->real or complex->complex stream");
         return SFE_ESTATE;
     }
     f->out_tx10 = fmt == SFE_FMT_TX10;

@@ -54,8 +54,8 @@ __device__ __forceinline__ v2f load_sample(const void *p, unsigned lane)
 // PAIR (real data, real taps only): the real and imaginary parts of one transform carry two
 // CONSECUTIVE real segments of the stream (z = x_A + j x_B; real taps keep them apart), so a real
 // stream costs what a complex one does per sample instead of twice as much.
-// OUT_TX10 (with PAIR): the real output is written in the device's transmit wire format, 10-bit
-// offset binary, 4 samples in 5 bytes -- ((short)(x*511)+512)&0x3FF, packed as
+// OUT_TX10 (real streams with PAIR, or complex in and out): the output is written in the device's
+// transmit wire format, 10-bit offset binary, 4 floats (4 real or 2 complex samples) in 5 bytes -- ((short)(x*511)+512)&0x3FF, packed as
 // gr-simplefe/lib/sink_f_impl.cc:117-143 / examples/bpsk/bpsk.cxx:76-101 do on the host.
 template <bool IN_C, bool OUT_C, int WAVES, bool PREFETCH, bool SWZ, bool HREG = false, bool IN_U8 = false, bool PAIR = false,
           bool OUT_TX10 = false>
@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 
     constexpr int ISZ = IN_U8 ? (IN_C ? 2 : 1) : (IN_C ? 8 : 4);   // bytes per input sample
     const char *in_c = static_cast<const char *>(a.in) + (size_t)ch * a.in_stride * ISZ;
-    char *out_c = static_cast<char *>(a.out) + (OUT_TX10 ? (size_t)ch * (a.out_stride / 4) * 5 : (size_t)ch * a.out_stride * (OUT_C ? 8 : 4));
+    // 10-bit output: the channel's floats (2 per complex sample) in whole groups of 4 -> 5 bytes
+    char *out_c = static_cast<char *>(a.out) + (OUT_TX10 ? (size_t)ch * (a.out_stride * (OUT_C ? 2 : 1) / 4) * 5 : (size_t)ch * a.out_stride * (OUT_C ? 8 : 4));
     const char *hist_c = static_cast<const char *>(a.hist) + (size_t)ch * a.hl * (IN_C ? 8 : 4);
 
     // Per-thread twiddle bases, resident for the whole launch.  A twiddle with exponent
@@ -289,6 +290,25 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const long long orow = obase + 256 * r;          // uniform
+            if constexpr (OUT_TX10 && OUT_C) {
+                // complex stream (gr-simplefe/lib/sink_c_impl.cc:118-144): lanes 2g, 2g+1 hold two
+                // consecutive samples = the four floats of one 5-byte group; lane 2g writes it
+                if (r < row0) continue;
+                const v2f y = v[P16(r)];
+                const int lane = (int)(t & 63u);
+                const unsigned u0 = (unsigned)((int)(short)(int)(y.x * 511.0f) + 512) & 0x3FFu;
+                const unsigned u1 = (unsigned)((int)(short)(int)(y.y * 511.0f) + 512) & 0x3FFu;
+                const unsigned u2 = __shfl(u0, lane | 1), u3 = __shfl(u1, lane | 1);
+                if ((t & 1u) == 0 && orow + (long long)t + 1 < a.n) {
+                    unsigned char *d = reinterpret_cast<unsigned char *>(out_c) + ((orow + (long long)t) >> 1) * 5;
+                    d[0] = (unsigned char)((u0 >> 8) | ((u1 >> 8) << 2) | ((u2 >> 8) << 4) | ((u3 >> 8) << 6));
+                    d[1] = (unsigned char)u0;
+                    d[2] = (unsigned char)u1;
+                    d[3] = (unsigned char)u2;
+                    d[4] = (unsigned char)u3;
+                }
+                continue;
+            }
             if (r >= row0 && (whole || orow + (long long)t < a.n)) {
                 const v2f y = v[P16(r)];
                 char *rp = out_c + orow * OSZ;               // uniform row pointer
@@ -411,9 +431,18 @@ int launch_fir_fft(const FirFftArgs &a, int in_complex, int out_complex, int in_
     case 7: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, true, false>), grid, block, 0, s, a); break; \
     default: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 4, false, false, true>), grid, block, 0, s, a); break; \
     }
-    if (out_tx10 && (in_complex || out_complex)) {
-        set_error("fir_fft: 10-bit output is built for real streams (the bpsk transmit chain)");
+    if (out_tx10 && in_complex != out_complex) {
+        set_error("fir_fft: 10-bit output is built for real->real and complex->complex streams");
         return SFE_EINVAL;
+    }
+    if (out_tx10 && in_u8) {
+        set_error("fir_fft: u8 input together with 10-bit output is not built");
+        return SFE_EINVAL;
+    }
+    if (out_tx10 && in_complex) {
+        hipLaunchKernelGGL((fir_fft4096_kernel<true, true, 4, false, false, true, false, false, true>), grid, block, 0, s, a);
+        SFE_HIP(hipGetLastError());
+        return SFE_OK;
     }
     if (!in_complex && !out_complex && !copy_only && (out_tx10 || !(ev && ev[0] >= '2' && ev[0] <= '4'))) {
         // real stream, real taps: two segments per transform (PAIR); a.nblk counts transforms
@@ -422,10 +451,6 @@ int launch_fir_fft(const FirFftArgs &a, int in_complex, int out_complex, int in_
         long long g2 = b.nblk < gx ? b.nblk : gx;
         dim3 grid2((unsigned)(g2 < 1 ? 1 : g2), (unsigned)n_channels);
         if (out_tx10) {
-            if (in_u8) {
-                set_error("fir_fft: u8 input together with 10-bit output is not built");
-                return SFE_EINVAL;
-            }
             hipLaunchKernelGGL((fir_fft4096_kernel<false, false, 4, false, false, true, false, true, true>), grid2, block, 0, s, b);
         } else if (in_u8) hipLaunchKernelGGL((fir_fft4096_kernel<false, false, 4, false, false, true, true, true>), grid2, block, 0, s, b);
         else hipLaunchKernelGGL((fir_fft4096_kernel<false, false, 4, false, false, true, false, true>), grid2, block, 0, s, b);

@@ -539,5 +539,33 @@ def test_fir_tx10_output_fused(api, L, orc):
     va = np.stack([((b5a[:, 0] >> (2 * k)) & 3) << 8 | b5a[:, 1 + k] for k in range(4)], 1)
     vb = np.stack([((b5b[:, 0] >> (2 * k)) & 3) << 8 | b5b[:, 1 + k] for k in range(4)], 1)
     assert np.abs(va - vb).max() <= 1 and np.count_nonzero(va != vb) <= 0.002 * va.size
-    with pytest.raises(api.SfeError):                 # complex streams: not built
-        api.Fir(taps, data_complex=True).set_output_format(L.FMT_TX10)
+    with pytest.raises(api.SfeError):                 # real data through complex taps: not built
+        api.Fir(taps.astype(np.complex64), data_complex=False).set_output_format(L.FMT_TX10)
+
+
+@pytest.mark.parametrize("ctaps", [False, True])
+def test_fir_tx10_output_fused_complex(api, L, orc, ctaps):
+    """Complex stream with the transmit converter fused into the store
+    (gr-simplefe/lib/sink_c_impl.cc:118-144: re, im, re, im -> 5 bytes): equals
+    oracle.tx_f32_to_10bit over the interleaved float output of the same kernel, bit for bit;
+    an odd trailing sample forms no group; two channels at their byte strides."""
+    taps = synth.lowpass_taps(111, 0.2)
+    if ctaps:
+        taps = (taps * np.exp(1j * 0.3 * np.arange(len(taps)))).astype(np.complex64)
+    n, nch = 30001, 2
+    x = np.stack([(0.5 * synth.synth_cf32(n, ch=c)).astype(np.float32) for c in range(nch)])
+    yf = api.Fir(taps, data_complex=True, n_channels=nch, algo=L.FIR_ALGO_FFT).filter(x)
+    f = api.Fir(taps, data_complex=True, n_channels=nch, algo=L.FIR_ALGO_FFT)
+    f.set_output_format(L.FMT_TX10)
+    d_in = api.DeviceArray.from_numpy(x)
+    stride = n + 1                                      # even: channel c at byte offset c*(stride/2)*5
+    d_out = api.DeviceArray(nch * (stride // 2) * 5 // 4 + 8)
+    d_out.zero()
+    f.process_stream(d_in, d_out, n, in_stride=n, out_stride=stride)
+    raw = d_out.to_numpy().view(np.uint8)
+    for c in range(nch):
+        want = orc.tx_f32_to_10bit(yf[c][: (n // 2) * 4])
+        got = raw[c * (stride // 2) * 5: c * (stride // 2) * 5 + (n // 2) * 5]
+        assert len(want) == (n // 2) * 5 and np.array_equal(got, want), c
+    # the half group after the last whole one stays untouched
+    assert not raw[(nch - 1) * (stride // 2) * 5 + (n // 2) * 5:][:5].any()
