@@ -41,12 +41,14 @@ constexpr int PF_AREA = 272;      // cells per lane group: 16 rows of 17 (exchan
 // 3-4 deep on the same banks.  Only the low four bits move, i.e. a sample stays in its row of 16:
 // the group's row reads (ds_read_b64, 32 lanes = two groups, 64 banks) stay conflict-free.
 __host__ __device__ constexpr unsigned pf_swz(unsigned c) { return c < 4 ? 4u * c : 2u + 4u * (c - 4); }
+static_assert(pf_swz(7) < 16, "the swizzle must stay inside a row of 16");
 
 template <int SP, int UP, int R, bool IN_U8>
 __global__ __launch_bounds__(256, 4) void poly_fft256_kernel(PolyFftArgs a)
 {
     constexpr int F = R * SP, I = R * UP;
     static_assert(F + I <= 16, "one lane group per transform");
+    static_assert(SP <= 8, "pf_swz covers components 0..7");
     __shared__ v2f lds[16 * PF_AREA + 96];     // 16 group areas + the six twiddle bases per lane
     const unsigned t = threadIdx.x, l = t & 15u, g = t >> 4;
     const int ch = blockIdx.y;
@@ -222,8 +224,10 @@ int launch_one(const PolyFftArgs &a, int n_channels, hipStream_t s)
             return hip_fail(hipGetLastError(), "poly_fft occupancy");
         resident = cus * per_cu;
     }
-    // persistent workgroups, two per resident slot (1, 2, 3, 4, 8 measured within noise of each other)
-    const long long cap = 2LL * resident;
+    // persistent workgroups, two per resident slot (1, 2, 3, 4, 8 measured within noise of each
+    // other), shared over the channels
+    long long cap = (2LL * resident + n_channels - 1) / n_channels;
+    if (cap < 1) cap = 1;
     dim3 grid((unsigned)(a.n_pass < cap ? a.n_pass : cap), (unsigned)n_channels);
     hipLaunchKernelGGL((poly_fft256_kernel<SP, UP, R, IN_U8>), grid, dim3(256), 0, s, a);
     hipError_t err = hipGetLastError();
@@ -232,16 +236,16 @@ int launch_one(const PolyFftArgs &a, int n_channels, hipStream_t s)
 
 }  // namespace
 
+// instantiated shapes: (SP, UP, R) with R*(SP + UP) <= 16 lane groups
+#define SFE_PF_SHAPES(X) \
+    X(5, 3, 2) X(3, 2, 3) X(5, 2, 2) X(4, 3, 2) X(2, 1, 5) X(3, 1, 4) X(4, 1, 3) X(5, 1, 2) \
+    X(6, 1, 2) X(7, 1, 2) X(8, 1, 1) X(7, 2, 1) X(5, 4, 1)
+
 int poly_fft_segments(int SP, int UP)
 {
-    if (SP == 5 && UP == 3) return 2;
-    if (SP == 3 && UP == 2) return 3;
-    if (SP == 5 && UP == 2) return 2;
-    if (SP == 4 && UP == 3) return 2;
-    if (SP == 2 && UP == 1) return 5;
-    if (SP == 3 && UP == 1) return 4;
-    if (SP == 4 && UP == 1) return 3;
-    if (SP == 5 && UP == 1) return 2;
+#define SFE_PF(sp, up, r) if (SP == sp && UP == up) return r;
+    SFE_PF_SHAPES(SFE_PF)
+#undef SFE_PF
     return 0;
 }
 
@@ -255,15 +259,8 @@ int launch_poly_fft(const PolyFftPlan &plan, const PolyFftArgs &a0, int in_u8, i
     a.n_pass = (n_seg + R - 1) / R;
 #define SFE_PF(sp, up, r)                                                                         \
     if (plan.SP == sp && plan.UP == up)                                                           \
-        return in_u8 ? launch_one<sp, up, r, true>(a, n_channels, s) : launch_one<sp, up, r, false>(a, n_channels, s)
-    SFE_PF(5, 3, 2);
-    SFE_PF(3, 2, 3);
-    SFE_PF(5, 2, 2);
-    SFE_PF(4, 3, 2);
-    SFE_PF(2, 1, 5);
-    SFE_PF(3, 1, 4);
-    SFE_PF(4, 1, 3);
-    SFE_PF(5, 1, 2);
+        return in_u8 ? launch_one<sp, up, r, true>(a, n_channels, s) : launch_one<sp, up, r, false>(a, n_channels, s);
+    SFE_PF_SHAPES(SFE_PF)
 #undef SFE_PF
     return SFE_ESTATE;
 }
