@@ -54,14 +54,14 @@ def main():
         os.environ["SFE_RS_FFT"] = "1" if fft else "0"
         r = api.Rs(taps, 3, 4096, mode=lib.RS_RESAMPLE, data_complex=True)
         ts = []
-        for it in range(12):
+        for it in range(60):
             r.reset()
             tm = api.Timer()
             tm.start()
             k = r.process_stream(d_in, n, d_out, cap, 5.0 / 3.0)
             tm.stop()
             ts.append(tm.elapsed_ms())
-        print(f"fft={fft}: k={k} ms {['%.3f' % t for t in ts]}", flush=True)
+        print(f"fft={fft}: k={k} ms first {ts[0]:.3f} mean[10:] {sum(ts[10:]) / len(ts[10:]):.4f} min {min(ts):.3f}", flush=True)
         r.close()
     return bad
 

@@ -52,11 +52,30 @@ __global__ __launch_bounds__(256, 4) void poly_fft256_kernel(PolyFftArgs a)
     __shared__ v2f lds[16 * PF_AREA + 96];     // 16 group areas + the six twiddle bases per lane
     const unsigned t = threadIdx.x, l = t & 15u, g = t >> 4;
     const int ch = blockIdx.y;
-    const bool is_fwd = g < (unsigned)F, is_inv = !is_fwd && g < (unsigned)(F + I);
-    const unsigned seg = is_fwd ? g / SP : (g - F) / UP;     // segment of the pass this group works on
-    const unsigned comp = is_fwd ? g % SP : (g - F) % UP;    // input component c' / output phase r
-    unsigned cell0 = g * PF_AREA + l;                        // this lane's column of its group's area
-    unsigned cell_in = g * PF_AREA + (l ^ (is_fwd ? pf_swz(comp) : 0u));
+    // Which transform a lane group runs.  Areas are indexed by JOB (forward job f = seg*SP + c' ->
+    // area f, inverse job v = seg*UP + r -> area F + v).  With UP > 1 the UP inverse jobs of a
+    // segment sit in ONE wave (the top UP groups of wave 3 - seg), so that a store instruction of
+    // that wave covers out[UP*m + r] for all r: contiguous 128-byte lines instead of every UP-th
+    // 8 bytes; forward jobs fill the remaining groups in order.
+    bool is_fwd, is_inv;
+    unsigned job;
+    if constexpr (UP > 1) {
+        static_assert(R <= 4 && UP <= 4, "one wave hosts one segment's inverse transforms");
+        const unsigned w = g >> 2, pos = g & 3u, sw = 3u - w;
+        is_inv = sw < (unsigned)R && pos >= (unsigned)(4 - UP);
+        const unsigned f = g - UP * (w > (unsigned)(4 - R) ? w - (4 - R) : 0u);
+        is_fwd = !is_inv && f < (unsigned)F;
+        job = is_inv ? sw * UP + (pos - (4 - UP)) : f;
+    } else {
+        is_fwd = g < (unsigned)F;
+        is_inv = !is_fwd && g < (unsigned)(F + I);
+        job = is_fwd ? g : g - F;
+    }
+    const unsigned seg = is_fwd ? job / SP : job / UP;       // segment of the pass this group works on
+    const unsigned comp = is_fwd ? job % SP : job % UP;      // input component c' / output phase r
+    const unsigned area = is_fwd ? job : (is_inv ? F + job : 15u);   // idle groups: a harmless area of their own
+    unsigned cell0 = area * PF_AREA + l;                     // this lane's column of its job's area
+    unsigned cell_in = area * PF_AREA + (l ^ (is_fwd ? pf_swz(comp) : 0u));
 
     constexpr int ISZ = IN_U8 ? 2 : 8;                       // bytes per input sample
     const char *in_c = static_cast<const char *>(a.in) + (size_t)ch * a.in_stride * ISZ;
@@ -186,8 +205,8 @@ __global__ __launch_bounds__(256, 4) void poly_fft256_kernel(PolyFftArgs a)
             char *op = reinterpret_cast<char *>(out_c + ko0) + (long long)nu * 8;
 #pragma unroll
             for (int k0 = 0; k0 < 16; k0++)
-                if (xb - (unsigned)(16 * UP * k0) < span) *reinterpret_cast<v2f *>(op - 16 * UP * 8 * k0) = v[P16(k0)];
-            if (l == 0 && a.ovl == 0 && lim > 0) out_c[ko0] = v[P16(0)];
+                if (xb - (unsigned)(16 * UP * k0) < span) __builtin_nontemporal_store(v[P16(k0)], reinterpret_cast<v2f *>(op - 16 * UP * 8 * k0));
+            if (l == 0 && a.ovl == 0 && lim > 0) __builtin_nontemporal_store(v[P16(0)], out_c + ko0);
         }
         lds_barrier();
         // request the next pass's samples now: v[] is dead, they land while S3 and the barrier run
