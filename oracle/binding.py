@@ -9,6 +9,8 @@ Two libraries:
   _ref/libsferef.so  -- the unmodified reference resample/decimate classes compiled from
                         /root/reference in the authoring container (RefResample,
                         RefDecimate); present on the GPU box only as the prebuilt .so
+  _ref/libsferef_blkconv.so -- the unmodified reference blkconv class on ROCm's libhipfftw
+                        (RefBlkconv); runs on a GPU box only
 """
 import ctypes as C
 import os
@@ -82,6 +84,34 @@ def ref_lib():
     return _ref
 
 
+_ref_blk = None
+
+
+def ref_blkconv_lib():
+    """The compiled reference blkconv class (oracle/_ref/libsferef_blkconv.so: blkconv.cxx on
+    ROCm's libhipfftw), or None when it is absent.  Creating an object needs a GPU."""
+    global _ref_blk
+    if _ref_blk is None:
+        p = os.path.join(HERE, "_ref", "libsferef_blkconv.so")
+        if not os.path.exists(p) and os.path.isdir("/root/reference"):
+            build(ref=True)
+        try:
+            R = _load(p)
+        except OSError:
+            R = None
+        if R is None:
+            return None
+        R.ref_blkconv_create.restype = C.c_void_p
+        R.ref_blkconv_create.argtypes = [_f32p, C.c_int, C.c_int]
+        R.ref_blkconv_blksize.argtypes = [C.c_void_p]
+        R.ref_blkconv_buf.restype = C.POINTER(C.c_float)
+        R.ref_blkconv_buf.argtypes = [C.c_void_p]
+        R.ref_blkconv_process.argtypes = [C.c_void_p]
+        R.ref_blkconv_destroy.argtypes = [C.c_void_p]
+        _ref_blk = R
+    return _ref_blk
+
+
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
@@ -109,6 +139,41 @@ class Blkconv:
     def __del__(self):
         if getattr(self, "_h", None):
             self._L.orc_blkconv_destroy(self._h)
+            self._h = None
+
+
+class RefBlkconv:
+    """The reference's own blkconv class (libdsp/blkconv.cxx:34-122), compiled unmodified."""
+
+    def __init__(self, taps, fft_len):
+        taps = _f32(taps)
+        self._L = ref_blkconv_lib()
+        if self._L is None:
+            raise RuntimeError("oracle/_ref/libsferef_blkconv.so not built")
+        self._h = self._L.ref_blkconv_create(taps, len(taps), int(fft_len))
+        self.blk = self._L.ref_blkconv_blksize(self._h)
+        p = self._L.ref_blkconv_buf(self._h)
+        self.buf = np.ctypeslib.as_array(p, shape=(fft_len + 2,))
+
+    def process(self):
+        self._L.ref_blkconv_process(self._h)
+
+    def stream(self, x):
+        """Feed x block by block the way the reference's callers do (write [0, blk), process(),
+        read [0, blk)); a ragged tail is zero-padded and the padding's outputs dropped."""
+        x = _f32(x)
+        y = np.empty_like(x)
+        for off in range(0, len(x), self.blk):
+            m = min(self.blk, len(x) - off)
+            self.buf[:m] = x[off:off + m]
+            self.buf[m:self.blk] = 0.0
+            self.process()
+            y[off:off + m] = self.buf[:m]
+        return y
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.ref_blkconv_destroy(self._h)
             self._h = None
 
 

@@ -6,8 +6,8 @@
 // the C restatement (sfe_oracle.c), to generate tests/golden/*.npz, and as the
 // "reference" CPU baseline in bench.py.
 //
-// blkconv.cxx is NOT built: it needs libfftw3f (FFTW 3.3.5), which this image lacks
-// and the reference ships only as Win64 DLLs; no stand-in is written for it.
+// blkconv.cxx is built separately (ref_wrap_blkconv.cxx): it needs an FFTW3-API library, and
+// the one this image has (ROCm's libhipfftw) runs on a GPU box only.
 #include "decimate.h"   // -I/root/reference/libdsp
 #include "resample.h"
 

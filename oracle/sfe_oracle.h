@@ -11,11 +11,13 @@
  *   - orc_resample_* / orc_decimate_* : pinned BIT-EXACT against the unmodified
  *     reference sources compiled in place into oracle/_ref/ (tests/golden fixtures).
  *   - orc_blkconv_* : the reference's FFT arithmetic lives in FFTW 3.3.5 (libfftw3f),
- *     which is not in this image and not vendored as source, so blkconv.cxx is
- *     unbuildable here.  The restatement is pinned by the reference's own
- *     known-answer scenario (libdsp/test/test_blkconv.cxx:5-33, which prints but
- *     asserts nothing) and by float64 direct linear convolution; at the FFTW
- *     rounding boundary itself parity is UNPINNED.
+ *     which is not in this image and not vendored as source.  The reference class itself,
+ *     blkconv.cxx unmodified, IS built -- against the reference's vendored fftw3.h and ROCm's
+ *     libhipfftw.so (the FFTW3 API on hipFFT; runs on a GPU box only) -- and its outputs are
+ *     the fixture tests/golden/g6_blkconv_reference.npz: the restatement matches them to
+ *     float32 FFT rounding (rel-RMS 3e-7).  Also pinned by the reference's known-answer
+ *     scenario (libdsp/test/test_blkconv.cxx:5-33) and float64 direct linear convolution.
+ *     Unpinned: only FFTW's own rounding versus hipFFT's (no FFTW binary exists here).
  */
 #ifndef SFE_ORACLE_H_
 #define SFE_ORACLE_H_

@@ -31,6 +31,12 @@ def g5():
 
 
 @pytest.fixture(scope="session")
+def g6():
+    """Outputs of the reference's own blkconv class (tests/golden/make_golden_blkconv.py)."""
+    return np.load(os.path.join(GOLDEN, "g6_blkconv_reference.npz"))
+
+
+@pytest.fixture(scope="session")
 def orc():
     from oracle import binding
     binding.lib()

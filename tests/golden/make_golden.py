@@ -3,8 +3,9 @@
 
   resample / decimate : outputs of the unmodified /root/reference/libdsp/{resample,decimate}.cxx
       compiled in place by oracle/Makefile into oracle/_ref/libsferef.so (-O2 -ffp-contract=off).
-  blkconv             : blkconv.cxx is unbuildable here (needs libfftw3f; no stand-ins are
-      written), so its fixtures are (a) the known-answer scenario of
+  blkconv             : the reference class itself needs a GPU box to run (it is built on ROCm's
+      libhipfftw): those fixtures are g6_*.npz, made by make_golden_blkconv.py.  The ones made
+      here are (a) the known-answer scenario of
       libdsp/test/test_blkconv.cxx:5-33 -- 5-tap boxcar, fft 32, a block of ones then a block
       of zeros -- with the values that program prints (to %.2f), and (b) float64 direct linear
       convolution, the mathematical definition blkconv.cxx:77-110 implements.

@@ -183,6 +183,30 @@ def _drive(obj, x, B, out_len, rate):
     return np.concatenate(ys), ns
 
 
+@pytest.mark.parametrize("name", ["kat", "bpsk", "cfg1", "cfg2"])
+def test_blkconv_class_vs_reference_class(api, orc, g6, name):
+    """The drop-in blkconv class against the reference's own (blkconv.cxx on libhipfftw): the
+    committed outputs (g6), and the compiled reference run live here beside it when the prebuilt
+    oracle/_ref/libsferef_blkconv.so travelled with the snapshot.  Same calls as the
+    reference's callers: write [0, blk) of get_process_buf(), process(), read it back."""
+    taps, fft_len, x, want = g6[f"{name}_taps"], int(g6[f"{name}_fft_len"]), g6[f"{name}_x"], g6[f"{name}_y"]
+    c = api.blkconv(taps, fft_len)
+    blk = c.get_blksize()
+    buf = c.get_process_buf()
+    assert blk == fft_len + 1 - len(taps)
+    got = np.empty_like(x)
+    for off in range(0, len(x), blk):
+        buf[:blk] = x[off: off + blk]
+        c.process()
+        got[off: off + blk] = buf[:blk]
+    assert synth.rel_rms(got, want) <= TOL
+    assert synth.rel_rms(got, want) < 1e-6            # what is actually observed: ~3e-7
+    if orc.ref_blkconv_lib() is not None:
+        live = orc.RefBlkconv(taps, fft_len).stream(x)
+        assert synth.rel_rms(live, want) < 1e-6       # hipFFT plans may differ between boxes: rounding only
+        assert synth.rel_rms(got, live) < 1e-6
+
+
 @pytest.mark.parametrize("cls", ["resample", "decimate"])
 @pytest.mark.parametrize("tag", RATES + ("0p77",))
 def test_rs_class_reference_vector_bit_exact(api, g4, cls, tag):

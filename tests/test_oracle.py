@@ -105,6 +105,23 @@ def test_blkconv_known_answer(orc, g1):
     assert np.allclose(c.buf[: c.blk], g1["out2"], atol=float(g1["print_tol"]))
 
 
+@pytest.mark.parametrize("name", ["kat", "bpsk", "cfg1", "cfg2"])
+def test_blkconv_restatement_vs_reference_class(orc, g6, name):
+    """The restatement against outputs of the reference's own blkconv class (blkconv.cxx compiled
+    unmodified on ROCm's libhipfftw, run on a GPU box: tests/golden/make_golden_blkconv.py), fed
+    block by block as its callers do.  The two use different float32 FFTs: equal to rounding."""
+    taps, fft_len, x, want = g6[f"{name}_taps"], int(g6[f"{name}_fft_len"]), g6[f"{name}_x"], g6[f"{name}_y"]
+    c = orc.Blkconv(taps, fft_len)
+    assert c.blk == fft_len + 1 - len(taps) and len(x) % c.blk == 0
+    got = np.empty_like(x)
+    for off in range(0, len(x), c.blk):
+        c.buf[: c.blk] = x[off: off + c.blk]
+        c.process()
+        got[off: off + c.blk] = c.buf[: c.blk]
+    assert synth.rel_rms(got, want) < 1e-6
+    assert np.abs(got - want).max() < 2e-6 * max(1.0, float(np.abs(want).max()))
+
+
 def test_blkconv_pulse_shaping_vs_float64(orc, g1):
     """bpsk.cxx:122-164 shape (111 taps, fft 2048) against float64 direct convolution."""
     c = orc.Blkconv(g1["g2_taps"], int(g1["g2_fft_len"]))
