@@ -36,6 +36,21 @@ def test_reference_test_blkconv_program_unmodified(g1):
     assert [v.lstrip("-") for v in vals] == want       # "-0.00" and "0.00" print alike in effect
 
 
+def test_reference_test_program_prints_the_same_either_way():
+    """test_blkconv.cxx linked the reference's way (its own blkconv.cxx + ROCm's libhipfftw for
+    the FFTW calls) and linked to the drop-in: the two programs print the same lines."""
+    a = os.path.join(ROOT, "oracle/_ref/test_blkconv_reference")
+    b = os.path.join(ROOT, "oracle/_ref/test_blkconv_dropin")
+    if not (os.path.exists(a) and os.path.exists(b)):
+        pytest.skip("oracle/_ref test programs not prebuilt")
+    ra = subprocess.run([a], capture_output=True, text=True, timeout=120)
+    rb = subprocess.run([b], capture_output=True, text=True, timeout=120)
+    assert ra.returncode == 0 and rb.returncode == 0, (ra.stderr, rb.stderr)
+    la = [l.strip().replace("-0.00", "0.00") for l in ra.stdout.split("\n") if l.strip()]
+    lb = [l.strip().replace("-0.00", "0.00") for l in rb.stdout.split("\n") if l.strip()]
+    assert len(la) == 57 and la == lb
+
+
 def test_cxx_blkconv_class(dropin_exe, g1):
     r = subprocess.run([dropin_exe, "blkconv"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
