@@ -139,6 +139,21 @@ def test_ring_buffer_reference_scenarios(tmp_path):
     assert r.returncode == 0 and "ringbuf ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_ring_buffer_scenarios_hold_on_the_reference_header_too(tmp_path):
+    """The same scenario program compiled against the reference's own libdsp/ringbuf.h (in
+    place): both classes pass, i.e. they behave alike wherever the reference asserts anything.
+    Authoring container only (the reference tree does not travel)."""
+    ref = "/root/reference/libdsp"
+    if not os.path.exists(os.path.join(ref, "ringbuf.h")):
+        pytest.skip("reference tree not present")
+    exe = str(tmp_path / "rb_ref")
+    r = _cxx(["g++", "-O1", "-w", "-fsanitize=address,undefined", "-DSFE_REF_RINGBUF", "-I" + ref,
+              os.path.join(ROOT, "tests/host/test_ringbuf.cpp"), "-o", exe])
+    assert r.returncode == 0, r.stderr
+    r = _cxx([exe])
+    assert r.returncode == 0 and "ringbuf ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_register_dft16_host_check(tmp_path):
     exe = str(tmp_path / "fft16")
     r = _cxx(["/opt/rocm/bin/hipcc", "-O2", "-x", "hip", "--offload-arch=gfx950",
