@@ -89,3 +89,36 @@ def test_rs_random_shapes_bit_exact(api, L, orc, seed):
         got = y[part::w]
         assert len(ref) - len(got) in (0, 1), (seed, U, n_taps, B, rate, len(ref), len(got))
         assert np.array_equal(got, ref[: len(got)]), (seed, U, n_taps, B, rate, cplx, chunk)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_rs_fft_path_random_shapes(api, L, monkeypatch, seed):
+    """Transform-domain kernel forced on, random instantiated (U, step) pairs, tap counts up to
+    the longest overlap it accepts (beyond that the call silently takes the direct kernel), stream
+    lengths around segment/pass boundaries, random chunkings and channel counts -- against the
+    exact-mode kernels (bit-exact with the compiled reference, tested elsewhere)."""
+    monkeypatch.setenv("SFE_RS_FFT", "1")
+    rng = np.random.default_rng(3000 + seed)
+    U, S = [(3, 5), (2, 3), (2, 5), (3, 4), (1, 2), (1, 3), (1, 4), (1, 5), (1, 6), (1, 7), (1, 8), (2, 7), (4, 5),
+            (6, 10), (2, 4), (3, 9)][seed]
+    g = int(np.gcd(U, S))
+    SP = S // g
+    n_taps = int(rng.integers(U, 96 * SP * U + 40))
+    taps = (rng.standard_normal(n_taps) / np.sqrt(n_taps)).astype(np.float32)
+    nch = int(rng.integers(1, 4))
+    n = int(rng.choice([7000 * SP, 231 * SP * 64 + 1, 100003, 180000]))
+    x = np.stack([synth.synth_cf32(n, ch=50 + seed * 4 + c) for c in range(nch)])
+    rate = float(np.float32(S) / np.float32(U))
+    cuts = sorted(set([0, n] + [int(v) for v in rng.integers(1, n, size=int(rng.integers(0, 3)))]))
+    outs = {}
+    for exact in (False, True):
+        r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=True, n_channels=nch)
+        r.set_exact(exact)
+        parts = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            parts.append(r.resample_array(np.ascontiguousarray(x[:, 2 * a: 2 * b]), rate))
+        outs[exact] = np.concatenate(parts, axis=1)
+        r.close()
+    assert outs[False].shape == outs[True].shape, (U, S, n_taps, n, cuts)
+    for c in range(nch):
+        assert synth.rel_rms(outs[False][c], outs[True][c]) <= 1e-5, (U, S, n_taps, n, nch, cuts, c)
