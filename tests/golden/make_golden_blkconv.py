@@ -11,8 +11,8 @@ snapshot):
     cp gpurun_out/g6_blkconv_reference.npz tests/golden/
 
 Cases: the reference test program's scenario (test_blkconv.cxx:5-33: 5-tap boxcar, fft 32, a
-block of ones then a block of zeros), the bpsk pulse filter shape (111 taps, fft 2048,
-examples/bpsk/bpsk.cxx:122-124), BASELINE cfg1 (63 taps, fft 1024) and cfg2 (256 taps,
+block of ones then a block of zeros), the bpsk pulse-shaping stream of fixture G2 (111 taps, fft
+2048, +-0.63 impulses every 10 samples: examples/bpsk/bpsk.cxx:122-164), BASELINE cfg1 (63 taps, fft 1024) and cfg2 (256 taps,
 fft 4096), each fed several blocks of the synthetic stream through get_process_buf()/process().
 The fixture holds inputs and the reference's outputs (data only).
 """
@@ -43,11 +43,13 @@ def main():
     x = np.concatenate([np.ones(28, np.float32), np.zeros(28, np.float32)])
     y, blk = run_blocks(taps, 32, x)
     g.update(kat_taps=taps, kat_fft_len=32, kat_x=x, kat_y=y)
-    for name, taps, fft_len, nblk in (("bpsk", synth.lowpass_taps(111, 0.2), 2048, 6),
+    g1 = np.load(os.path.join(ROOT, "tests", "golden", "g1_blkconv.npz"))   # the bpsk-pattern stream of G2
+    for name, taps, fft_len, nblk in (("bpsk", g1["g2_taps"], int(g1["g2_fft_len"]), 8),
                                       ("cfg1", synth.taps_cfg1(), 1024, 9),
                                       ("cfg2", synth.taps_cfg2(), 4096, 5)):
         blk = fft_len + 1 - len(taps)
-        x = synth.synth_f32(nblk * blk, ch=len(taps))
+        x = g1["g2_x"] if name == "bpsk" else synth.synth_f32(nblk * blk, ch=len(taps))
+        assert len(x) == nblk * blk
         y, _ = run_blocks(taps, fft_len, x)
         g.update({f"{name}_taps": taps, f"{name}_fft_len": fft_len, f"{name}_x": x, f"{name}_y": y})
         o = orc.Blkconv(taps, fft_len).stream(x)
