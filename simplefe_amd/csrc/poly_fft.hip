@@ -18,12 +18,15 @@
 // the two, thread b of the workgroup owns bin b: it holds the UP*SP spectra H_rc[b]/256 in
 // registers for the life of the (persistent) workgroup and turns the R*SP forward results into
 // R*UP inverse inputs.
-//   S0  all threads: coalesced loads of the pass's R*SP*256 input samples, scattered into the
-//       forward groups' LDS areas by polyphase component (the transpose happens on the LDS write)
-//   S1  every group: 16 reads of its area, DFT16, twiddle, exchange, DFT16
-//   S2  forward groups: spectrum -> own area;   inverse groups: store y_r[m] (interleaved by r)
-//   S3  bin owners: Y_r = sum_c H_rc X_c for the pass's segments -> inverse groups' areas
-// Three workgroup barriers per pass; 34 KiB LDS, <= 128 VGPRs -> 4 workgroups per CU.
+//   S0  all threads: the pass's R*SP*256 input samples (loaded coalesced during the last pass's
+//       S3) are scattered into the forward jobs' LDS areas by polyphase component -- the
+//       transpose happens on the LDS write
+//   S1  every group: 16 reads of its job's area, DFT16, twiddle, exchange, DFT16
+//   S2  forward groups: spectrum -> the job's area;  inverse groups: store y_r[m] (a segment's
+//       UP phases sit in one wave, so a store instruction covers whole lines of out[UP*m + r])
+//   S3  bin owners: Y_r = sum_c H_rc X_c for the pass's segments -> the inverse jobs' areas
+// Three workgroup barriers per pass; 35.6 KiB LDS (16 job areas + the per-lane twiddle bases),
+// <= 128 VGPRs -> 4 workgroups per CU.  DESIGN.md section 4.2c has the measurements.
 #include <stdlib.h>
 
 #include "common.h"
