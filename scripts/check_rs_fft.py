@@ -63,6 +63,22 @@ def main():
             ts.append(tm.elapsed_ms())
         print(f"fft={fft}: k={k} ms first {ts[0]:.3f} mean[10:] {sum(ts[10:]) / len(ts[10:]):.4f} min {min(ts):.3f}", flush=True)
         r.close()
+    # real data: 2^29 float32 samples (the same bytes), two real segments per transform
+    nr = 1 << 29
+    capr = nr * 3 // 5 + 16
+    for fft in (False, True, False, True):
+        os.environ["SFE_RS_FFT"] = "1" if fft else "0"
+        r = api.Rs(taps, 3, 4096, mode=lib.RS_RESAMPLE, data_complex=False)
+        ts = []
+        for it in range(60):
+            r.reset()
+            tm = api.Timer()
+            tm.start()
+            k = r.process_stream(d_in, nr, d_out, capr, 5.0 / 3.0)
+            tm.stop()
+            ts.append(tm.elapsed_ms())
+        print(f"real data fft={fft}: k={k} ms first {ts[0]:.3f} mean[10:] {sum(ts[10:]) / len(ts[10:]):.4f} min {min(ts):.3f}", flush=True)
+        r.close()
     return bad
 
 

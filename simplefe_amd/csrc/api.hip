@@ -194,7 +194,7 @@ static const PolyFftPlan *get_fft_plan(FftPlanCache &cache, const std::vector<fl
     pl.e_max = f.e_max;
     // worth it when the direct form spends more multiply-adds per input sample than the transforms
     // do (~100 flop per sample at 256 points), and the overlap does not eat the block
-    const double direct_flops = 2.0 * 2.0 * f.Lp * f.UP / f.SP;    // cf32 x real taps, per input sample
+    const double direct_flops = 2.0 * 2.0 * f.Lp * f.UP / f.SP;    // per complex input sample (or per pair of real ones)
     const char *env = getenv("SFE_RS_FFT");
     const bool forced = env && env[0] == '1';
     if (!pl.R || pl.Li > 96 || (env && env[0] == '0') || (!forced && direct_flops < 200.0)) {
@@ -1143,7 +1143,7 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         }
         // transform-domain form (fused numerics, cf32): long filters on streams long enough to fill the chip
         const PolyFftPlan *fp = nullptr;
-        if (!mp && !r->exact_stream && r->data_complex && K >= 4096) {
+        if (!mp && !r->exact_stream && K >= 4096) {
             fp = get_fft_plan(r->fft_plans, r->h_taps_pm, r->U, r->plen, (int)S, pos0, &rc);
             if (rc != SFE_OK) return rc;
         }
@@ -1165,7 +1165,7 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
             fa.e_max = fp->e_max;
             fa.ovl = fp->Li - 1;
             fa.V = 256 - fa.ovl;
-            rc = launch_poly_fft(*fp, fa, r->in_u8, r->n_channels, s);
+            rc = launch_poly_fft(*fp, fa, r->data_complex, r->in_u8, r->n_channels, s);
         } else if (mp) {
             PolyMfmaArgs ma;
             memset(&ma, 0, sizeof(ma));

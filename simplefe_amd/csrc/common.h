@@ -127,7 +127,7 @@ struct PolyMfmaArgs {
 };
 int launch_poly_mfma(const PolyMfmaArgs &a, int n_channels, hipStream_t s);   // cf32 data only
 bool poly_mfma_fits(int GS, int RG, int Kp);
-// Transform-domain form of the integer-step law (cf32 data, fused numerics): the UP output phases
+// Transform-domain form of the integer-step law (cf32 or real f32 data, fused numerics): the UP output phases
 // are UP filters on the SP input polyphase components, all at the low (1/SP) rate, so a block of
 // 256 low-rate points costs SP forward and UP inverse 256-point FFTs plus UP*SP multiplies per
 // bin -- ~100 flop per input sample for the 5/3, 381-tap headline shape instead of ~300 for the
@@ -147,7 +147,7 @@ struct PolyFftArgs {
     int         hl, e_max, ovl, V;
 };
 // returns SFE_ESTATE when (SP, UP) has no instantiation
-int launch_poly_fft(const PolyFftPlan &plan, const PolyFftArgs &a, int in_u8, int n_channels, hipStream_t s);
+int launch_poly_fft(const PolyFftPlan &plan, const PolyFftArgs &a, int data_complex, int in_u8, int n_channels, hipStream_t s);
 // segments per pass for (SP, UP), 0 when the shape has no instantiation
 int poly_fft_segments(int SP, int UP);
 int launch_poly_sched(const PolyArgs &a, int data_complex, int exact, int n_channels,

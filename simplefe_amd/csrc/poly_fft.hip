@@ -46,7 +46,10 @@ constexpr int PF_AREA = 272;      // cells per lane group: 16 rows of 17 (exchan
 __host__ __device__ constexpr unsigned pf_swz(unsigned c) { return c < 4 ? 4u * c : 2u + 4u * (c - 4); }
 static_assert(pf_swz(7) < 16, "the swizzle must stay inside a row of 16");
 
-template <int SP, int UP, int R, bool IN_U8>
+// PAIR (real data): the real and imaginary parts of a transform carry two CONSECUTIVE real
+// segments of the stream (the sub-filters are real, so they stay apart): a real stream costs
+// what a complex one does per sample pair.
+template <int SP, int UP, int R, bool IN_U8, bool PAIR>
 __global__ __launch_bounds__(256, 4) void poly_fft256_kernel(PolyFftArgs a)
 {
     constexpr int F = R * SP, I = R * UP;
@@ -80,10 +83,11 @@ __global__ __launch_bounds__(256, 4) void poly_fft256_kernel(PolyFftArgs a)
     unsigned cell0 = area * PF_AREA + l;                     // this lane's column of its job's area
     unsigned cell_in = area * PF_AREA + (l ^ (is_fwd ? pf_swz(comp) : 0u));
 
-    constexpr int ISZ = IN_U8 ? 2 : 8;                       // bytes per input sample
+    constexpr int ISZ = (IN_U8 ? 2 : 8) / (PAIR ? 2 : 1);    // bytes per input sample
+    constexpr int ESZ = PAIR ? 4 : 8;                         // bytes per float32 sample (history, output)
     const char *in_c = static_cast<const char *>(a.in) + (size_t)ch * a.in_stride * ISZ;
-    v2f *out_c = static_cast<v2f *>(a.out) + (size_t)ch * a.out_stride;
-    const v2f *hist_c = static_cast<const v2f *>(a.hist) + (size_t)ch * a.hl;
+    char *out_c = static_cast<char *>(a.out) + (size_t)ch * a.out_stride * ESZ;
+    const char *hist_c = static_cast<const char *>(a.hist) + (size_t)ch * a.hl * ESZ;
 
     const v2f *tw = reinterpret_cast<const v2f *>(a.tw);
     // the six twiddle bases per lane W_256^(l k), W_256^(4 l k) sit in LDS and are re-read every
@@ -99,35 +103,47 @@ __global__ __launch_bounds__(256, 4) void poly_fft256_kernel(PolyFftArgs a)
             asm volatile("" : "+v"(G[r][c]));
         }
 
+    // one complex sample (or, PAIR, one real sample in .x) at p[lane]
     auto load_in = [&](const char *p, unsigned lane) -> v2f {
-        if constexpr (IN_U8) {   // wire format: (b - 128) / 127 on load (gr-simplefe/lib/source_c_impl.cc:121-132)
+        if constexpr (PAIR) {
+            if constexpr (IN_U8) return (v2f){u8_to_f32(__builtin_nontemporal_load(reinterpret_cast<const unsigned char *>(p) + lane)), 0.0f};
+            else return (v2f){__builtin_nontemporal_load(reinterpret_cast<const float *>(p) + lane), 0.0f};
+        } else if constexpr (IN_U8) {   // wire format: (b - 128) / 127 on load (gr-simplefe/lib/source_c_impl.cc:121-132)
             const unsigned w = __builtin_nontemporal_load(reinterpret_cast<const unsigned short *>(p) + lane);
             return (v2f){u8_to_f32(w & 0xFFu), u8_to_f32(w >> 8)};
         } else {
             return __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p) + lane);
         }
     };
-    // the R*SP*256 staged samples of a pass, thread t: sample t + 256 i of each segment
+    // sample idx of the virtual stream history ++ input ++ zeros (edge segments only)
+    auto load_guarded = [&](long long idx) -> v2f {
+        if (idx >= 0) return idx < a.n_in ? load_in(in_c + idx * ISZ, 0u) : (v2f){0.0f, 0.0f};
+        if (idx + a.hl < 0) return (v2f){0.0f, 0.0f};
+        if constexpr (PAIR) return (v2f){reinterpret_cast<const float *>(hist_c)[idx + a.hl], 0.0f};
+        else return reinterpret_cast<const v2f *>(hist_c)[idx + a.hl];
+    };
+    // the R*SP*256 staged samples of a pass, thread t: sample t + 256 i of each segment.  PAIR:
+    // transform (pass*R + sg) carries real segments 2*(pass*R + sg) in .x and the next one in .y.
     auto load_pass = [&](v2f (&s)[R * SP], long long pass) {
 #pragma unroll
         for (int sg = 0; sg < R; sg++) {
             // stream index of the segment's staged sample 0 (uniform)
-            const long long start = ((pass * R + sg) * a.V - a.ovl) * SP + a.e_max - (SP - 1);
-            if (start >= 0 && start + (long long)PF_M * SP <= a.n_in) {
+            const long long sidx = (pass * R + sg) * (PAIR ? 2 : 1);
+            const long long start = (sidx * a.V - a.ovl) * SP + a.e_max - (SP - 1);
+            const long long span = (long long)PF_M * SP + (PAIR ? (long long)a.V * SP : 0);
+            if (start >= 0 && start + span <= a.n_in) {
                 const char *p = in_c + start * ISZ;
 #pragma unroll
-                for (int i = 0; i < SP; i++) s[sg * SP + i] = load_in(p, t + 256u * i);
+                for (int i = 0; i < SP; i++) {
+                    s[sg * SP + i] = load_in(p, t + 256u * i);
+                    if constexpr (PAIR) s[sg * SP + i].y = load_in(p + (long long)a.V * SP * ISZ, t + 256u * i).x;
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < SP; i++) {
                     const long long idx = start + (long long)(t + 256u * i);
-                    v2f x = (v2f){0.0f, 0.0f};
-                    if (idx >= 0) {
-                        if (idx < a.n_in) x = load_in(in_c + idx * ISZ, 0u);
-                    } else if (idx + a.hl >= 0) {
-                        x = hist_c[idx + a.hl];
-                    }
-                    s[sg * SP + i] = x;
+                    s[sg * SP + i] = load_guarded(idx);
+                    if constexpr (PAIR) s[sg * SP + i].y = load_guarded(idx + (long long)a.V * SP).x;
                 }
             }
         }
@@ -192,8 +208,8 @@ __global__ __launch_bounds__(256, 4) void poly_fft256_kernel(PolyFftArgs a)
         } else if (is_inv && prev >= 0) {
             // forward transform of Y, read backwards: y[n] = FFT(Y)[(256 - n) mod 256]
             // output index of this group's n = 0: uniform part + per-thread part (32-bit)
-            const long long ku = ((prev * R) * a.V - a.ovl) * UP;
-            const int koff = (int)(seg * (unsigned)a.V * UP + comp);
+            const long long ku = ((prev * R) * (PAIR ? 2 : 1) * a.V - a.ovl) * UP;
+            const int koff = (int)(seg * (PAIR ? 2u : 1u) * (unsigned)a.V * UP + comp);
             // outputs of this group exist for ovl <= n and ku + koff + UP n < n_out
             const long long remu = a.n_out - ku;
             const int rem = (remu > (1 << 30) ? (1 << 30) : (int)remu) - koff;
@@ -205,11 +221,28 @@ __global__ __launch_bounds__(256, 4) void poly_fft256_kernel(PolyFftArgs a)
             // ovu <= x < lim as ONE unsigned compare per store: (x - ovu) < (lim - ovu)
             const unsigned span = lim > ovu ? (unsigned)(lim - ovu) : 0u;
             const unsigned xb = (unsigned)(nu - ovu);
-            char *op = reinterpret_cast<char *>(out_c + ko0) + (long long)nu * 8;
+            char *op = out_c + (ko0 + nu) * ESZ;
+            if constexpr (PAIR) {
+                // .x belongs to real segment 2*sigma, .y to segment 2*sigma + 1, V*UP outputs further on
+                const int limB = rem - a.V * UP > 256 * UP ? 256 * UP : rem - a.V * UP;
+                const unsigned spanB = limB > ovu ? (unsigned)(limB - ovu) : 0u;
+                char *opB = op + (long long)a.V * UP * ESZ;
 #pragma unroll
-            for (int k0 = 0; k0 < 16; k0++)
-                if (xb - (unsigned)(16 * UP * k0) < span) __builtin_nontemporal_store(v[P16(k0)], reinterpret_cast<v2f *>(op - 16 * UP * 8 * k0));
-            if (l == 0 && a.ovl == 0 && lim > 0) __builtin_nontemporal_store(v[P16(0)], out_c + ko0);
+                for (int k0 = 0; k0 < 16; k0++) {
+                    const unsigned xo = xb - (unsigned)(16 * UP * k0);
+                    if (xo < span) __builtin_nontemporal_store(v[P16(k0)].x, reinterpret_cast<float *>(op - 16 * UP * ESZ * k0));
+                    if (xo < spanB) __builtin_nontemporal_store(v[P16(k0)].y, reinterpret_cast<float *>(opB - 16 * UP * ESZ * k0));
+                }
+                if (l == 0 && a.ovl == 0) {
+                    if (lim > 0) __builtin_nontemporal_store(v[P16(0)].x, reinterpret_cast<float *>(out_c + ko0 * ESZ));
+                    if (limB > 0) __builtin_nontemporal_store(v[P16(0)].y, reinterpret_cast<float *>(out_c + (ko0 + (long long)a.V * UP) * ESZ));
+                }
+            } else {
+#pragma unroll
+                for (int k0 = 0; k0 < 16; k0++)
+                    if (xb - (unsigned)(16 * UP * k0) < span) __builtin_nontemporal_store(v[P16(k0)], reinterpret_cast<v2f *>(op - 16 * UP * 8 * k0));
+                if (l == 0 && a.ovl == 0 && lim > 0) __builtin_nontemporal_store(v[P16(0)], reinterpret_cast<v2f *>(out_c + ko0 * 8));
+            }
         }
         lds_barrier();
         // request the next pass's samples now: v[] is dead, they land while S3 and the barrier run
@@ -235,14 +268,14 @@ __global__ __launch_bounds__(256, 4) void poly_fft256_kernel(PolyFftArgs a)
     }
 }
 
-template <int SP, int UP, int R, bool IN_U8>
+template <int SP, int UP, int R, bool IN_U8, bool PAIR>
 int launch_one(const PolyFftArgs &a, int n_channels, hipStream_t s)
 {
     static int resident = 0;
     if (!resident) {
         int dev = 0, cus = 0, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, poly_fft256_kernel<SP, UP, R, IN_U8>, 256, 0) != hipSuccess || per_cu < 1)
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, poly_fft256_kernel<SP, UP, R, IN_U8, PAIR>, 256, 0) != hipSuccess || per_cu < 1)
             return hip_fail(hipGetLastError(), "poly_fft occupancy");
         resident = cus * per_cu;
     }
@@ -251,7 +284,7 @@ int launch_one(const PolyFftArgs &a, int n_channels, hipStream_t s)
     long long cap = (2LL * resident + n_channels - 1) / n_channels;
     if (cap < 1) cap = 1;
     dim3 grid((unsigned)(a.n_pass < cap ? a.n_pass : cap), (unsigned)n_channels);
-    hipLaunchKernelGGL((poly_fft256_kernel<SP, UP, R, IN_U8>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((poly_fft256_kernel<SP, UP, R, IN_U8, PAIR>), grid, dim3(256), 0, s, a);
     hipError_t err = hipGetLastError();
     return err == hipSuccess ? SFE_OK : hip_fail(err, "poly_fft launch");
 }
@@ -271,17 +304,19 @@ int poly_fft_segments(int SP, int UP)
     return 0;
 }
 
-int launch_poly_fft(const PolyFftPlan &plan, const PolyFftArgs &a0, int in_u8, int n_channels, hipStream_t s)
+int launch_poly_fft(const PolyFftPlan &plan, const PolyFftArgs &a0, int data_complex, int in_u8, int n_channels, hipStream_t s)
 {
     PolyFftArgs a = a0;
     const int R = poly_fft_segments(plan.SP, plan.UP);
     if (!R || a.n_out <= 0) return SFE_ESTATE;
     const long long m_count = (a.n_out + plan.UP - 1) / plan.UP;
     const long long n_seg = (m_count + a.V - 1) / a.V;
-    a.n_pass = (n_seg + R - 1) / R;
+    const long long n_xf = data_complex ? n_seg : (n_seg + 1) / 2;      // real data: two segments per transform
+    a.n_pass = (n_xf + R - 1) / R;
 #define SFE_PF(sp, up, r)                                                                         \
     if (plan.SP == sp && plan.UP == up)                                                           \
-        return in_u8 ? launch_one<sp, up, r, true>(a, n_channels, s) : launch_one<sp, up, r, false>(a, n_channels, s);
+        return data_complex ? (in_u8 ? launch_one<sp, up, r, true, false>(a, n_channels, s) : launch_one<sp, up, r, false, false>(a, n_channels, s)) \
+                            : (in_u8 ? launch_one<sp, up, r, true, true>(a, n_channels, s) : launch_one<sp, up, r, false, true>(a, n_channels, s));
     SFE_PF_SHAPES(SFE_PF)
 #undef SFE_PF
     return SFE_ESTATE;

@@ -377,6 +377,27 @@ def test_rs_bulk_fft_path_cf32(api, L, orc, monkeypatch, U, S, n_taps, n, nch, c
             assert synth.rel_rms(got, ref[: len(got)]) <= TOL, (c, part)
 
 
+@pytest.mark.parametrize("U,S,n_taps,n,nch,chunk", [
+    (3, 5, 381, 100000, 1, None), (3, 5, 381, 250001, 2, 65536), (2, 3, 200, 90001, 1, None),
+    (1, 4, 256, 80000, 2, 30001), (1, 8, 600, 120000, 1, None), (4, 5, 700, 90000, 1, None),
+    (3, 5, 381, 7001, 1, None), (3, 5, 381, 5 * 231 * 3, 1, None)])
+def test_rs_bulk_fft_path_real_data(api, L, orc, monkeypatch, U, S, n_taps, n, nch, chunk):
+    """Real float32 streams through the transform-domain kernel: two consecutive real segments
+    ride as the real and imaginary parts of one transform (the sub-filters are real).  Odd and
+    even segment counts, streams ending inside the first / second half of a pair, chunked calls."""
+    monkeypatch.setenv("SFE_RS_FFT", "1")
+    rng = np.random.default_rng(U * 1000 + S)
+    taps = (rng.standard_normal(n_taps) / np.sqrt(n_taps)).astype(np.float32)
+    x = np.stack([synth.synth_f32(n, ch=20 + c) for c in range(nch)])
+    rate = float(np.float32(S) / np.float32(U))
+    r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=False, n_channels=nch)
+    y = r.resample_array(x, rate, chunk=chunk)
+    for c in range(nch):
+        ref, _ = orc.Resample(taps, U, 4096).stream(x[c], rate)
+        assert 0 <= len(ref) - len(y[c]) <= 1
+        assert synth.rel_rms(y[c], ref[: len(y[c])]) <= TOL, c
+
+
 def test_rs_fft_path_is_the_default_for_long_filters(api, L, g5, monkeypatch):
     """cfg3 (5/3, 381 taps) takes the transform-domain kernel by default and the direct kernel
     with SFE_RS_FFT=0 or in exact mode; the two agree to float32 rounding and the exact one is
