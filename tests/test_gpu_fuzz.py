@@ -122,3 +122,33 @@ def test_rs_fft_path_random_shapes(api, L, monkeypatch, seed):
     assert outs[False].shape == outs[True].shape, (U, S, n_taps, n, cuts)
     for c in range(nch):
         assert synth.rel_rms(outs[False][c], outs[True][c]) <= 1e-5, (U, S, n_taps, n, nch, cuts, c)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_blkconv_class_vs_compiled_reference_random(api, orc, seed):
+    """The drop-in blkconv class beside the reference's own (blkconv.cxx on ROCm's libhipfftw),
+    run live on random tap counts and fft lengths -- powers of two, even and odd lengths, taps from
+    1 to most of the block -- through the same get_process_buf()/process() calls; and the CPU
+    restatement beside both."""
+    if orc.ref_blkconv_lib() is None:
+        pytest.skip("oracle/_ref/libsferef_blkconv.so not prebuilt")
+    rng = np.random.default_rng(4000 + seed)
+    fft_len = int(rng.choice([32, 64, 100, 255, 1000, 1024, 2048, 4096, 5000, 16384]))
+    n_taps = int(rng.integers(1, max(2, fft_len // 2)))
+    taps = (rng.standard_normal(n_taps) / np.sqrt(n_taps)).astype(np.float32)
+    ref = orc.RefBlkconv(taps, fft_len)
+    dut = api.blkconv(taps, fft_len)
+    cpu = orc.Blkconv(taps, fft_len)
+    blk = ref.blk
+    assert dut.get_blksize() == blk == cpu.blk == fft_len + 1 - n_taps
+    nblk = int(rng.integers(2, 7))
+    x = synth.synth_f32(nblk * blk, ch=200 + seed)
+    buf = dut.get_process_buf()
+    got, want, rest = np.empty_like(x), np.empty_like(x), np.empty_like(x)
+    for off in range(0, len(x), blk):
+        for obj, b, dst in ((ref, ref.buf, want), (dut, buf, got), (cpu, cpu.buf, rest)):
+            b[:blk] = x[off: off + blk]
+            obj.process()
+            dst[off: off + blk] = b[:blk]
+    assert synth.rel_rms(got, want) < 2e-6, (fft_len, n_taps)
+    assert synth.rel_rms(rest, want) < 2e-6, (fft_len, n_taps)
