@@ -398,6 +398,30 @@ def test_rs_bulk_fft_path_real_data(api, L, orc, monkeypatch, U, S, n_taps, n, n
         assert synth.rel_rms(y[c], ref[: len(y[c])]) <= TOL, c
 
 
+@pytest.mark.parametrize("U,S,n_taps", [(1, 4, 256), (1, 5, 333), (2, 6, 400), (1, 8, 640)])
+def test_rs_bulk_fft_path_decimate_mode(api, L, orc, monkeypatch, U, S, n_taps):
+    """The decimate class's bulk path (mode DECIMATE: its own tap folding, decimate.cxx:37-66)
+    takes the transform-domain kernel for long filters by default; against the oracle's Decimate."""
+    monkeypatch.delenv("SFE_RS_FFT", raising=False)
+    rng = np.random.default_rng(S * 10 + U)
+    taps = (rng.standard_normal(n_taps) / np.sqrt(n_taps)).astype(np.float32)
+    n = 150001
+    x = synth.synth_cf32(n, ch=7)[None, :]
+    rate = float(np.float32(S) / np.float32(U))
+    r = api.Rs(taps, U, 4096, mode=L.RS_DECIMATE, data_complex=True)
+    y = r.resample_array(x, rate, chunk=70000)[0]
+    r2 = api.Rs(taps, U, 4096, mode=L.RS_DECIMATE, data_complex=True)
+    r2.set_exact(True)
+    ye = r2.resample_array(x, rate, chunk=70000)[0]
+    assert y.shape == ye.shape and not np.array_equal(y, ye)      # a different kernel served the default
+    for part in (0, 1):
+        ref, _ = orc.Decimate(taps, U, 4096).stream(x[0, part::2], rate)
+        got = y[part::2]
+        assert 0 <= len(ref) - len(got) <= 1
+        assert synth.rel_rms(got, ref[: len(got)]) <= TOL
+        assert np.array_equal(ye[part::2], ref[: len(got)])       # exact mode: the reference's bits
+
+
 def test_rs_fft_path_is_the_default_for_long_filters(api, L, g5, monkeypatch):
     """cfg3 (5/3, 381 taps) takes the transform-domain kernel by default and the direct kernel
     with SFE_RS_FFT=0 or in exact mode; the two agree to float32 rounding and the exact one is
