@@ -75,18 +75,21 @@ private:
 
 // Integer decimation by D with an anti-alias FIR: the `decimate` class at rate D, upsample 1
 // (libdsp/decimate.cxx:69-129).  A sync_decimator: work() consumes D*noutput_items inputs.
-class decimate_ccf : public gr::sync_decimator
+// CPLX: gr_complex items (decimate_ccf) or float items (decimate_fff).
+template <bool CPLX>
+class decimate_xxf : public gr::sync_decimator
 {
 public:
-    typedef std::shared_ptr<decimate_ccf> sptr;
+    typedef std::shared_ptr<decimate_xxf> sptr;
     static sptr make(const std::vector<float> &taps, unsigned decimation, int max_items = 1 << 16, int device = 0)
     {
-        return sptr(new decimate_ccf(taps, decimation, max_items, device));
+        return sptr(new decimate_xxf(taps, decimation, max_items, device));
     }
-    ~decimate_ccf() { sfe_dsp_rs_destroy(d_h); }
+    ~decimate_xxf() { sfe_dsp_rs_destroy(d_h); }
 
     int work(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &output_items)
     {
+        constexpr size_t W = CPLX ? 2 : 1;          // floats per item
         const float *in = static_cast<const float *>(input_items[0]);
         float *out = static_cast<float *>(output_items[0]);
         int produced = 0, n_in = noutput_items * (int)decimation();
@@ -94,36 +97,40 @@ public:
         for (int off = 0; off < n_in; off += d_blk) {
             const int m = n_in - off < d_blk ? n_in - off : d_blk;
             int n_out = 0;
-            check(sfe_dsp_rs_process(d_h, in + 2 * (size_t)off, m, out + 2 * (size_t)produced, noutput_items - produced + 1,
-                                     (float)decimation(), &n_out), "decimate_ccf::work");
+            check(sfe_dsp_rs_process(d_h, in + W * (size_t)off, m, out + W * (size_t)produced, noutput_items - produced + 1,
+                                     (float)decimation(), &n_out), "decimate::work");
             produced += n_out;
         }
         return produced;
     }
 
 private:
-    decimate_ccf(const std::vector<float> &taps, unsigned d, int max_items, int device)
-        : gr::sync_decimator("sfe_decimate_ccf", gr::io_signature::make(1, 1, sizeof(gr_complex)),
-                             gr::io_signature::make(1, 1, sizeof(gr_complex)), d), d_h(0), d_blk(max_items)
+    decimate_xxf(const std::vector<float> &taps, unsigned d, int max_items, int device)
+        : gr::sync_decimator(CPLX ? "sfe_decimate_ccf" : "sfe_decimate_fff",
+                             gr::io_signature::make(1, 1, CPLX ? sizeof(gr_complex) : sizeof(float)),
+                             gr::io_signature::make(1, 1, CPLX ? sizeof(gr_complex) : sizeof(float)), d), d_h(0), d_blk(max_items)
     {
-        check(sfe_dsp_rs_create(taps.data(), (int)taps.size(), 1, max_items, 1, 1, device, SFE_RS_DECIMATE, &d_h), "decimate_ccf");
+        check(sfe_dsp_rs_create(taps.data(), (int)taps.size(), 1, max_items, CPLX ? 1 : 0, 1, device, SFE_RS_DECIMATE, &d_h), "decimate");
     }
     sfe_rs_t d_h;
     int d_blk;
 };
+typedef decimate_xxf<true> decimate_ccf;
+typedef decimate_xxf<false> decimate_fff;
 
 // Rational resampler: `interp` outputs per `decim` inputs through a prototype designed at the
 // upsampled rate -- the `resample` class with upsample = interp, rate = decim/interp
 // (libdsp/resample.cxx:85-153).  A general block: general_work() consumes what it is given.
-class rational_resampler_ccf : public gr::block
+template <bool CPLX>
+class rational_resampler_xxf : public gr::block
 {
 public:
-    typedef std::shared_ptr<rational_resampler_ccf> sptr;
+    typedef std::shared_ptr<rational_resampler_xxf> sptr;
     static sptr make(unsigned interp, unsigned decim, const std::vector<float> &taps, int max_items = 1 << 16, int device = 0)
     {
-        return sptr(new rational_resampler_ccf(interp, decim, taps, max_items, device));
+        return sptr(new rational_resampler_xxf(interp, decim, taps, max_items, device));
     }
-    ~rational_resampler_ccf() { sfe_dsp_rs_destroy(d_h); }
+    ~rational_resampler_xxf() { sfe_dsp_rs_destroy(d_h); }
 
     void forecast(int noutput_items, gr_vector_int &req)
     {
@@ -141,26 +148,29 @@ public:
         if (n_in > d_blk) n_in = d_blk;
         if (n_in <= 0) { consume_each(0); return 0; }
         int n_out = 0;
-        check(sfe_dsp_rs_process(d_h, in, n_in, out, noutput_items, d_rate, &n_out), "rational_resampler_ccf::general_work");
+        check(sfe_dsp_rs_process(d_h, in, n_in, out, noutput_items, d_rate, &n_out), "rational_resampler::general_work");
         consume_each(n_in);
         return n_out;
     }
 
 private:
-    rational_resampler_ccf(unsigned interp, unsigned decim, const std::vector<float> &taps, int max_items, int device)
-        : gr::block("sfe_rational_resampler_ccf", gr::io_signature::make(1, 1, sizeof(gr_complex)),
-                    gr::io_signature::make(1, 1, sizeof(gr_complex))),
+    rational_resampler_xxf(unsigned interp, unsigned decim, const std::vector<float> &taps, int max_items, int device)
+        : gr::block(CPLX ? "sfe_rational_resampler_ccf" : "sfe_rational_resampler_fff",
+                    gr::io_signature::make(1, 1, CPLX ? sizeof(gr_complex) : sizeof(float)),
+                    gr::io_signature::make(1, 1, CPLX ? sizeof(gr_complex) : sizeof(float))),
           d_h(0), d_interp(interp), d_decim(decim), d_blk(max_items), d_rate((float)decim / (float)interp)
     {
         set_relative_rate((double)interp / decim);
-        check(sfe_dsp_rs_create(taps.data(), (int)taps.size(), (int)interp, max_items, 1, 1, device, SFE_RS_RESAMPLE, &d_h),
-              "rational_resampler_ccf");
+        check(sfe_dsp_rs_create(taps.data(), (int)taps.size(), (int)interp, max_items, CPLX ? 1 : 0, 1, device, SFE_RS_RESAMPLE, &d_h),
+              "rational_resampler");
     }
     sfe_rs_t d_h;
     unsigned d_interp, d_decim;
     int d_blk;
     float d_rate;
 };
+typedef rational_resampler_xxf<true> rational_resampler_ccf;
+typedef rational_resampler_xxf<false> rational_resampler_fff;
 
 }  // namespace sfe
 }  // namespace gr

@@ -124,6 +124,20 @@ def test_gr_decimate_and_resampler_blocks_bit_exact(gr_exe, tmp_path, g5, orc):
         assert len(ref) - len(got) <= 2 and np.array_equal(got, ref[: len(got)])
 
 
+def test_gr_float_item_blocks_bit_exact(gr_exe, tmp_path, g5, orc):
+    """The float-item twins (decimate_fff, rational_resampler_fff: the reference's classes are
+    real-valued, its source_f / sink_f blocks carry float items) against the oracle, bit-exact."""
+    from simplefe_amd import synth
+    n = 50000
+    x = synth.synth_f32(n, ch=9)
+    y = _run_gr(gr_exe, tmp_path, "decimate_f", g5["cfg4_taps"], x, 8)
+    ref, _ = orc.Decimate(g5["cfg4_taps"], 1, 4096).stream(x, 8.0)
+    assert len(ref) - len(y) <= 1 and np.array_equal(y, ref[: len(y)])
+    y = _run_gr(gr_exe, tmp_path, "resample_f", g5["cfg3_taps"], x, 5, 3)
+    ref, _ = orc.Resample(g5["cfg3_taps"], 3, 4096).stream(x, 5.0 / 3.0)
+    assert len(ref) - len(y) <= 2 and np.array_equal(y, ref[: len(y)])
+
+
 # ------------------------------------------ bpsk pipeline end to end on the GPU path (N3)
 def _bpsk_stream(n_blocks, blk):
     """The process thread's symbol generator of examples/bpsk_gpu/bpsk_gpu.cpp, in Python."""
