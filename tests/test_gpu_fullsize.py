@@ -156,3 +156,17 @@ def test_multichannel_cfg5_shape(api, L, orc):
             got = y.to_numpy(2 * W, offset=2 * (n * c + s0))
             ref = orc.Blkconv(taps, 4096).stream(np.ascontiguousarray(seg[0::2]))[s0 - lo:]
             assert synth.rel_rms(got[0::2], ref) <= TOL, (c, s0)
+
+
+def test_bulk_kernels_are_deterministic_run_to_run():
+    """scripts/soak_determinism.py: every bulk kernel (FIR, transform-domain resample complex and
+    real, decimate) writes the same bits on repeated runs over a 2^26-sample stream -- a missing
+    barrier or an LDS hazard between passes would show as run-to-run differences."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "soak_determinism.py"), "12"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("12 runs") == 4, r.stdout
