@@ -27,6 +27,7 @@
 //   S3  bin owners: Y_r = sum_c H_rc X_c for the pass's segments -> the inverse jobs' areas
 // Three workgroup barriers per pass; 35.6 KiB LDS (16 job areas + the per-lane twiddle bases),
 // <= 128 VGPRs -> 4 workgroups per CU.  DESIGN.md section 4.2c has the measurements.
+#include <stdint.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -149,18 +150,68 @@ __global__ __launch_bounds__(256, 4) void poly_fft256_kernel(PolyFftArgs a)
         }
     };
 
+    // WIDE (u8 complex input): a pass's samples are requested as 16-byte lanes (8 samples each,
+    // from the 16-byte boundary at or below the segment's start) instead of 2-byte lanes -- a
+    // tenth of the load instructions and whole-line requests -- kept raw in 4 VGPRs per segment
+    // and converted when they are scattered.  Edge passes (history, stream end, unaligned base)
+    // take the per-sample path, synchronously.
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    constexpr int NCHUNK = 32 * SP + 1;                       // 16-byte chunks covering 256*SP samples at any phase
+    constexpr bool WIDE = IN_U8 && !PAIR && NCHUNK <= 256;
+    const bool base16 = (reinterpret_cast<uintptr_t>(in_c) & 15u) == 0;
+    auto seg_start = [&](long long pass, int sg) -> long long {
+        return ((pass * R + sg) * a.V - a.ovl) * SP + a.e_max - (SP - 1);
+    };
+    auto pass_is_wide = [&](long long pass) -> bool {
+        if (!WIDE || !base16) return false;
+        const long long a0 = seg_start(pass, 0) & ~7LL, a1 = seg_start(pass, R - 1) & ~7LL;
+        return a0 >= 0 && a1 + 8LL * NCHUNK <= a.n_in;
+    };
+    auto load_pass_wide = [&](v4u (&raw)[R], long long pass) {
+#pragma unroll
+        for (int sg = 0; sg < R; sg++) {
+            const long long a0 = seg_start(pass, sg) & ~7LL;
+            if (t < (unsigned)NCHUNK) raw[sg] = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(in_c + a0 * 2) + t);
+        }
+    };
+
     long long prev = -1;       // pass whose inverse transforms run in this iteration
     v2f s[R * SP];
+    v4u raw[R];
     // passes are dealt round-robin (blockIdx.x, + gridDim.x, ...): at any moment the resident
     // workgroups read one compact window of the stream.  Giving each workgroup a contiguous run of
     // passes instead (so the overlap re-read hits L2) measured 8 % SLOWER: a thousand separate
     // read/write streams cost HBM more than the 5 % of re-read bytes they save.
-    if ((long long)blockIdx.x < a.n_pass) load_pass(s, blockIdx.x);
+    bool cur_wide = false;
+    if ((long long)blockIdx.x < a.n_pass) {
+        cur_wide = pass_is_wide(blockIdx.x);
+        if (cur_wide) load_pass_wide(raw, blockIdx.x);
+        else if (!WIDE) load_pass(s, blockIdx.x);
+    }
     for (long long pass = blockIdx.x;; pass += gridDim.x) {
         const bool cur = pass < a.n_pass;
         if (!cur && prev < 0) break;
         // ---- S0: stage this pass's input (requested during the last iteration's S3), transposed by component
-        if (cur) {
+        if (cur && WIDE && cur_wide) {
+            unsigned tt = t;
+            asm volatile("" : "+v"(tt));
+            if (tt < (unsigned)NCHUNK) {
+#pragma unroll
+                for (int sg = 0; sg < R; sg++) {
+                    const int delta = (int)(seg_start(pass, sg) & 7LL);       // uniform
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const unsigned w = raw[sg][e >> 1] >> (16 * (e & 1));
+                        const unsigned j = 8u * tt + e - (unsigned)delta;      // wraps for the samples before the start
+                        if (j < 256u * SP) {
+                            const unsigned c = j % SP, k = j / SP;
+                            lds[(sg * SP + c) * PF_AREA + (k ^ pf_swz(c))] = (v2f){u8_to_f32(w & 0xFFu), u8_to_f32((w >> 8) & 0xFFu)};
+                        }
+                    }
+                }
+            }
+        } else if (cur) {
+            if (WIDE) load_pass(s, pass);      // an edge pass of the wide variant: nothing was requested ahead
             unsigned tt = t;
             asm volatile("" : "+v"(tt));      // recompute the scatter cells here instead of keeping R*SP of them live
 #pragma unroll
@@ -247,7 +298,11 @@ __global__ __launch_bounds__(256, 4) void poly_fft256_kernel(PolyFftArgs a)
         lds_barrier();
         // request the next pass's samples now: v[] is dead, they land while S3 and the barrier run
         // (requesting them a whole pass ahead instead measured the same: latency is not what binds)
-        if (pass + gridDim.x < a.n_pass) load_pass(s, pass + gridDim.x);
+        if (pass + gridDim.x < a.n_pass) {
+            cur_wide = pass_is_wide(pass + gridDim.x);
+            if (cur_wide) load_pass_wide(raw, pass + gridDim.x);
+            else if (!WIDE) load_pass(s, pass + gridDim.x);
+        }
         // ---- S3: bin t of every segment of this pass
         if (cur) {
 #pragma unroll
