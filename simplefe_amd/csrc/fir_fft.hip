@@ -21,6 +21,7 @@
 // Twiddle bases live in registers for the life of the (persistent) workgroup, which walks
 // transforms blockIdx.x, +gridDim.x, ...; the taps' spectrum (32 KiB, L2-resident) is
 // re-read per transform.  Budget: <= 128 VGPRs and 34 KiB LDS -> 4 workgroups per CU.
+#include <stdint.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -149,6 +150,29 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             return;
         }
         const long long base = blk * a.advance - a.hl;   // stream index of transform element 0
+        if constexpr (IN_U8 && IN_C && !PREFETCH) {
+            // u8 wire format, interior transform, 16-byte-aligned stream: the transform's 8 KiB are
+            // requested as 16-byte lanes (two per thread instead of sixteen 2-byte ones), parked raw
+            // in the first 8 KiB of the exchange buffer and picked up as this thread's 16 samples.
+            // (base*2 is a multiple of 512: advance and hl are multiples of 256.)
+            if (base >= 0 && base + FFT_N <= a.n && (reinterpret_cast<uintptr_t>(in_c) & 15u) == 0) {
+                typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                const v4u *src = reinterpret_cast<const v4u *>(in_c + base * 2);
+                const v4u r0 = __builtin_nontemporal_load(src + t), r1 = __builtin_nontemporal_load(src + 256u + t);
+                v4u *raw = reinterpret_cast<v4u *>(lds);
+                raw[t] = r0;
+                raw[256u + t] = r1;
+                lds_barrier();
+                const unsigned short *rs = reinterpret_cast<const unsigned short *>(lds);
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const unsigned w = rs[256 * r + t];
+                    x[r] = (v2f){u8_to_f32(w & 0xFFu), u8_to_f32(w >> 8)};
+                }
+                lds_barrier();      // F1 rewrites these cells
+                return;
+            }
+        }
         if (base >= 0 && base + FFT_N <= a.n) {
 #pragma unroll
             for (int r = 0; r < 16; r++) x[r] = load_sample<IN_C, IN_U8>(in_c + (base + 256 * r) * ISZ, t);
