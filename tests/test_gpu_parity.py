@@ -478,6 +478,36 @@ def test_fir_u8_input_fused(api, L, orc):
     assert synth.rel_rms(got, ref) <= TOL
 
 
+@pytest.mark.parametrize("byte_offset", [0, 2, 6, 16])
+def test_u8_input_any_alignment_two_channels(api, L, orc, byte_offset):
+    """u8 streams that do not start on a 16-byte boundary (the wide-lane request needs one) and
+    whose second channel sits at an odd stride take the 2-byte path: same bits as the float path,
+    FIR and transform-domain resampler alike."""
+    n, nch, stride = 40000, 2, 40000 + 3
+    b = _u8_stream(2 * (stride * nch + 16), 5)
+    xf = np.stack([orc.rx_u8_to_cf32(b[byte_offset + 2 * stride * c: byte_offset + 2 * stride * c + 2 * n]) for c in range(nch)])
+    d_all = api.DeviceArray.from_bytes(b)
+    for kind in ("fir", "rs"):
+        if kind == "fir":
+            taps = synth.taps_cfg2()
+            want = api.Fir(taps, data_complex=True, n_channels=nch, algo=L.FIR_ALGO_FFT).filter(xf)
+            f = api.Fir(taps, data_complex=True, n_channels=nch, algo=L.FIR_ALGO_FFT)
+            f.set_input_format(L.FMT_U8)
+            d_out = api.DeviceArray(nch * 2 * n)
+            f.process_stream(d_all.ptr + byte_offset, d_out, n, in_stride=stride, out_stride=n)
+            got = d_out.to_numpy().reshape(nch, 2 * n)
+        else:
+            taps, U, rate = synth.taps_cfg3(), 3, 5.0 / 3.0
+            want = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=True, n_channels=nch).resample_array(xf, rate)
+            r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=True, n_channels=nch)
+            r.set_input_format(L.FMT_U8)
+            cap = want.shape[1] // 2 + 8
+            d_out = api.DeviceArray(nch * 2 * cap)
+            k = r.process_stream(d_all.ptr + byte_offset, n, d_out, cap, rate, in_stride=stride, out_stride=cap)
+            got = d_out.to_numpy().reshape(nch, 2 * cap)[:, : 2 * k]
+        assert got.shape == want.shape and np.array_equal(got, want), (kind, byte_offset)
+
+
 @pytest.mark.parametrize("name,cplx", [("cfg4", True), ("cfg4", False), ("cfg3", True)])
 @pytest.mark.parametrize("chunk", [None, 4099, 1001])
 def test_rs_u8_input_fused(api, L, orc, g5, name, cplx, chunk):
