@@ -48,6 +48,29 @@ __device__ __forceinline__ v2f load_sample(const void *p, unsigned lane)
     else return (v2f){__builtin_nontemporal_load(reinterpret_cast<const float *>(p) + lane), 0.0f};
 }
 
+// value held by lane K of this lane's quad / by the odd lane of this lane's pair: DPP quad_perm
+// moves (plain VALU), not ds_bpermute -- the packing runs 15 rows x 2 segments per transform
+template <int K>
+__device__ __forceinline__ unsigned quad_lane(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, K | (K << 2) | (K << 4) | (K << 6), 0xF, 0xF, true);
+}
+__device__ __forceinline__ unsigned quad_odd(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 1 | (1 << 2) | (3 << 4) | (3 << 6), 0xF, 0xF, true);
+}
+
+// four 10-bit codes -> the 5-byte group of the transmit wire format (sink_f_impl.cc:133-140): the
+// high-bits byte and the first three low bytes go out as ONE (unaligned) dword store, the last low
+// byte as a byte store -- two stores per group instead of five
+__device__ __forceinline__ void store_group(unsigned char *d, unsigned u0, unsigned u1, unsigned u2, unsigned u3)
+{
+    const unsigned w = ((u0 >> 8) | ((u1 >> 8) << 2) | ((u2 >> 8) << 4) | ((u3 >> 8) << 6)) | ((u0 & 0xFFu) << 8) |
+                       ((u1 & 0xFFu) << 16) | ((u2 & 0xFFu) << 24);
+    __builtin_memcpy(d, &w, 4);
+    d[4] = (unsigned char)u3;
+}
+
 // WAVES = waves per SIMD the register allocator must fit (3 -> <=168 VGPRs, 2 -> <=256);
 // PREFETCH = request transform i+1's rows during transform i's inverse stages.
 // HREG = keep this thread's 16 bins of H/N in registers (32 VGPRs) instead of re-reading 32 KiB
@@ -282,21 +305,15 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
                 if constexpr (OUT_TX10) {
                     // lanes 4g..4g+3 hold 4 consecutive samples: quantise in place, gather the four
                     // 10-bit codes into lane 4g, which writes the 5 bytes of group (row + t)/4
-                    const int lane = (int)(t & 63u);
 #pragma unroll
                     for (int q = 0; q < 2; q++) {
                         const long long o = (q ? oB : oA) + 256 * r;                 // multiple of 256
                         const unsigned u = (unsigned)((int)(short)(int)((q ? y.y : y.x) * 511.0f) + 512) & 0x3FFu;
-                        const unsigned u0 = __shfl(u, lane & ~3), u1 = __shfl(u, (lane & ~3) + 1);
-                        const unsigned u2 = __shfl(u, (lane & ~3) + 2), u3 = __shfl(u, (lane & ~3) + 3);
+                        const unsigned u0 = quad_lane<0>(u), u1 = quad_lane<1>(u), u2 = quad_lane<2>(u), u3 = quad_lane<3>(u);
                         // only whole groups of 4 are emitted (the reference's loop steps by 4)
                         if ((t & 3u) == 0 && o + (long long)t + 3 < a.n) {
                             unsigned char *d = reinterpret_cast<unsigned char *>(out_c) + ((o + (long long)t) >> 2) * 5;
-                            d[0] = (unsigned char)((u0 >> 8) | ((u1 >> 8) << 2) | ((u2 >> 8) << 4) | ((u3 >> 8) << 6));
-                            d[1] = (unsigned char)u0;
-                            d[2] = (unsigned char)u1;
-                            d[3] = (unsigned char)u2;
-                            d[4] = (unsigned char)u3;
+                            store_group(d, u0, u1, u2, u3);
                         }
                     }
                 } else {
@@ -319,17 +336,12 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
                 // consecutive samples = the four floats of one 5-byte group; lane 2g writes it
                 if (r < row0) continue;
                 const v2f y = v[P16(r)];
-                const int lane = (int)(t & 63u);
                 const unsigned u0 = (unsigned)((int)(short)(int)(y.x * 511.0f) + 512) & 0x3FFu;
                 const unsigned u1 = (unsigned)((int)(short)(int)(y.y * 511.0f) + 512) & 0x3FFu;
-                const unsigned u2 = __shfl(u0, lane | 1), u3 = __shfl(u1, lane | 1);
+                const unsigned u2 = quad_odd(u0), u3 = quad_odd(u1);       // the odd partner's codes
                 if ((t & 1u) == 0 && orow + (long long)t + 1 < a.n) {
                     unsigned char *d = reinterpret_cast<unsigned char *>(out_c) + ((orow + (long long)t) >> 1) * 5;
-                    d[0] = (unsigned char)((u0 >> 8) | ((u1 >> 8) << 2) | ((u2 >> 8) << 4) | ((u3 >> 8) << 6));
-                    d[1] = (unsigned char)u0;
-                    d[2] = (unsigned char)u1;
-                    d[3] = (unsigned char)u2;
-                    d[4] = (unsigned char)u3;
+                    store_group(d, u0, u1, u2, u3);
                 }
                 continue;
             }
