@@ -834,8 +834,8 @@ int sfe_dsp_fir_process_stream(sfe_fir_t h, const void *d_in, void *d_out, size_
         set_error("fir_process_stream: channel stride smaller than n");
         return SFE_EINVAL;
     }
-    if ((reinterpret_cast<uintptr_t>(d_out) & 7) || (reinterpret_cast<uintptr_t>(d_in) & (f->in_u8 ? 1 : 7))) {
-        set_error("fir_process_stream: buffers must be 8-byte aligned (2-byte for u8 input)");
+    if ((reinterpret_cast<uintptr_t>(d_out) & 7) || (reinterpret_cast<uintptr_t>(d_in) & (f->in_u8 ? (f->data_complex ? 1 : 0) : 7))) {
+        set_error("fir_process_stream: buffers must be 8-byte aligned (u8 input: 2-byte for (I,Q) pairs, none for real)");
         return SFE_EINVAL;
     }
     SFE_ON_DEVICE(f->device);

@@ -151,6 +151,24 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         if constexpr (PAIR) {
             // segment A = transform 2*blk of the real stream, segment B = transform 2*blk + 1
             const long long baseA = 2 * blk * a.advance - a.hl, baseB = baseA + a.advance;
+            if constexpr (IN_U8 && !PREFETCH) {
+                // real u8 stream: each segment's 4 KiB as one 16-byte lane per thread, parked raw in
+                // LDS and picked up bytewise (the complex form is below)
+                if (baseA >= 0 && baseB + FFT_N <= a.n && (reinterpret_cast<uintptr_t>(in_c) & 15u) == 0) {
+                    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                    const v4u rA = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(in_c + baseA) + t);
+                    const v4u rB = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(in_c + baseB) + t);
+                    v4u *raw = reinterpret_cast<v4u *>(lds);
+                    raw[t] = rA;
+                    raw[256u + t] = rB;
+                    lds_barrier();
+                    const unsigned char *rs = reinterpret_cast<const unsigned char *>(lds);
+#pragma unroll
+                    for (int r = 0; r < 16; r++) x[r] = (v2f){u8_to_f32(rs[256 * r + t]), u8_to_f32(rs[4096 + 256 * r + t])};
+                    lds_barrier();      // F1 rewrites these cells
+                    return;
+                }
+            }
             if (baseA >= 0 && baseB + FFT_N <= a.n) {
 #pragma unroll
                 for (int r = 0; r < 16; r++)

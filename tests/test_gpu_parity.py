@@ -478,6 +478,27 @@ def test_fir_u8_input_fused(api, L, orc):
     assert synth.rel_rms(got, ref) <= TOL
 
 
+@pytest.mark.parametrize("n", [100000, 7681, 30000 + 5])
+@pytest.mark.parametrize("byte_offset", [0, 3])
+def test_fir_u8_input_fused_real_stream(api, L, orc, n, byte_offset):
+    """Real u8 stream (source_f wire format, source_f_impl.cc:120-129) through the FIR: two real
+    segments per transform, bytes requested as 16-byte lanes when the stream is 16-byte aligned
+    and bytewise otherwise -- either way the same bits as filtering the converted floats."""
+    taps = synth.taps_cfg2()
+    b = _u8_stream(n + 16, 9)
+    xf = orc.rx_u8_to_f32(b[byte_offset: byte_offset + n])
+    want = api.Fir(taps, data_complex=False, algo=L.FIR_ALGO_FFT).filter(xf)[0]
+    f = api.Fir(taps, data_complex=False, algo=L.FIR_ALGO_FFT)
+    f.set_input_format(L.FMT_U8)
+    d_in = api.DeviceArray.from_bytes(b)
+    d_out = api.DeviceArray(n)
+    f.process_stream(d_in.ptr + byte_offset, d_out, n)
+    got = d_out.to_numpy()
+    assert np.array_equal(got, want)
+    ref = orc.Blkconv(taps, 4096).stream(xf)
+    assert synth.rel_rms(got, ref) <= TOL
+
+
 @pytest.mark.parametrize("byte_offset", [0, 2, 6, 16])
 def test_u8_input_any_alignment_two_channels(api, L, orc, byte_offset):
     """u8 streams that do not start on a 16-byte boundary (the wide-lane request needs one) and
