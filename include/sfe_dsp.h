@@ -101,7 +101,9 @@ int sfe_dsp_fir_process_block(sfe_fir_t h);
 /* Bulk device-resident form of the same law (the measured path): n samples per channel,
  * channel c at d_in + c*in_stride and d_out + c*out_stride (strides in samples; pass n for
  * packed).  d_out must not alias d_in.  Asynchronous on `stream`.  Output is complex when
- * data or taps are complex, else real. */
+ * data or taps are complex, else real.  d_in and d_out are 8-byte aligned; with SFE_FMT_U8 input
+ * d_in needs 2-byte alignment for (I,Q) pairs and none for real streams (16-byte aligned streams
+ * take the faster wide-lane request). */
 int sfe_dsp_fir_process_stream(sfe_fir_t h, const void *d_in, void *d_out, size_t n,
                                size_t in_stride, size_t out_stride, sfe_stream_t stream);
 /* Host-pointer form of the bulk law for ONE channel and any n: H2D, kernel, D2H through pinned
