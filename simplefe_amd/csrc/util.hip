@@ -66,9 +66,38 @@ __device__ __forceinline__ uint32_t q10(float x)
     return (uint32_t)(v + 512) & 0x3FFu;
 }
 
+// One thread packs FOUR groups: 16 floats in (four 16-byte loads), 20 bytes out as five dwords
+// (20 k is 4-byte aligned whenever dst is); the last n_groups % 4 groups go out bytewise.
 __global__ __launch_bounds__(256) void tx_10bit_kernel(const float *src, uint8_t *dst, size_t n_groups)
 {
-    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < n_groups; g += (size_t)gridDim.x * 256) {
+    const size_t n_quads = n_groups / 4;
+    const bool dst_aligned = (reinterpret_cast<uintptr_t>(dst) & 3) == 0;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n_quads; q += (size_t)gridDim.x * 256) {
+        uint8_t b[20];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const v4f x = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src) + 4 * q + k);
+            const uint32_t u0 = q10(x.x), u1 = q10(x.y), u2 = q10(x.z), u3 = q10(x.w);
+            b[5 * k + 0] = (uint8_t)((u0 >> 8) | ((u1 >> 8) << 2) | ((u2 >> 8) << 4) | ((u3 >> 8) << 6));
+            b[5 * k + 1] = (uint8_t)(u0 & 0xFF);
+            b[5 * k + 2] = (uint8_t)(u1 & 0xFF);
+            b[5 * k + 3] = (uint8_t)(u2 & 0xFF);
+            b[5 * k + 4] = (uint8_t)(u3 & 0xFF);
+        }
+        uint8_t *o = dst + q * 20;
+        if (dst_aligned) {
+#pragma unroll
+            for (int w = 0; w < 5; w++)
+                reinterpret_cast<uint32_t *>(o)[w] = (uint32_t)b[4 * w] | ((uint32_t)b[4 * w + 1] << 8) | ((uint32_t)b[4 * w + 2] << 16) |
+                                                     ((uint32_t)b[4 * w + 3] << 24);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 20; i++) o[i] = b[i];
+        }
+    }
+    // tail groups (fewer than four), one thread each
+    const size_t g = n_quads * 4 + (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (g < n_groups) {
         const v4f x = reinterpret_cast<const v4f *>(src)[g];
         const uint32_t u0 = q10(x.x), u1 = q10(x.y), u2 = q10(x.z), u3 = q10(x.w);
         uint8_t *o = dst + g * 5;
@@ -122,7 +151,7 @@ int launch_tx_f32_to_10bit(const float *src, uint8_t *dst, size_t n_floats, hipS
         set_error("tx_f32_to_10bit: src must be 16-byte aligned");
         return SFE_EINVAL;
     }
-    hipLaunchKernelGGL(tx_10bit_kernel, dim3(grid_for(groups)), dim3(256), 0, s, src, dst, groups);
+    hipLaunchKernelGGL(tx_10bit_kernel, dim3(grid_for(groups / 4 + 1)), dim3(256), 0, s, src, dst, groups);
     SFE_HIP(hipGetLastError());
     return SFE_OK;
 }

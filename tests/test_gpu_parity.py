@@ -321,6 +321,14 @@ def test_converters_bit_exact(api, L, orc):
     api.check(lib.sfe_dsp_tx_f32_to_10bit(d_x.ptr, d_o.ptr, len(x), None))
     out = d_o.to_numpy().view(np.uint8)[: len(x) // 4 * 5]
     assert np.array_equal(out, orc.tx_f32_to_10bit(x))
+    # group counts of every residue mod 4 (the kernel packs four groups per thread, tail bytewise),
+    # a byte-unaligned destination, and floats left over after the last whole group
+    for n_floats, off in ((4 * 13, 0), (4 * 14 + 1, 0), (4 * 15 + 3, 1), (4 * 16 + 2, 3), (4 * 1001, 2), (3, 0)):
+        d_o.zero()
+        api.check(lib.sfe_dsp_tx_f32_to_10bit(d_x.ptr, d_o.ptr + off, n_floats, None))
+        raw = d_o.to_numpy().view(np.uint8)
+        want = orc.tx_f32_to_10bit(x[:n_floats])
+        assert np.array_equal(raw[off: off + len(want)], want) and not raw[off + len(want): off + len(want) + 8].any()
 
 
 # ------------------------------------------------- matrix-pipe (f32 MFMA) polyphase path
