@@ -192,12 +192,21 @@ static const PolyFftPlan *get_fft_plan(FftPlanCache &cache, const std::vector<fl
     pl.R = poly_fft_segments(f.SP, f.UP);
     pl.Li = f.Lp / f.SP;
     pl.e_max = f.e_max;
-    // worth it when the direct form spends more multiply-adds per input sample than the transforms
-    // do (~100 flop per sample at 256 points), and the overlap does not eat the block
+    // Selection (measured over a grid of shapes at 2^26 samples, scripts/calibrate_rs_fft.py):
+    //  - the overlap must leave a useful block: Li <= 192 (V = 257 - Li >= 65 of 256 points);
+    //  - shapes the tiled direct kernel has no instantiation for fall to the generic kernel, which is
+    //    3-11x slower than this one: take the transform whenever it exists;
+    //  - otherwise the transform wins once the direct form costs more than ~230 flop per (complex)
+    //    input sample, scaled by how much of each 256-point block is overlap, and 1.4x later for
+    //    UP = 4 (one segment per pass fills only 9 of the 16 lane groups).
     const double direct_flops = 2.0 * 2.0 * f.Lp * f.UP / f.SP;    // per complex input sample (or per pair of real ones)
+    const int V = 257 - pl.Li;
+    const int Lp2 = ((f.Lp + 2 * f.SP - 1) / (2 * f.SP)) * (2 * f.SP);
+    const bool tiled_ok = poly_tiled_supported(f.SP, f.UP, Lp2);
+    const double threshold = 230.0 * 231.0 / (V > 0 ? V : 1) * (f.UP >= 4 ? 1.4 : 1.0);
     const char *env = getenv("SFE_RS_FFT");
     const bool forced = env && env[0] == '1';
-    if (!pl.R || pl.Li > 96 || (env && env[0] == '0') || (!forced && direct_flops < 200.0)) {
+    if (!pl.R || pl.Li > 192 || (env && env[0] == '0') || (!forced && tiled_ok && direct_flops < threshold)) {
         cache.plans[key] = pl;
         return nullptr;
     }

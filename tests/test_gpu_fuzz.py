@@ -103,7 +103,7 @@ def test_rs_fft_path_random_shapes(api, L, monkeypatch, seed):
             (6, 10), (2, 4), (3, 9)][seed]
     g = int(np.gcd(U, S))
     SP = S // g
-    n_taps = int(rng.integers(U, 96 * SP * U + 40))
+    n_taps = int(rng.integers(U, 192 * SP * U + 40))
     taps = (rng.standard_normal(n_taps) / np.sqrt(n_taps)).astype(np.float32)
     nch = int(rng.integers(1, 4))
     n = int(rng.choice([7000 * SP, 231 * SP * 64 + 1, 100003, 180000]))

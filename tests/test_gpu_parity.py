@@ -363,14 +363,14 @@ def test_rs_bulk_mfma_path_cf32(api, L, orc, g5, monkeypatch, name, force, chunk
     (2, 5, 301, 90000, 3, 40000), (3, 4, 255, 120000, 1, None), (1, 2, 128, 80000, 1, 30000),
     (1, 3, 200, 80000, 1, None), (1, 4, 256, 80000, 2, None), (1, 5, 333, 80000, 1, 20001),
     (3, 5, 30, 60000, 1, None), (3, 5, 1000, 200000, 1, 70000), (6, 10, 762, 100000, 1, None),
-    (3, 5, 381, 8000, 1, None), (3, 5, 1420, 50000, 1, None),
+    (3, 5, 381, 8000, 1, None), (3, 5, 1420, 50000, 1, None), (3, 5, 2860, 60000, 1, 25000),
     (1, 6, 400, 90000, 1, None), (1, 7, 500, 100000, 2, 50001), (1, 8, 600, 120000, 1, None),
     (2, 7, 450, 100000, 1, 33000), (4, 5, 700, 90000, 1, None), (3, 5, 381, 30000, 19, None)])
 def test_rs_bulk_fft_path_cf32(api, L, orc, monkeypatch, U, S, n_taps, n, nch, chunk):
     """Every instantiated (SP, UP) of the 256-point transform-domain kernel, forced on
     (SFE_RS_FFT=1), against the oracle with I and Q as two real passes: ragged ends, chunked calls
     (carried history and pos0), channel strides, a filter too short to need it, one whose overlap
-    (Li = 96 low-rate taps) is the longest it accepts, and a stream of few segments."""
+    (Li = 192 low-rate taps of every 256 points) is the longest it accepts, and a stream of few segments."""
     monkeypatch.setenv("SFE_RS_FFT", "1")
     rng = np.random.default_rng(U * 100 + S)
     taps = (rng.standard_normal(n_taps) / np.sqrt(n_taps)).astype(np.float32)
