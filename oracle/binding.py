@@ -58,6 +58,11 @@ def lib():
             getattr(L, f"orc_{k}_create").argtypes = [_f32p, C.c_int, C.c_int, C.c_int]
             getattr(L, f"orc_{k}_process").argtypes = [C.c_void_p, _f32p, C.c_int, _f32p, C.c_int, C.c_float]
             getattr(L, f"orc_{k}_destroy").argtypes = [C.c_void_p]
+        L.orc_blkconv_stream_mt.restype = C.c_long
+        L.orc_blkconv_stream_mt.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_void_p, C.c_long, C.c_int]
+        L.orc_rs_stream_mt.restype = C.c_long
+        L.orc_rs_stream_mt.argtypes = [C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_float, _f32p, C.c_long,
+                                       C.c_long, C.c_int]
         L.orc_rx_u8_to_cf32.argtypes = [_f32p, _u8p, C.c_int]
         L.orc_rx_u8_to_f32.argtypes = [_f32p, _u8p, C.c_int]
         L.orc_tx_f32_to_10bit.argtypes = [_u8p, _f32p, C.c_int]
@@ -80,6 +85,10 @@ def ref_lib():
             getattr(R, f"ref_{k}_create").argtypes = [_f32p, C.c_int, C.c_int, C.c_int]
             getattr(R, f"ref_{k}_process").argtypes = [C.c_void_p, _f32p, C.c_int, _f32p, C.c_int, C.c_float]
             getattr(R, f"ref_{k}_destroy").argtypes = [C.c_void_p]
+        if hasattr(R, "ref_rs_stream_mt"):
+            R.ref_rs_stream_mt.restype = C.c_long
+            R.ref_rs_stream_mt.argtypes = [C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_float, _f32p, C.c_long,
+                                           C.c_long, C.c_int]
         _ref = R
     return _ref
 
@@ -232,6 +241,26 @@ class RefResample(_Rs):
 class RefDecimate(_Rs):
     _prefix = "ref_decimate"
     _getlib = staticmethod(ref_lib)
+
+
+def blkconv_stream_mt(taps, fft_len, x, n_threads, want_output=True):
+    """One real stream through n_threads blkconv objects, one per span with n_taps-1 samples of
+    lead-in (all-host-cores baseline, bench.py).  Returns y (or None) ."""
+    taps, x = _f32(taps), _f32(x)
+    y = np.empty_like(x) if want_output else None
+    lib().orc_blkconv_stream_mt(taps, len(taps), int(fft_len), x, y.ctypes.data if want_output else None,
+                                len(x), int(n_threads))
+    return y
+
+
+def rs_stream_mt(which, taps, upsample, blksize, rate, x, quantum, n_threads, reference=False):
+    """One real stream through n_threads resample/decimate objects (spans cut on whole phase
+    periods, phase_len+1 samples of lead-in); returns the number of outputs produced (lead-ins
+    included).  reference=True runs the reference's own classes (oracle/_ref)."""
+    taps, x = _f32(taps), _f32(x)
+    fn = ref_lib().ref_rs_stream_mt if reference else lib().orc_rs_stream_mt
+    return fn(1 if which == "decimate" else 0, taps, len(taps), int(upsample), int(blksize), float(rate), x, len(x),
+              int(quantum), int(n_threads))
 
 
 def rx_u8_to_cf32(b):

@@ -7,6 +7,7 @@
  * so that the float32 operation order below is the order executed (an FMA-contracted
  * build differs from the reference in the last bit).
  */
+#define _GNU_SOURCE
 #include "sfe_oracle.h"
 
 #include <math.h>
@@ -503,4 +504,152 @@ int orc_tx_f32_to_10bit(unsigned char *dst, const float *src, int src_len)
         dst[j++] = (unsigned char)(u[3] & 0xFF);
     }
     return j;
+}
+
+/* =============================================================================
+ * All-host-cores CPU baseline (bench.py cpu_baseline.all_cores; SURVEY.md 8(d) last row).
+ * The reference classes are single-threaded, one object per stream (no threads anywhere in
+ * libdsp/); the only way to use more cores on ONE stream is to cut it into spans, give each
+ * span its own object and feed every object `ovl` samples of the stream in front of its span
+ * so its carried state (blkconv.cxx:105-109 overlap / the resamplers' history) is the
+ * stream's.  Outputs of the lead-in are dropped.  Timing/validation helper, not a product path.
+ * ========================================================================== */
+#include <pthread.h>
+#include <sched.h>
+
+/* Pin the calling thread to the idx-th CPU this process may run on: short-lived worker threads
+ * are otherwise left time-slicing on the core that created them (measured here: 8 threads of
+ * 70 ms each took 700 ms unpinned, 75 ms pinned). */
+static void pin_to_nth_cpu(int idx)
+{
+    cpu_set_t allowed, one;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+    const int n = CPU_COUNT(&allowed);
+    if (n <= 1) return;
+    int want = idx % n, seen = 0;
+    for (int c = 0; c < CPU_SETSIZE; c++)
+        if (CPU_ISSET(c, &allowed)) {
+            if (seen == want) {
+                CPU_ZERO(&one);
+                CPU_SET(c, &one);
+                (void)pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
+                return;
+            }
+            seen++;
+        }
+}
+
+typedef struct {
+    int kind;                  /* 0 blkconv, 1 resample, 2 decimate */
+    const float *taps;
+    int n_taps, p1, p2;        /* blkconv: fft_len, -; rs: upsample, blksize */
+    float rate;
+    const float *x;
+    float *y;                  /* blkconv: y[n] (may be NULL: outputs discarded) */
+    long lo, s, e;             /* feed x[lo..e), keep outputs of x[s..e) */
+    long n_out;
+    int  cpu;                  /* >= 0: pin to that index of the allowed set */
+} mt_job;
+
+static void *mt_run(void *arg)
+{
+    mt_job *j = (mt_job *)arg;
+    const long span = j->e - j->lo;
+    if (span <= 0) return NULL;
+    if (j->cpu >= 0) pin_to_nth_cpu(j->cpu);
+    if (j->kind == 0) {
+        orc_blkconv *c = orc_blkconv_create(j->taps, j->n_taps, j->p1);
+        const int blk = orc_blkconv_blksize(c);
+        float *buf = orc_blkconv_buf(c);
+        /* block by block through the object's own buffer, as a caller of the class would
+         * (no span-sized scratch: fresh pages from N threads at once serialise in the kernel) */
+        for (long off = j->lo; off < j->e; off += blk) {
+            const long m = (j->e - off) < blk ? (j->e - off) : blk;
+            memcpy(buf, j->x + off, sizeof(float) * (size_t)m);
+            for (long i = m; i < blk; i++) buf[i] = 0.0f;
+            orc_blkconv_process(c);
+            if (j->y && off + m > j->s) {
+                const long a = off < j->s ? j->s - off : 0;
+                memcpy(j->y + off + a, buf + a, sizeof(float) * (size_t)(m - a));
+            }
+        }
+        j->n_out = j->e - j->s;
+        orc_blkconv_destroy(c);
+    } else {
+        const int B = j->p2;
+        const int cap = (int)((float)B / j->rate) + 4;
+        float *out = (float *)malloc(sizeof(float) * (size_t)cap);
+        void *h = j->kind == 1 ? (void *)orc_resample_create(j->taps, j->n_taps, j->p1, B)
+                               : (void *)orc_decimate_create(j->taps, j->n_taps, j->p1, B);
+        long k = 0;
+        for (long off = j->lo; off < j->e; off += B) {
+            const int m = (int)((j->e - off) < B ? (j->e - off) : B);
+            k += j->kind == 1 ? orc_resample_process((orc_resample *)h, j->x + off, m, out, cap, j->rate)
+                              : orc_decimate_process((orc_decimate *)h, j->x + off, m, out, cap, j->rate);
+        }
+        j->n_out = k;
+        if (j->kind == 1) orc_resample_destroy((orc_resample *)h);
+        else orc_decimate_destroy((orc_decimate *)h);
+        free(out);
+    }
+    return NULL;
+}
+
+static long mt_dispatch(mt_job proto, long n, long ovl, long quantum, int n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    pthread_t th[256];
+    mt_job jobs[256];
+    long per = (n + n_threads - 1) / n_threads;
+    per = (per + quantum - 1) / quantum * quantum;    /* cuts on whole phase periods */
+    int used = 0;
+    for (int t = 0; t < n_threads; t++) {
+        long s = (long)t * per, e = s + per < n ? s + per : n;
+        if (s >= n) break;
+        jobs[t] = proto;
+        jobs[t].s = s;
+        jobs[t].e = e;
+        jobs[t].lo = s - ovl > 0 ? (s - ovl) / quantum * quantum : 0;
+        jobs[t].n_out = 0;
+        jobs[t].cpu = t > 0 ? t : -1;      /* job 0 runs on the caller's thread, left where it is */
+        used++;
+    }
+    for (int t = 1; t < used; t++) pthread_create(&th[t], NULL, mt_run, &jobs[t]);
+    mt_run(&jobs[0]);
+    long total = jobs[0].n_out;
+    for (int t = 1; t < used; t++) {
+        pthread_join(th[t], NULL);
+        total += jobs[t].n_out;
+    }
+    return total;
+}
+
+long orc_blkconv_stream_mt(const float *taps, int n_taps, int fft_len, const float *x, float *y, long n,
+                           int n_threads)
+{
+    mt_job p;
+    memset(&p, 0, sizeof(p));
+    p.kind = 0;
+    p.taps = taps;
+    p.n_taps = n_taps;
+    p.p1 = fft_len;
+    p.x = x;
+    p.y = y;
+    return mt_dispatch(p, n, n_taps - 1, 1, n_threads);
+}
+
+long orc_rs_stream_mt(int decimate_class, const float *taps, int n_taps, int upsample, int blksize, float rate,
+                      const float *x, long n, long quantum, int n_threads)
+{
+    mt_job p;
+    memset(&p, 0, sizeof(p));
+    p.kind = decimate_class ? 2 : 1;
+    p.taps = taps;
+    p.n_taps = n_taps;
+    p.p1 = upsample;
+    p.p2 = blksize;
+    p.rate = rate;
+    p.x = x;
+    return mt_dispatch(p, n, (n_taps + upsample - 1) / upsample + 1, quantum < 1 ? 1 : quantum, n_threads);
 }

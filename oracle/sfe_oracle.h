@@ -60,6 +60,16 @@ int orc_rx_u8_to_f32(float *dst, const unsigned char *src, int src_len);
  * gr-simplefe/lib/sink_c_impl.cc:118-144 == examples/bpsk/bpsk.cxx:76-101 */
 int orc_tx_f32_to_10bit(unsigned char *dst, const float *src, int src_len);
 
+/* ---- all-host-cores baseline helpers (bench.py cpu_baseline.all_cores) ----------
+ * One stream cut into n_threads spans, one object per span, each fed n_taps-1 (resamplers:
+ * phase_len+1) samples of lead-in so its carried state is the stream's; the lead-in's outputs
+ * are dropped.  blkconv: y (may be NULL) receives the n outputs.  Return: outputs produced. */
+long orc_blkconv_stream_mt(const float *taps, int n_taps, int fft_len, const float *x, float *y,
+                           long n, int n_threads);
+/* quantum: cut points are multiples of it (input samples per phase period, step/gcd(step,U)) */
+long orc_rs_stream_mt(int decimate_class, const float *taps, int n_taps, int upsample, int blksize,
+                      float rate, const float *x, long n, long quantum, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

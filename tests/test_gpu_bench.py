@@ -1,0 +1,60 @@
+"""bench.py as the driver runs it, on the GPU box (`-m gpu`): the N > 1 launch path from a bare
+shell, per-rank parity, the cross-rank checksum, and the shape of the one JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args, env_extra=None, timeout=600):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                       env=env, timeout=timeout, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus2_from_a_bare_shell_starts_two_ranks_and_checks_both():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must start 2 ranks itself (here both on the
+    one device, over gloo: SFE_BENCH_ONE_DEVICE=1) and report n_gpus == 2 with every rank's
+    windows checked; the all-reduced checksum equals the one-process run over the same 16
+    channels (seeds 0..15) -- the channel partition changes nothing."""
+    r2, j2 = _bench("--gpus", "2", "--log2n", "22", "--steps", "3", "--warmup", "1", "--no-cpu",
+                    env_extra={"SFE_BENCH_ONE_DEVICE": "1"})
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    assert j2["n_gpus"] == 2 and j2["config"]["channels_per_gpu"] == 8
+    assert j2["parity"]["ok"] and j2["parity"]["ranks_checked"] == 2 and j2["parity"]["windows"] == 8
+    assert j2["checksum"]["samples"] == 2 * (1 << 22)
+    r1, j1 = _bench("--gpus", "1", "--log2n", "23", "--channels", "16", "--steps", "3", "--warmup", "1", "--no-cpu")
+    assert r1.returncode == 0, r1.stdout + r1.stderr
+    assert j1["n_gpus"] == 1 and j1["checksum"]["samples"] == j2["checksum"]["samples"]
+    for k in ("sum_re", "sum_im", "sum_abs2"):
+        a, b = j1["checksum"][k], j2["checksum"][k]
+        assert abs(a - b) <= 1e-9 * max(1.0, abs(a)), (k, a, b)
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """Never an n_gpus=1 line for --gpus N: a mismatching WORLD_SIZE is an error, not a fallback."""
+    r, j = _bench("--gpus", "4", "--no-cpu", env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and j is None
+
+
+def test_bench_default_line_small():
+    """The default workload at a reduced size: headline keys, roofline, parity, checksum present."""
+    r, j = _bench("--log2n", "24", "--steps", "5", "--warmup", "2", "--cpu-seconds", "2")
+    assert r.returncode == 0, r.stdout + r.stderr
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "checksum"):
+        assert k in j, k
+    assert j["parity"]["ok"] and j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1
+    cb = j["cpu_baseline"]
+    assert cb["cores"] == 1 and cb["all_cores"]["cores"] == cb["host_cores"] >= 1

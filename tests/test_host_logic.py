@@ -202,3 +202,16 @@ def test_time_law_closed_form_matches_literal_replay(tmp_path):
     assert r.returncode == 0, r.stderr
     r = _cxx([exe])
     assert r.returncode == 0 and "timelaw ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_bench_gpus_n_without_a_gpu_fails_loudly():
+    """`python bench.py --gpus 2` on a host without a GPU: non-zero exit, no JSON line (the round-1
+    script printed an n_gpus=1 line for --gpus 8; ADVICE bench.py:125)."""
+    import subprocess
+    import sys
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("host has a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode != 0 and "{" not in r.stdout

@@ -180,3 +180,22 @@ def test_synth_is_exact_and_in_range():
     assert np.array_equal(x * np.float32(2 ** 23), np.round(x * np.float32(2 ** 23)))
     assert np.array_equal(synth.synth_f32(100, first=50), synth.synth_f32(150)[50:])
     assert abs(float(x.mean())) < 0.05
+
+
+def test_all_cores_helpers_agree_with_the_single_object(orc):
+    """bench.py's all-host-cores baseline cuts one stream into spans, one object per span with
+    n_taps-1 samples of lead-in: the stitched blkconv output equals the single
+    object's to float32 FFT rounding, and the resamplers produce the same output count."""
+    from simplefe_amd import synth
+    x = synth.synth_f32(200000)
+    t = synth.taps_cfg2()
+    y1 = orc.Blkconv(t, 4096).stream(x)
+    for C in (1, 3, 8):
+        assert synth.rel_rms(orc.blkconv_stream_mt(t, 4096, x, C), y1) <= 1e-6
+    t4 = synth.taps_cfg4()
+    ref, _ = orc.Decimate(t4, 1, 4096).stream(x, 8.0)
+    assert orc.rs_stream_mt("decimate", t4, 1, 4096, 8.0, x, 8, 1) == len(ref)
+    k4 = orc.rs_stream_mt("decimate", t4, 1, 4096, 8.0, x, 8, 4)
+    assert len(ref) <= k4 <= len(ref) + 4 * 12           # + the lead-ins' outputs
+    if orc.ref_lib() is not None and hasattr(orc.ref_lib(), "ref_rs_stream_mt"):
+        assert orc.rs_stream_mt("decimate", t4, 1, 4096, 8.0, x, 8, 4, reference=True) == k4
