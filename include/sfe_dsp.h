@@ -100,10 +100,12 @@ int sfe_dsp_fir_host_buffer(sfe_fir_t h, float **buf, int *blk);
 int sfe_dsp_fir_process_block(sfe_fir_t h);
 /* Bulk device-resident form of the same law (the measured path): n samples per channel,
  * channel c at d_in + c*in_stride and d_out + c*out_stride (strides in samples; pass n for
- * packed).  d_out must not alias d_in.  Asynchronous on `stream`.  Output is complex when
- * data or taps are complex, else real.  d_in and d_out are 8-byte aligned; with SFE_FMT_U8 input
- * d_in needs 2-byte alignment for (I,Q) pairs and none for real streams (16-byte aligned streams
- * take the faster wide-lane request). */
+ * packed; with n_channels > 1 both must be >= n).  The input and output byte ranges must not
+ * overlap at all (SFE_EINVAL).  Asynchronous on `stream`.  Output is complex when data or taps
+ * are complex, else real.  Buffers are aligned to their element: 8 bytes for complex float32,
+ * 4 for real float32; with SFE_FMT_U8 input d_in needs 2-byte alignment for (I,Q) pairs and
+ * none for real streams (16-byte aligned streams take the faster wide-lane request); with
+ * SFE_FMT_TX10 output d_out needs none. */
 int sfe_dsp_fir_process_stream(sfe_fir_t h, const void *d_in, void *d_out, size_t n,
                                size_t in_stride, size_t out_stride, sfe_stream_t stream);
 /* Host-pointer form of the bulk law for ONE channel and any n: H2D, kernel, D2H through pinned
@@ -161,7 +163,12 @@ int sfe_dsp_rs_process(sfe_rs_t h, const float *in, int n_in, float *out, int ou
  * fed the same stream in chunks of `blksize`.  When fl(rate*upsample) is integer-valued the
  * result does not depend on the chunking and one closed-form launch is used; otherwise the
  * float32 time recurrence is replayed on the host, chunk by chunk, and uploaded.
- * Fails with SFE_ERANGE if out_cap is too small (nothing is written).  Asynchronous. */
+ * Fails with SFE_ERANGE if out_cap is too small (nothing is written).  Asynchronous.
+ * Strides are in samples; with n_channels > 1, in_stride >= n_in and out_stride >= out_cap
+ * (up to out_cap outputs per channel may be written).  Buffers are aligned to their element
+ * (complex float32 8 bytes, real float32 4, SFE_FMT_U8 (I,Q) pairs 2, real u8 none) and the
+ * input and output byte ranges -- (n_channels-1)*stride + n_in resp. out_cap elements -- must
+ * not overlap; violations return SFE_EINVAL before anything is launched. */
 int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t in_stride,
                               void *d_out, size_t out_cap, size_t out_stride, float rate,
                               size_t *n_out, sfe_stream_t stream);

@@ -1,13 +1,19 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of FIR kernel variants in ONE process on ONE device
-(cdna_hip_programming.md rule 24).  Usage: ab_fir.py "3n" "3p" "2n" "2p:3" ...   (variant[:wg_per_cu])"""
+(cdna_hip_programming.md rule 24), through the DIAGNOSTIC library libsfe_dsp_diag.so (-DSFE_DIAG:
+built on demand; the product library has none of these switches).
+Usage: ab_fir.py "4n.h" "3p" "c:8" "4n.h+1" ...   variant[:wg_per_cu][+diag bits: 1 no loads, 2 no stores]
+  variant = <waves per SIMD 2-4><p prefetch | n none>[s XOR-swizzled LDS][h H/N in registers]
+            c / d / e = the bare access pattern (8-byte plain / 16-byte plain / 8-byte nontemporal lanes)"""
 import os
 import sys
 
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from simplefe_amd import api, lib, synth  # noqa: E402
+from simplefe_amd import build, lib  # noqa: E402
+lib.LIB_PATH = build.build_lib(diag=True)          # before anything loads the product library
+from simplefe_amd import api, synth  # noqa: E402
 
 variants = sys.argv[1:] or ["3n", "3p", "2n", "2p"]
 log2n = int(os.environ.get("LOG2N", "28"))
@@ -21,7 +27,9 @@ t = api.Timer()
 res = {v: [] for v in variants}
 for r in range(rounds + 1):
     for v in variants:
-        vv = v.split(":")
+        vd = v.split("+")
+        os.environ["SFE_FIR_DIAG"] = vd[1] if len(vd) > 1 else "0"
+        vv = vd[0].split(":")
         os.environ["SFE_FIR_VARIANT"] = vv[0]
         if len(vv) > 1:
             os.environ["SFE_FIR_WG_PER_CU"] = vv[1]

@@ -1,0 +1,101 @@
+// hbm_mix.hip -- what this box's HBM gives for pure reads, pure writes and a 1:1 copy, with the
+// lane widths and cache policies the FIR kernel could use.  The FIR kernel's memory floor is the
+// copy figure, not the read figure: the guide's ~6.3 TB/s is a read rate.
+//   hipcc --offload-arch=gfx950 -O3 scripts/probes/hbm_mix.hip -o scripts/probes/hbm_mix && scripts/probes/hbm_mix
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s\n", hipGetErrorString(e), #x); exit(1); } } while (0)
+
+template <typename T, bool NT, int U>
+__global__ __launch_bounds__(256) void k_read(const T *in, T *out, size_t n)
+{
+    T acc = {};
+    const size_t stride = (size_t)gridDim.x * 256 * U;
+    for (size_t i = (size_t)blockIdx.x * 256 * U + threadIdx.x; i + 256 * (U - 1) < n; i += stride) {
+        T v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = NT ? __builtin_nontemporal_load(in + i + 256 * u) : in[i + 256 * u];
+#pragma unroll
+        for (int u = 0; u < U; u++) acc += v[u];
+    }
+    if (acc[0] == 1.2345e38f) out[threadIdx.x] = acc;
+}
+template <typename T, bool NT, int U>
+__global__ __launch_bounds__(256) void k_write(T *out, size_t n)
+{
+    T v = {};
+    v[0] = (float)threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256 * U;
+    for (size_t i = (size_t)blockIdx.x * 256 * U + threadIdx.x; i + 256 * (U - 1) < n; i += stride) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (NT) __builtin_nontemporal_store(v, out + i + 256 * u);
+            else out[i + 256 * u] = v;
+        }
+    }
+}
+template <typename T, bool NTL, bool NTS, int U>
+__global__ __launch_bounds__(256) void k_copy(const T *in, T *out, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256 * U;
+    for (size_t i = (size_t)blockIdx.x * 256 * U + threadIdx.x; i + 256 * (U - 1) < n; i += stride) {
+        T v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = NTL ? __builtin_nontemporal_load(in + i + 256 * u) : in[i + 256 * u];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (NTS) __builtin_nontemporal_store(v[u], out + i + 256 * u);
+            else out[i + 256 * u] = v[u];
+        }
+    }
+}
+
+template <typename F>
+static void timeit(const char *name, double bytes, F launch)
+{
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    for (int i = 0; i < 5; i++) launch();
+    float best = 1e9f, sum = 0;
+    const int R = 30;
+    for (int i = 0; i < R; i++) {
+        CK(hipEventRecord(a));
+        launch();
+        CK(hipEventRecord(b));
+        CK(hipEventSynchronize(b));
+        float ms;
+        CK(hipEventElapsedTime(&ms, a, b));
+        best = ms < best ? ms : best;
+        sum += ms;
+    }
+    printf("%-44s mean %.4f ms (%.2f TB/s)   best %.4f ms (%.2f TB/s)\n", name, sum / R, bytes / (sum / R) / 1e9, best, bytes / best / 1e9);
+}
+
+int main(int argc, char **argv)
+{
+    const size_t bytes = (size_t)2 << 30;      // 2 GiB in, 2 GiB out: the FIR headline's buffers
+    void *in, *out;
+    CK(hipMalloc(&in, bytes));
+    CK(hipMalloc(&out, bytes));
+    CK(hipMemset(in, 1, bytes));
+    CK(hipMemset(out, 0, bytes));
+    const int grids[] = {2048, 8192, 65536};
+    for (int g : grids) {
+        printf("-- grid %d x 256 threads\n", g);
+        const size_t n16 = bytes / 16, n8 = bytes / 8;
+        timeit("read  16 B lanes, nt, 4 in flight", (double)bytes, [&] { hipLaunchKernelGGL((k_read<v4f, true, 4>), dim3(g), dim3(256), 0, 0, (const v4f *)in, (v4f *)out, n16); });
+        timeit("read   8 B lanes, nt, 8 in flight", (double)bytes, [&] { hipLaunchKernelGGL((k_read<v2f, true, 8>), dim3(g), dim3(256), 0, 0, (const v2f *)in, (v2f *)out, n8); });
+        timeit("write 16 B lanes, nt", (double)bytes, [&] { hipLaunchKernelGGL((k_write<v4f, true, 4>), dim3(g), dim3(256), 0, 0, (v4f *)out, n16); });
+        timeit("write  8 B lanes, nt", (double)bytes, [&] { hipLaunchKernelGGL((k_write<v2f, true, 8>), dim3(g), dim3(256), 0, 0, (v2f *)out, n8); });
+        timeit("write 16 B lanes, plain", (double)bytes, [&] { hipLaunchKernelGGL((k_write<v4f, false, 4>), dim3(g), dim3(256), 0, 0, (v4f *)out, n16); });
+        timeit("copy  16 B lanes, nt load + nt store", 2.0 * bytes, [&] { hipLaunchKernelGGL((k_copy<v4f, true, true, 4>), dim3(g), dim3(256), 0, 0, (const v4f *)in, (v4f *)out, n16); });
+        timeit("copy  16 B lanes, plain", 2.0 * bytes, [&] { hipLaunchKernelGGL((k_copy<v4f, false, false, 4>), dim3(g), dim3(256), 0, 0, (const v4f *)in, (v4f *)out, n16); });
+        timeit("copy  16 B lanes, nt load + plain store", 2.0 * bytes, [&] { hipLaunchKernelGGL((k_copy<v4f, true, false, 4>), dim3(g), dim3(256), 0, 0, (const v4f *)in, (v4f *)out, n16); });
+        timeit("copy   8 B lanes, nt load + nt store, 16 deep", 2.0 * bytes, [&] { hipLaunchKernelGGL((k_copy<v2f, true, true, 16>), dim3(g), dim3(256), 0, 0, (const v2f *)in, (v2f *)out, n8); });
+    }
+    return 0;
+}

@@ -13,6 +13,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsfe_dsp.so")
+# diagnostic flavour (-DSFE_DIAG): A/B kernel variants, bare access-pattern kernels, load/store
+# suppression switches, all behind environment variables.  Used by scripts/ only (ab_fir.py,
+# ablate.py); never loaded by simplefe_amd.lib, tests or bench.py, and not built by default.
+LIB_DIAG = os.path.join(HERE, "libsfe_dsp_diag.so")
 ARCH = "gfx950"
 # bit-exact restatements of the reference arithmetic: no implicit FMA contraction
 EXACT_SOURCES = ("polyphase.hip", "util.hip")
@@ -27,19 +31,22 @@ def _deps():
         os.path.join(os.path.dirname(HERE), "include", "*.h"))
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def needs_build(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(p) > t for p in _deps())
 
 
-def build_lib(force=False, verbose=False, extra=()):
-    if not force and not needs_build():
+def build_lib(force=False, verbose=False, extra=(), diag=False):
+    LIB = LIB_DIAG if diag else globals()["LIB"]
+    if diag:
+        extra = (*extra, "-DSFE_DIAG")
+    if not force and not needs_build(LIB):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
-    odir = os.path.join(HERE, "build")
+    odir = os.path.join(HERE, "build_diag" if diag else "build")
     os.makedirs(odir, exist_ok=True)
     procs = []
     for src in sources():
@@ -67,5 +74,4 @@ def build_lib(force=False, verbose=False, extra=()):
 
 
 if __name__ == "__main__":
-    build_lib(force="--force" in sys.argv, verbose=True)
-    print(LIB)
+    print(build_lib(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv))

@@ -56,6 +56,13 @@ struct DeviceGuard {
         return SFE_EHIP;                                     \
     }
 
+// [a, a + an) and [b, b + bn) share a byte
+static bool ranges_overlap(const void *a, size_t an, const void *b, size_t bn)
+{
+    const uintptr_t pa = reinterpret_cast<uintptr_t>(a), pb = reinterpret_cast<uintptr_t>(b);
+    return an && bn && pa < pb + bn && pb < pa + an;
+}
+
 static int use_device(int device)
 {
     int n = 0;
@@ -157,6 +164,7 @@ static const PolyTiledPlan *get_tiled_plan(PlanCache &cache, const std::vector<f
     hipError_t e = hipMalloc(&pl.d_G, f.G.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(pl.d_G, f.G.data(), f.G.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
+        if (pl.d_G) (void)hipFree(pl.d_G);
         *rc = hip_fail(e, "tiled plan upload");
         return nullptr;
     }
@@ -178,8 +186,9 @@ struct FftPlanCache {
 };
 
 // nullptr when the shape is not worth (or not instantiated for) the transform-domain kernel
+// fft_mode: 0 = choose by the calibrated rule, 1 = always when instantiated, -1 = never
 static const PolyFftPlan *get_fft_plan(FftPlanCache &cache, const std::vector<float> &taps_pm, int U, int plen,
-                                       int step, long long pos0, int *rc)
+                                       int step, long long pos0, int fft_mode, int *rc)
 {
     *rc = SFE_OK;
     auto key = std::make_pair(step, pos0);
@@ -204,9 +213,8 @@ static const PolyFftPlan *get_fft_plan(FftPlanCache &cache, const std::vector<fl
     const int Lp2 = ((f.Lp + 2 * f.SP - 1) / (2 * f.SP)) * (2 * f.SP);
     const bool tiled_ok = poly_tiled_supported(f.SP, f.UP, Lp2);
     const double threshold = 230.0 * 231.0 / (V > 0 ? V : 1) * (f.UP >= 4 ? 1.4 : 1.0);
-    const char *env = getenv("SFE_RS_FFT");
-    const bool forced = env && env[0] == '1';
-    if (!pl.R || pl.Li > 192 || (env && env[0] == '0') || (!forced && tiled_ok && direct_flops < threshold)) {
+    const bool forced = fft_mode > 0;
+    if (!pl.R || pl.Li > 192 || fft_mode < 0 || (!forced && tiled_ok && direct_flops < threshold)) {
         cache.plans[key] = pl;
         return nullptr;
     }
@@ -242,6 +250,8 @@ static const PolyFftPlan *get_fft_plan(FftPlanCache &cache, const std::vector<fl
     if (e == hipSuccess) e = hipMemcpy(pl.d_H, H.data(), H.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(pl.d_tw, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
+        if (pl.d_H) (void)hipFree(pl.d_H);
+        if (pl.d_tw) (void)hipFree(pl.d_tw);
         *rc = hip_fail(e, "transform-domain plan upload");
         return nullptr;
     }
@@ -316,6 +326,7 @@ static const PolyMfmaPlan *get_mfma_plan(MfmaCache &cache, const std::vector<flo
     hipError_t e = hipMalloc(&pl.d_A, Af.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(pl.d_A, Af.data(), Af.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
+        if (pl.d_A) (void)hipFree(pl.d_A);
         *rc = hip_fail(e, "mfma plan upload");
         return nullptr;
     }
@@ -516,6 +527,8 @@ struct Rs {
     uint32_t magic = 0x52533031u;   // 'RS01'
     int U = 1, n_taps = 0, plen = 0, blksize = 0, data_complex = 0, n_channels = 1;
     int device = 0, mode = SFE_RS_RESAMPLE, exact_stream = 0, in_u8 = 0;
+    int fft_mode = 0;                      // SFE_RS_FFT at create: 1 force the transform-domain kernel, -1 never
+    int use_mfma = 0;                      // SFE_RS_MFMA=1 at create: the matrix-pipe form (measured slower; opt-in)
     int hl = 0;
     float *d_taps = nullptr;               // [U][plen] phase-major
     std::vector<float> h_taps_pm;          // host copy of the same (tiled plans)
@@ -689,10 +702,20 @@ struct Timer {
 int sfe_dsp_timer_create(sfe_timer_t *t)
 {
     if (!t) return SFE_EINVAL;
+    *t = nullptr;
     Timer *x = new (std::nothrow) Timer;
     if (!x) return SFE_ENOMEM;
-    SFE_HIP(hipEventCreate(&x->a));
-    SFE_HIP(hipEventCreate(&x->b));
+    hipError_t e = hipEventCreate(&x->a);
+    if (e != hipSuccess) {
+        delete x;
+        return hip_fail(e, "hipEventCreate");
+    }
+    e = hipEventCreate(&x->b);
+    if (e != hipSuccess) {
+        (void)hipEventDestroy(x->a);
+        delete x;
+        return hip_fail(e, "hipEventCreate");
+    }
     *t = x;
     return SFE_OK;
 }
@@ -835,17 +858,30 @@ int sfe_dsp_fir_process_stream(sfe_fir_t h, const void *d_in, void *d_out, size_
         set_error("fir_process_stream: null handle or buffer");
         return SFE_EINVAL;
     }
-    if (d_in == d_out) {
-        set_error("fir_process_stream: in-place operation is not supported");
-        return SFE_EINVAL;
-    }
     if (f->n_channels > 1 && (in_stride < n || out_stride < n)) {
         set_error("fir_process_stream: channel stride smaller than n");
         return SFE_EINVAL;
     }
-    if ((reinterpret_cast<uintptr_t>(d_out) & 7) || (reinterpret_cast<uintptr_t>(d_in) & (f->in_u8 ? (f->data_complex ? 1 : 0) : 7))) {
-        set_error("fir_process_stream: buffers must be 8-byte aligned (u8 input: 2-byte for (I,Q) pairs, none for real)");
+    // bytes per element as the kernels address them
+    const size_t isz = f->in_u8 ? (f->data_complex ? 2 : 1) : (f->data_complex ? 8 : 4);
+    const size_t osz = f->out_complex ? 8 : 4;
+    if ((reinterpret_cast<uintptr_t>(d_in) & (isz - 1)) ||
+        (reinterpret_cast<uintptr_t>(d_out) & (f->out_tx10 ? 0 : osz - 1))) {
+        set_error("fir_process_stream: buffers must be aligned to their element (cf32 8 B, f32 4 B, u8 (I,Q) pairs 2 B; 10-bit output: none)");
         return SFE_EINVAL;
+    }
+    if (f->out_tx10 && f->n_channels > 1 && ((out_stride * (f->out_complex ? 2 : 1)) & 3)) {
+        set_error("fir_process_stream: 10-bit output packs 4 floats per group: out_stride must keep channels on group boundaries");
+        return SFE_EINVAL;
+    }
+    {
+        const size_t in_b = ((size_t)(f->n_channels - 1) * in_stride + n) * isz;
+        const size_t out_b = f->out_tx10 ? (((size_t)(f->n_channels - 1) * out_stride + n) * (f->out_complex ? 2 : 1) / 4 + 1) * 5
+                                         : ((size_t)(f->n_channels - 1) * out_stride + n) * osz;
+        if (ranges_overlap(d_in, in_b, d_out, out_b)) {
+            set_error("fir_process_stream: input and output ranges overlap (in-place operation is not supported)");
+            return SFE_EINVAL;
+        }
     }
     SFE_ON_DEVICE(f->device);
     return fir_run(f, d_in, d_out, n, in_stride, out_stride, (hipStream_t)stream);
@@ -979,6 +1015,9 @@ int sfe_dsp_rs_create(const float *taps, int n_taps, int upsample, int blksize, 
     r->n_channels = n_channels;
     r->device = device;
     r->mode = mode;
+    // environment switches are read ONCE, here: never on the per-call path
+    if (const char *e = getenv("SFE_RS_FFT")) r->fft_mode = e[0] == '1' ? 1 : (e[0] == '0' ? -1 : 0);
+    if (const char *e = getenv("SFE_RS_MFMA")) r->use_mfma = e[0] == '1';
     // decimate appends a zero tap when n_taps is even (decimate.cxx:42-51); resample pads the
     // last phase with zeros (resample.cxx:43,55-64).  Both are "ceil to a whole phase row".
     const int eff = (mode == SFE_RS_DECIMATE && (n_taps % 2 == 0)) ? n_taps + 1 : n_taps;
@@ -1104,9 +1143,28 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         return SFE_EINVAL;
     }
     if (n_in == 0) return SFE_OK;
-    if (!d_in || !d_out || d_in == d_out) {
-        set_error("rs_process_stream: null or aliased buffers");
+    if (!d_in || !d_out) {
+        set_error("rs_process_stream: null buffer");
         return SFE_EINVAL;
+    }
+    if (r->n_channels > 1 && (in_stride < n_in || out_stride < out_cap)) {
+        // out_cap outputs per channel may be written: a smaller stride would let channels overwrite each other
+        set_error("rs_process_stream: channel stride smaller than the channel (in_stride >= n_in, out_stride >= out_cap)");
+        return SFE_EINVAL;
+    }
+    {
+        const size_t isz = r->in_u8 ? (r->data_complex ? 2 : 1) : (size_t)r->esz();
+        const size_t osz = (size_t)r->esz();
+        if ((reinterpret_cast<uintptr_t>(d_in) & (isz - 1)) || (reinterpret_cast<uintptr_t>(d_out) & (osz - 1))) {
+            set_error("rs_process_stream: buffers must be aligned to their element (cf32 8 B, f32 4 B, u8 (I,Q) pairs 2 B)");
+            return SFE_EINVAL;
+        }
+        const size_t in_b = ((size_t)(r->n_channels - 1) * in_stride + n_in) * isz;
+        const size_t out_b = ((size_t)(r->n_channels - 1) * out_stride + out_cap) * osz;
+        if (ranges_overlap(d_in, in_b, d_out, out_b)) {
+            set_error("rs_process_stream: input and output ranges overlap");
+            return SFE_EINVAL;
+        }
     }
     SFE_ON_DEVICE(r->device);
     hipStream_t s = (hipStream_t)stream;
@@ -1143,17 +1201,14 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         // matrix-pipe form (fused numerics, cf32): opt-in with SFE_RS_MFMA=1.  Measured slower
         // than the VALU kernel on the one shape where its tap matrix is dense (polyphase.hip).
         const PolyMfmaPlan *mp = nullptr;
-        {
-            const char *e = getenv("SFE_RS_MFMA");
-            if (e && e[0] == '1' && !r->exact_stream && r->data_complex && !r->in_u8) {
-                mp = get_mfma_plan(r->mfma_plans, r->h_taps_pm, r->U, r->plen, (int)S, pos0, &rc);
-                if (rc != SFE_OK) return rc;
-            }
+        if (r->use_mfma && !r->exact_stream && r->data_complex && !r->in_u8) {
+            mp = get_mfma_plan(r->mfma_plans, r->h_taps_pm, r->U, r->plen, (int)S, pos0, &rc);
+            if (rc != SFE_OK) return rc;
         }
         // transform-domain form (fused numerics, cf32): long filters on streams long enough to fill the chip
         const PolyFftPlan *fp = nullptr;
         if (!mp && !r->exact_stream && K >= 4096) {
-            fp = get_fft_plan(r->fft_plans, r->h_taps_pm, r->U, r->plen, (int)S, pos0, &rc);
+            fp = get_fft_plan(r->fft_plans, r->h_taps_pm, r->U, r->plen, (int)S, pos0, r->fft_mode, &rc);
             if (rc != SFE_OK) return rc;
         }
         const PolyTiledPlan *pl = (mp || fp) ? nullptr : get_tiled_plan(r->plans, r->h_taps_pm, r->U, r->plen, (int)S, pos0, &rc);

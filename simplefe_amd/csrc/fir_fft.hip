@@ -18,9 +18,14 @@
 // Global traffic is perfectly coalesced in both directions (lane == consecutive sample,
 // register == row of 256); the first hl/256 rows of the result are the overlap-save discard.
 // LDS rows are padded (272 / 17 complex) so every ds_read_b64/ds_write_b64 is conflict-free.
-// Twiddle bases live in registers for the life of the (persistent) workgroup, which walks
-// transforms blockIdx.x, +gridDim.x, ...; the taps' spectrum (32 KiB, L2-resident) is
-// re-read per transform.  Budget: <= 128 VGPRs and 34 KiB LDS -> 4 workgroups per CU.
+// Twiddle bases AND this thread's 16 bins of the taps' spectrum H/N (HREG, 32 VGPRs) live in
+// registers for the life of the (persistent) workgroup, which walks transforms blockIdx.x,
+// +gridDim.x, ...  Budget: <= 128 VGPRs and 34 KiB LDS -> 4 workgroups per CU.
+//
+// Build flavours: the product library (libsfe_dsp.so) contains only the kernels the C ABI can
+// reach and reads no environment variable.  -DSFE_DIAG (libsfe_dsp_diag.so, simplefe_amd/build.py
+// build_lib(diag=True); used by scripts/ only) adds the A/B variants, the bare access-pattern
+// kernels and the load/store suppression switches behind SFE_FIR_VARIANT / SFE_FIR_DIAG.
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -81,10 +86,21 @@ __device__ __forceinline__ void store_group(unsigned char *d, unsigned u0, unsig
 // OUT_TX10 (real streams with PAIR, or complex in and out): the output is written in the device's
 // transmit wire format, 10-bit offset binary, 4 floats (4 real or 2 complex samples) in 5 bytes -- ((short)(x*511)+512)&0x3FF, packed as
 // gr-simplefe/lib/sink_f_impl.cc:117-143 / examples/bpsk/bpsk.cxx:76-101 do on the host.
+// DMA (complex float32 input, 16-byte aligned channels): an interior transform's 32 KiB of input are
+// requested by LDS-DMA (global_load_lds_dwordx4: 16-byte lanes, no VGPR destination) straight into
+// the exchange buffer's padded row layout, and they are requested EARLY -- as soon as the previous
+// transform's last LDS reads are done, i.e. before its final DFT16 and its 15 rows of stores -- so
+// part of the HBM latency runs under that work without costing a register (the register prefetch
+// variant lost a resident workgroup to its 32 extra VGPRs).  F1 then reads its column from LDS.
+// Edge transforms (history in front, ragged end) keep the guarded register loads.
 template <bool IN_C, bool OUT_C, int WAVES, bool PREFETCH, bool SWZ, bool HREG = false, bool IN_U8 = false, bool PAIR = false,
-          bool OUT_TX10 = false>
+          bool OUT_TX10 = false, bool DMA = false, int DIAG = 0>
 __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 {
+    // DIAG (instantiated under -DSFE_DIAG only, scripts/ablate.py): bit 0 = input loads replaced by
+    // constants, bit 1 = output stores folded into one never-taken store -- compile-time, so the
+    // product kernel's instruction stream and register allocation are untouched.
+    static_assert(!DMA || (IN_C && !IN_U8 && !PAIR && !SWZ && !PREFETCH), "LDS-DMA input: complex float32, padded layout");
     __shared__ v2f lds[FFT_ROWS * LDS_K2_STRIDE];
     const unsigned t = threadIdx.x;   // unsigned: lets loads/stores use SGPR base + 32-bit VGPR offset
     const int ch = blockIdx.y;
@@ -191,6 +207,13 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             return;
         }
         const long long base = blk * a.advance - a.hl;   // stream index of transform element 0
+        if constexpr (DIAG & 1) {       // ablation: no input loads (values that keep the arithmetic alive)
+            unsigned u = t + ((unsigned)blk << 12);
+            asm volatile("" : "+v"(u));        // opaque per iteration: nothing of this is hoisted out of the loop
+#pragma unroll
+            for (int r = 0; r < 16; r++) x[r] = (v2f){__builtin_bit_cast(float, 0x3f000000u | ((u + 256u * r) & 0x7fffffu)), 0.25f};
+            return;
+        }
         if constexpr (IN_U8 && IN_C && !PREFETCH) {
             // u8 wire format, interior transform, 16-byte-aligned stream: the transform's 8 KiB are
             // requested as 16-byte lanes (two per thread instead of sixteen 2-byte ones), parked raw
@@ -228,14 +251,51 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         }
     };
 
+    // LDS-DMA of one interior transform: wave w requests rows 4w..4w+3 as eight 1-KiB pieces (half a
+    // row of 128 samples each: 64 lanes x 16 bytes), piece (row, half) landing at the padded cell
+    // 272*row + 128*half -- the [n2][t] cells F1 reads.  M0 = the piece's LDS byte address.
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) v2f *)lds;
+    const unsigned wv = __builtin_amdgcn_readfirstlane(t >> 6), lane16 = (t & 63u) * 16u;
+    auto interior = [&](long long blk) -> bool {
+        if constexpr (DIAG & 1) return false;
+        const long long base = blk * a.advance - a.hl;
+        return base >= 0 && base + FFT_N <= a.n;
+    };
+    auto dma_rows = [&](long long blk) {
+        const char *g = in_c + (blk * a.advance - a.hl) * 8;      // uniform
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            const unsigned row = 4u * wv + (p >> 1), half = p & 1;
+            const unsigned dst = lds_base + (row * LDS_K2_STRIDE + half * 128u) * 8u;
+            const unsigned off = (row * 256u + half * 128u) * 8u + lane16;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(off), "s"(g), "s"(dst) : "memory");
+        }
+    };
+
     // Software pipeline: the rows of transform i+1 are requested after the spectrum stage of
     // transform i (where register pressure peaks) and land while its two inverse stages and
     // its stores run; F1 of the next iteration consumes them.
     v2f nx[16];
     if (PREFETCH && (long long)blockIdx.x < a.nblk) load_rows(nx, blockIdx.x);
+    bool landed = false;         // DMA: this transform's rows were requested by the previous iteration
+    bool counted = false;        // ... and exactly 15 stores were issued after them (vmcnt(15) suffices)
+    if (DMA && (long long)blockIdx.x < a.nblk && interior(blockIdx.x)) {
+        dma_rows(blockIdx.x);
+        landed = true;
+    }
     for (long long blk = blockIdx.x; blk < a.nblk; blk += gridDim.x) {
         v2f v[16];
-        if (!PREFETCH) load_rows(nx, blk);
+        if (DMA && landed) {
+            // the DMA pieces are older than the previous transform's stores: waiting for all but the
+            // 15 youngest vector-memory operations retires them and leaves the stores in flight
+            if (counted) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();       // every wave's pieces have landed
+#pragma unroll
+            for (int r = 0; r < 16; r++) nx[r] = lds[base_a + r * LDS_K2_STRIDE];
+        } else if (!PREFETCH) load_rows(nx, blk);
         // ---- F1: over n2, twiddle W_4096^(t k2), scatter to [k2][t]
         dft16<-1>(nx);
 #pragma unroll
@@ -309,9 +369,20 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             else if (r & 3) x = cmul_conj(x, p1[r & 3]);
             v[r] = x;
         }
+        if constexpr (DMA) {
+            // all I3 reads done -> the buffer is free: request the next transform's rows NOW, under
+            // this transform's last DFT16 and its stores
+            lds_barrier();
+            const long long nb = blk + gridDim.x;
+            landed = nb < a.nblk && interior(nb);
+            if (landed) dma_rows(nb);
+            counted = landed && !OUT_TX10 && row0 == 1 && blk * a.advance + a.advance <= a.n;
+            dft16<+1>(v);
+        } else {
         dft16<+1>(v);
         if (!SWZ) lds_barrier();   // LDS free for the next transform
         else __builtin_amdgcn_sched_barrier(0);
+        }
 
         if constexpr (PAIR) {
             const long long oA = 2 * blk * a.advance - a.hl, oB = oA + a.advance;
@@ -363,6 +434,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
                 }
                 continue;
             }
+            if constexpr (DIAG & 2) continue;      // ablation: no output stores (folded below)
             if (r >= row0 && (whole || orow + (long long)t < a.n)) {
                 const v2f y = v[P16(r)];
                 char *rp = out_c + orow * OSZ;               // uniform row pointer
@@ -370,10 +442,17 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
                 else __builtin_nontemporal_store(y.x, reinterpret_cast<float *>(rp) + t);
             }
         }
+        if constexpr (DIAG & 2) {   // keeps every result alive behind one store that never happens
+            v2f acc = v[0];
+#pragma unroll
+            for (int r = 1; r < 16; r++) acc += v[r];
+            if (acc.x == 1.2345e38f) reinterpret_cast<v2f *>(out_c)[t] = acc;
+        }
     }
 }
 
 
+#ifdef SFE_DIAG
 // Diagnostic only (SFE_FIR_VARIANT=c): the kernel's global access pattern with no transform --
 // each workgroup loads its 16 rows and stores rows row0..15 unchanged.  Times the memory side
 // of the FIR kernel alone (results are NOT a filter output; never used by the product path).
@@ -441,92 +520,150 @@ __global__ __launch_bounds__(256, WAVES) void fir_copy_pattern_nt_kernel(FirFftA
     }
 }
 
+// Diagnostic only (SFE_FIR_VARIANT=g): the access pattern of the LDS-DMA variant -- rows requested by
+// global_load_lds_dwordx4 into the padded layout, picked up column-wise, stored with nontemporal
+// 8-byte lanes; the next transform's request goes out before this one's stores.
+template <int WAVES>
+__global__ __launch_bounds__(256, WAVES) void fir_copy_pattern_dma_kernel(FirFftArgs a)
+{
+    __shared__ v2f lds[FFT_ROWS * LDS_K2_STRIDE];
+    const unsigned t = threadIdx.x;
+    const char *in_c = static_cast<const char *>(a.in) + (size_t)blockIdx.y * a.in_stride * 8;
+    char *out_c = static_cast<char *>(a.out) + (size_t)blockIdx.y * a.out_stride * 8;
+    const int row0 = a.hl >> 8;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) v2f *)lds;
+    const unsigned wv = __builtin_amdgcn_readfirstlane(t >> 6), lane16 = (t & 63u) * 16u;
+    auto ok = [&](long long blk) { const long long b = blk * a.advance - a.hl; return blk < a.nblk && b >= 0 && b + FFT_N <= a.n; };
+    auto dma_rows = [&](long long blk) {
+        const char *g = in_c + (blk * a.advance - a.hl) * 8;
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            const unsigned row = 4u * wv + (p >> 1), half = p & 1;
+            const unsigned dst = lds_base + (row * LDS_K2_STRIDE + half * 128u) * 8u;
+            const unsigned off = (row * 256u + half * 128u) * 8u + lane16;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(off), "s"(g), "s"(dst) : "memory");
+        }
+    };
+    long long blk = blockIdx.x;
+    while (blk < a.nblk && !ok(blk)) blk += gridDim.x;
+    if (blk < a.nblk) dma_rows(blk);
+    while (blk < a.nblk) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        v2f v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = lds[t + r * LDS_K2_STRIDE];
+        lds_barrier();
+        long long nb = blk + gridDim.x;
+        while (nb < a.nblk && !ok(nb)) nb += gridDim.x;
+        if (nb < a.nblk) dma_rows(nb);
+        const long long base = blk * a.advance - a.hl;
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            if (r >= row0) __builtin_nontemporal_store(v[r], reinterpret_cast<v2f *>(out_c + (base + 256 * r) * 8) + t);
+        blk = nb;
+    }
+}
+#endif  // SFE_DIAG
+
 }  // namespace
 
-int launch_fir_fft(const FirFftArgs &a, int in_complex, int out_complex, int in_u8, int out_tx10, int n_channels,
+int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in_u8, int out_tx10, int n_channels,
                    hipStream_t s)
 {
+    FirFftArgs a = a0;
     if (a.nblk <= 0) return SFE_OK;
     if (a.hl <= 0 || (a.hl & 255) || a.hl >= FFT_N || a.advance != FFT_N - a.hl) {
         set_error("fir_fft: bad overlap rows (hl=%d advance=%d)", a.hl, a.advance);
         return SFE_EINVAL;
     }
-    // variant: SFE_FIR_VARIANT = "<waves><p|n>" e.g. "3n" (3 waves/SIMD, no prefetch), "2p"
-    int variant;
-    {
-        const char *e = getenv("SFE_FIR_VARIANT");    // re-read per launch: cheap, allows A/B in one process
-        int w = 4, pf = 0, sw = 0, hr = 1;   // default "4n.h": 4 waves/SIMD (124 VGPRs), no prefetch, H in registers
-        if (e && e[0] >= '2' && e[0] <= '4') { w = e[0] - '0'; pf = (e[1] != 'n'); sw = (e[1] && e[2] == 's'); hr = (e[1] && e[2] && e[3] == 'h') || (e[1] && e[2] == 'h'); }
-        variant = w * 2 + pf + (sw ? 16 : 0) + (hr ? 32 : 0);
-    }
-    int wg_per_cu = 2 * ((variant & 15) >> 1);
-    if ((variant & 32) && (variant & 15) >> 1 == 2) wg_per_cu = 4;   // 2 x resident: finer tail balance (measured +2%)
-    const char *ev = getenv("SFE_FIR_VARIANT");
-    const bool copy_only = ev && (ev[0] == 'c' || ev[0] == 'd' || ev[0] == 'e');
-    if (const char *e = getenv("SFE_FIR_WG_PER_CU")) wg_per_cu = atoi(e) > 0 ? atoi(e) : wg_per_cu;
-    // persistent workgroups: fill the 256 CUs at the resident count, shared over channels
-    long long gx = a.nblk;
-    const long long cap = (256LL * wg_per_cu + n_channels - 1) / n_channels;
-    if (gx > cap) gx = cap < 1 ? 1 : cap;
-    dim3 grid((unsigned)gx, (unsigned)n_channels), block(256);
-#define SFE_LAUNCH(IC, OC)                                                                                 \
-    switch (variant) {                                                                                     \
-    case 6: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, false, false>), grid, block, 0, s, a); break; \
-    case 8: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 4, false, false>), grid, block, 0, s, a); break; \
-    case 32 + 6: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, false, false, true>), grid, block, 0, s, a); break; \
-    case 32 + 16 + 6: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, false, true, true>), grid, block, 0, s, a); break; \
-    case 32 + 7: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, true, false, true>), grid, block, 0, s, a); break; \
-    case 32 + 8: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 4, false, false, true>), grid, block, 0, s, a); break; \
-    case 32 + 16 + 8: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 4, false, true, true>), grid, block, 0, s, a); break; \
-    case 16 + 6: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, false, true>), grid, block, 0, s, a); break; \
-    case 16 + 7: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, true, true>), grid, block, 0, s, a); break;  \
-    case 16 + 8: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 4, false, true>), grid, block, 0, s, a); break; \
-    case 16 + 9: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 4, true, true>), grid, block, 0, s, a); break;  \
-    case 7: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 3, true, false>), grid, block, 0, s, a); break; \
-    default: hipLaunchKernelGGL((fir_fft4096_kernel<IC, OC, 4, false, false, true>), grid, block, 0, s, a); break; \
-    }
-    if (out_tx10 && in_complex != out_complex) {
-        set_error("fir_fft: 10-bit output is built for real->real and complex->complex streams");
-        return SFE_EINVAL;
-    }
-    if (out_tx10 && in_u8) {
-        set_error("fir_fft: u8 input together with 10-bit output is not built");
-        return SFE_EINVAL;
-    }
-    if (out_tx10 && in_complex) {
-        hipLaunchKernelGGL((fir_fft4096_kernel<true, true, 4, false, false, true, false, false, true>), grid, block, 0, s, a);
-        SFE_HIP(hipGetLastError());
-        return SFE_OK;
-    }
-    if (!in_complex && !out_complex && !copy_only && (out_tx10 || !(ev && ev[0] >= '2' && ev[0] <= '4'))) {
-        // real stream, real taps: two segments per transform (PAIR); a.nblk counts transforms
-        FirFftArgs b = a;
-        b.nblk = (a.nblk + 1) / 2;
-        long long g2 = b.nblk < gx ? b.nblk : gx;
-        dim3 grid2((unsigned)(g2 < 1 ? 1 : g2), (unsigned)n_channels);
-        if (out_tx10) {
-            hipLaunchKernelGGL((fir_fft4096_kernel<false, false, 4, false, false, true, false, true, true>), grid2, block, 0, s, b);
-        } else if (in_u8) hipLaunchKernelGGL((fir_fft4096_kernel<false, false, 4, false, false, true, true, true>), grid2, block, 0, s, b);
-        else hipLaunchKernelGGL((fir_fft4096_kernel<false, false, 4, false, false, true, false, true>), grid2, block, 0, s, b);
-    } else if (in_u8) {   // wire-format input: default kernel shape only
-        if (in_complex && out_complex) hipLaunchKernelGGL((fir_fft4096_kernel<true, true, 4, false, false, true, true>), grid, block, 0, s, a);
-        else if (!in_complex && !out_complex) hipLaunchKernelGGL((fir_fft4096_kernel<false, false, 4, false, false, true, true>), grid, block, 0, s, a);
-        else {
-            set_error("fir_fft: u8 input is supported for real->real and complex->complex");
-            return SFE_EINVAL;
-        }
-    } else if (copy_only && in_complex && out_complex) {
-        if (ev[0] == 'd') hipLaunchKernelGGL((fir_copy_pattern16_kernel<4>), grid, block, 0, s, a);
-        else if (ev[0] == 'e') hipLaunchKernelGGL((fir_copy_pattern_nt_kernel<4>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((fir_copy_pattern_kernel<4>), grid, block, 0, s, a);
-    } else if (in_complex && out_complex) { SFE_LAUNCH(true, true) }
-    else if (!in_complex && out_complex) { SFE_LAUNCH(false, true) }
-    else if (!in_complex && !out_complex) { SFE_LAUNCH(false, false) }
-    else {
+    if (in_complex && !out_complex) {
         set_error("fir_fft: complex input with real output is not a defined combination");
         return SFE_EINVAL;
     }
-#undef SFE_LAUNCH
+    if ((out_tx10 || in_u8) && in_complex != out_complex) {
+        set_error("fir_fft: wire-format input/output is built for real->real and complex->complex streams");
+        return SFE_EINVAL;
+    }
+    // persistent workgroups: 2 x the resident count (4 per CU at 124 VGPRs / 34 KiB LDS; the finer
+    // tail balance measured +2 %), shared over the channels
+    int wg_per_cu = 8;
+    const bool pair = !in_complex && !out_complex;     // real stream, real taps: two segments per transform
+    // LDS-DMA moves 16-byte lanes: every channel's first sample must sit on a 16-byte boundary
+    const bool dma_ok = (reinterpret_cast<uintptr_t>(a.in) & 15u) == 0 && (n_channels == 1 || (a.in_stride & 1) == 0);
+#ifdef SFE_DIAG
+    // SFE_FIR_VARIANT = "<waves 2-4><p|n>[s][h]" | "c" | "d" | "e",  SFE_FIR_DIAG = bit 0 no loads, bit 1 no stores,
+    // SFE_FIR_WG_PER_CU: read per launch so scripts/ab_fir.py can interleave variants in one process
+    const char *ev = getenv("SFE_FIR_VARIANT");
+    const int diag = getenv("SFE_FIR_DIAG") ? atoi(getenv("SFE_FIR_DIAG")) & 3 : 0;
+    if (const char *e = getenv("SFE_FIR_WG_PER_CU")) wg_per_cu = atoi(e) > 0 ? atoi(e) : wg_per_cu;
+#endif
+    long long nb = pair ? (a.nblk + 1) / 2 : a.nblk;
+    a.nblk = nb;
+    long long gx = nb;
+    const long long cap = (256LL * wg_per_cu + n_channels - 1) / n_channels;
+    if (gx > cap) gx = cap < 1 ? 1 : cap;
+    const dim3 grid((unsigned)gx, (unsigned)n_channels), block(256);
+#define SFE_K(...) hipLaunchKernelGGL((fir_fft4096_kernel<__VA_ARGS__>), grid, block, 0, s, a)
+#ifdef SFE_DIAG
+    if (ev && in_complex && out_complex && !in_u8 && !out_tx10) {
+        bool done = true;
+        if (ev[0] == 'c') hipLaunchKernelGGL((fir_copy_pattern_kernel<4>), grid, block, 0, s, a);
+        else if (ev[0] == 'd') hipLaunchKernelGGL((fir_copy_pattern16_kernel<4>), grid, block, 0, s, a);
+        else if (ev[0] == 'e') hipLaunchKernelGGL((fir_copy_pattern_nt_kernel<4>), grid, block, 0, s, a);
+        else if (ev[0] == 'g') hipLaunchKernelGGL((fir_copy_pattern_dma_kernel<4>), grid, block, 0, s, a);
+        else if (ev[0] == 'D') {                                                                     // LDS-DMA early request
+            if (diag == 1) SFE_K(true, true, 4, false, false, true, false, false, false, true, 1);
+            else if (diag == 2) SFE_K(true, true, 4, false, false, true, false, false, false, true, 2);
+            else if (diag == 3) SFE_K(true, true, 4, false, false, true, false, false, false, true, 3);
+            else SFE_K(true, true, 4, false, false, true, false, false, false, true);
+        } else if (ev[0] == '4' && diag) {                                                           // ablations of "4n.h"
+            if (diag == 1) SFE_K(true, true, 4, false, false, true, false, false, false, false, 1);
+            else if (diag == 2) SFE_K(true, true, 4, false, false, true, false, false, false, false, 2);
+            else SFE_K(true, true, 4, false, false, true, false, false, false, false, 3);
+        }
+        else if (ev[0] >= '2' && ev[0] <= '4') {
+            const int w = ev[0] - '0', pf = ev[1] == 'p', sw = ev[1] && ev[2] == 's';
+            const int hr = (ev[1] && ev[2] == 'h') || (ev[1] && ev[2] && ev[3] == 'h');
+            switch (w * 8 + pf * 4 + sw * 2 + hr) {
+            case 3 * 8 + 0: SFE_K(true, true, 3, false, false); break;
+            case 3 * 8 + 1: SFE_K(true, true, 3, false, false, true); break;
+            case 3 * 8 + 2: SFE_K(true, true, 3, false, true); break;
+            case 3 * 8 + 3: SFE_K(true, true, 3, false, true, true); break;
+            case 3 * 8 + 4: SFE_K(true, true, 3, true, false); break;
+            case 3 * 8 + 5: SFE_K(true, true, 3, true, false, true); break;
+            case 3 * 8 + 6: SFE_K(true, true, 3, true, true); break;
+            case 4 * 8 + 0: SFE_K(true, true, 4, false, false); break;
+            case 4 * 8 + 2: SFE_K(true, true, 4, false, true); break;
+            case 4 * 8 + 3: SFE_K(true, true, 4, false, true, true); break;
+            case 4 * 8 + 6: SFE_K(true, true, 4, true, true); break;
+            default: SFE_K(true, true, 4, false, false, true); break;
+            }
+        } else done = false;
+        if (done) {
+            SFE_HIP(hipGetLastError());
+            return SFE_OK;
+        }
+    }
+#endif
+    //       IN_C   OUT_C  WAVES PREFETCH SWZ  HREG  IN_U8  PAIR   OUT_TX10
+    if (in_complex) {
+        if (in_u8 && out_tx10) SFE_K(true, true, 4, false, false, true, true, false, true);      // wire to wire
+        else if (out_tx10) SFE_K(true, true, 4, false, false, true, false, false, true);
+        else if (in_u8) SFE_K(true, true, 4, false, false, true, true);
+        else if (dma_ok) SFE_K(true, true, 4, false, false, true, false, false, false, true);      // LDS-DMA early request
+        else SFE_K(true, true, 4, false, false, true);
+    } else if (out_complex) {
+        SFE_K(false, true, 4, false, false, true);                                                // real data, complex taps
+    } else {
+        if (in_u8 && out_tx10) SFE_K(false, false, 4, false, false, true, true, true, true);
+        else if (out_tx10) SFE_K(false, false, 4, false, false, true, false, true, true);
+        else if (in_u8) SFE_K(false, false, 4, false, false, true, true, true);
+        else SFE_K(false, false, 4, false, false, true, false, true);
+    }
+#undef SFE_K
     SFE_HIP(hipGetLastError());
     return SFE_OK;
 }

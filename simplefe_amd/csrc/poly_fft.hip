@@ -50,7 +50,9 @@ static_assert(pf_swz(7) < 16, "the swizzle must stay inside a row of 16");
 // PAIR (real data): the real and imaginary parts of a transform carry two CONSECUTIVE real
 // segments of the stream (the sub-filters are real, so they stay apart): a real stream costs
 // what a complex one does per sample pair.
-template <int SP, int UP, int R, bool IN_U8, bool PAIR>
+// DIAG (instantiated under -DSFE_DIAG only, scripts/ablate.py): bit 0 = input loads replaced by
+// constants, bit 1 = output stores folded into one never-taken store, bit 2 = no spectrum stage.
+template <int SP, int UP, int R, bool IN_U8, bool PAIR, int DIAG = 0>
 __global__ __launch_bounds__(256, 4) void poly_fft256_kernel(PolyFftArgs a)
 {
     constexpr int F = R * SP, I = R * UP;
@@ -126,6 +128,13 @@ __global__ __launch_bounds__(256, 4) void poly_fft256_kernel(PolyFftArgs a)
     // the R*SP*256 staged samples of a pass, thread t: sample t + 256 i of each segment.  PAIR:
     // transform (pass*R + sg) carries real segments 2*(pass*R + sg) in .x and the next one in .y.
     auto load_pass = [&](v2f (&s)[R * SP], long long pass) {
+        if constexpr (DIAG & 1) {       // ablation: no input loads
+            unsigned u = t + ((unsigned)pass << 12);
+            asm volatile("" : "+v"(u));
+#pragma unroll
+            for (int i = 0; i < R * SP; i++) s[i] = (v2f){__builtin_bit_cast(float, 0x3f000000u | ((u + 256u * i) & 0x7fffffu)), 0.25f};
+            return;
+        }
 #pragma unroll
         for (int sg = 0; sg < R; sg++) {
             // stream index of the segment's staged sample 0 (uniform)
@@ -289,9 +298,16 @@ __global__ __launch_bounds__(256, 4) void poly_fft256_kernel(PolyFftArgs a)
                     if (limB > 0) __builtin_nontemporal_store(v[P16(0)].y, reinterpret_cast<float *>(out_c + (ko0 + (long long)a.V * UP) * ESZ));
                 }
             } else {
+                if constexpr (DIAG & 2) {       // ablation: no output stores
+                    v2f acc = v[0];
+#pragma unroll
+                    for (int k0 = 1; k0 < 16; k0++) acc += v[k0];
+                    if (acc.x == 1.2345e38f) *reinterpret_cast<v2f *>(op) = acc;
+                } else {
 #pragma unroll
                 for (int k0 = 0; k0 < 16; k0++)
                     if (xb - (unsigned)(16 * UP * k0) < span) __builtin_nontemporal_store(v[P16(k0)], reinterpret_cast<v2f *>(op - 16 * UP * 8 * k0));
+                }
                 if (l == 0 && a.ovl == 0 && lim > 0) __builtin_nontemporal_store(v[P16(0)], reinterpret_cast<v2f *>(out_c + ko0 * 8));
             }
         }
@@ -304,7 +320,7 @@ __global__ __launch_bounds__(256, 4) void poly_fft256_kernel(PolyFftArgs a)
             else if (!WIDE) load_pass(s, pass + gridDim.x);
         }
         // ---- S3: bin t of every segment of this pass
-        if (cur) {
+        if (cur && !(DIAG & 4)) {
 #pragma unroll
             for (int sg = 0; sg < R; sg++) {
                 v2f acc[UP];
@@ -323,14 +339,14 @@ __global__ __launch_bounds__(256, 4) void poly_fft256_kernel(PolyFftArgs a)
     }
 }
 
-template <int SP, int UP, int R, bool IN_U8, bool PAIR>
+template <int SP, int UP, int R, bool IN_U8, bool PAIR, int DIAG = 0>
 int launch_one(const PolyFftArgs &a, int n_channels, hipStream_t s)
 {
     static int resident = 0;
     if (!resident) {
         int dev = 0, cus = 0, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, poly_fft256_kernel<SP, UP, R, IN_U8, PAIR>, 256, 0) != hipSuccess || per_cu < 1)
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, poly_fft256_kernel<SP, UP, R, IN_U8, PAIR, DIAG>, 256, 0) != hipSuccess || per_cu < 1)
             return hip_fail(hipGetLastError(), "poly_fft occupancy");
         resident = cus * per_cu;
     }
@@ -339,7 +355,7 @@ int launch_one(const PolyFftArgs &a, int n_channels, hipStream_t s)
     long long cap = (2LL * resident + n_channels - 1) / n_channels;
     if (cap < 1) cap = 1;
     dim3 grid((unsigned)(a.n_pass < cap ? a.n_pass : cap), (unsigned)n_channels);
-    hipLaunchKernelGGL((poly_fft256_kernel<SP, UP, R, IN_U8, PAIR>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((poly_fft256_kernel<SP, UP, R, IN_U8, PAIR, DIAG>), grid, dim3(256), 0, s, a);
     hipError_t err = hipGetLastError();
     return err == hipSuccess ? SFE_OK : hip_fail(err, "poly_fft launch");
 }
@@ -362,6 +378,24 @@ int poly_fft_segments(int SP, int UP)
 int launch_poly_fft(const PolyFftPlan &plan, const PolyFftArgs &a0, int data_complex, int in_u8, int n_channels, hipStream_t s)
 {
     PolyFftArgs a = a0;
+#ifdef SFE_DIAG
+    // ablations of the headline shape (scripts/ablate.py): SFE_RS_DIAG bit 0 no loads, 1 no stores, 2 no spectrum stage
+    if (const char *e = getenv("SFE_RS_DIAG")) {
+        const int d = atoi(e) & 7;
+        if (d && plan.SP == 5 && plan.UP == 3 && data_complex && !in_u8) {
+            const long long m_count = (a.n_out + plan.UP - 1) / plan.UP, n_seg = (m_count + a.V - 1) / a.V;
+            a.n_pass = (n_seg + 1) / 2;
+            switch (d) {
+            case 1: return launch_one<5, 3, 2, false, false, 1>(a, n_channels, s);
+            case 2: return launch_one<5, 3, 2, false, false, 2>(a, n_channels, s);
+            case 3: return launch_one<5, 3, 2, false, false, 3>(a, n_channels, s);
+            case 4: return launch_one<5, 3, 2, false, false, 4>(a, n_channels, s);
+            case 7: return launch_one<5, 3, 2, false, false, 7>(a, n_channels, s);
+            default: break;
+            }
+        }
+    }
+#endif
     const int R = poly_fft_segments(plan.SP, plan.UP);
     if (!R || a.n_out <= 0) return SFE_ESTATE;
     const long long m_count = (a.n_out + plan.UP - 1) / plan.UP;

@@ -735,13 +735,17 @@ int launch_poly_mfma(const PolyMfmaArgs &a, int n_channels, hipStream_t s)
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, poly_mfma_kernel, 256, sh) != hipSuccess || per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
+#ifdef SFE_DIAG
     if (const char *e = getenv("SFE_MFMA_WG_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
+#endif
     long long gx = (tiles + 3) / 4;
     const long long cap = (256LL * per_cu + n_channels - 1) / n_channels;
     if (gx > cap) gx = cap;
     dim3 grid((unsigned)gx, (unsigned)n_channels), block(256);
+#ifdef SFE_DIAG
     if (getenv("SFE_DEBUG_OCC"))
         fprintf(stderr, "poly_mfma: lds %zu B, grid %lld, wave tiles %lld, gs %d, %d blocks/CU\n", sh, gx, tiles, b.gs, per_cu);
+#endif
     hipLaunchKernelGGL(poly_mfma_kernel, grid, block, sh, s, b);
     SFE_HIP(hipGetLastError());
     return SFE_OK;

@@ -699,3 +699,52 @@ def test_fir_tx10_output_fused_complex(api, L, orc, ctaps):
         assert len(want) == (n // 2) * 5 and np.array_equal(got, want), c
     # the half group after the last whole one stays untouched
     assert not raw[(nch - 1) * (stride // 2) * 5 + (n // 2) * 5:][:5].any()
+
+
+def _codes(b):
+    b5 = np.asarray(b).reshape(-1, 5).astype(np.int32)
+    return np.stack([((b5[:, 0] >> (2 * k)) & 3) << 8 | b5[:, 1 + k] for k in range(4)], 1)
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+def test_fir_wire_to_wire_u8_in_tx10_out(api, L, orc, cplx):
+    """The source_c -> FIR -> sink_c flowgraph in ONE launch: u8 offset-binary samples in
+    (gr-simplefe/lib/source_c_impl.cc:121-132), 10-bit packed bytes out (sink_c_impl.cc:118-144;
+    real streams: source_f_impl.cc:120-129 / sink_f_impl.cc:117-143).  Bit for bit the oracle's
+    packing of the SAME kernel's float output; against the full oracle chain
+    tx_f32_to_10bit(blkconv(rx_u8(bytes))) codes may differ by one LSB where a filtered sample
+    sits on a quantiser step (the two float32 FFTs round differently), nowhere else."""
+    taps = synth.lowpass_taps(111, 0.2)
+    n = 50000 + (2 if cplx else 0)
+    w = 2 if cplx else 1
+    b = _u8_stream(n * w, 77)
+    d_b = api.DeviceArray.from_bytes(b)
+    # float output of the u8-input kernel
+    f0 = api.Fir(taps, data_complex=cplx, algo=L.FIR_ALGO_FFT)
+    f0.set_input_format(L.FMT_U8)
+    d_f = api.DeviceArray(n * w)
+    f0.process_stream(d_b, d_f, n)
+    yf = d_f.to_numpy()
+    # wire to wire
+    f = api.Fir(taps, data_complex=cplx, algo=L.FIR_ALGO_FFT)
+    f.set_input_format(L.FMT_U8)
+    f.set_output_format(L.FMT_TX10)
+    n_bytes = (n * w // 4) * 5
+    d_o = api.DeviceArray(n_bytes // 4 + 8)
+    d_o.zero()
+    f.process_stream(d_b, d_o, n)
+    got = d_o.to_numpy().view(np.uint8)[:n_bytes]
+    assert np.array_equal(got, orc.tx_f32_to_10bit(yf[: (n * w // 4) * 4]))
+    # the whole reference chain on the CPU
+    xf = orc.rx_u8_to_cf32(b) if cplx else orc.rx_u8_to_f32(b)
+    if cplx:
+        ref = oracle_fir_cf32(orc, taps, xf)
+    else:
+        ref = orc.Blkconv(taps, 4096).stream(xf)
+    want = orc.tx_f32_to_10bit(ref[: (n * w // 4) * 4])
+    va, vb = _codes(got), _codes(want)
+    assert np.abs(va - vb).max() <= 1 and np.count_nonzero(va != vb) <= 0.002 * va.size
+    # a second call continues the stream (carried history is float32 converted from the bytes)
+    f.process_stream(d_b, d_o, n)
+    f0.process_stream(d_b, d_f, n)
+    assert np.array_equal(d_o.to_numpy().view(np.uint8)[:n_bytes], orc.tx_f32_to_10bit(d_f.to_numpy()[: (n * w // 4) * 4]))

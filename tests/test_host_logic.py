@@ -215,3 +215,17 @@ def test_bench_gpus_n_without_a_gpu_fails_loudly():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        env=env, timeout=300)
     assert r.returncode != 0 and "{" not in r.stdout
+
+
+def test_product_library_has_no_diagnostic_kernels_or_switches():
+    """VERDICT r1 / ADVICE: a product entry point must not be able to return a non-result.  The
+    bare access-pattern kernels and the variant / ablation switches exist only under -DSFE_DIAG
+    (libsfe_dsp_diag.so, scripts/ only); the product library carries neither the kernels nor the
+    environment variable names that used to select them."""
+    from simplefe_amd import lib
+    blob = open(lib.LIB_PATH, "rb").read()
+    for needle in (b"copy_pattern", b"SFE_FIR_VARIANT", b"SFE_FIR_DIAG", b"SFE_FIR_WG_PER_CU", b"SFE_RS_DIAG",
+                   b"SFE_MFMA_WG_PER_CU", b"SFE_DEBUG_OCC"):
+        assert needle not in blob, needle
+    for f in ("simplefe_amd/api.py", "simplefe_amd/lib.py", "bench.py", "__graft_entry__.py"):
+        assert "libsfe_dsp_diag" not in open(os.path.join(ROOT, f)).read(), f
