@@ -113,6 +113,16 @@ int sfe_dsp_fir_process_stream(sfe_fir_t h, const void *d_in, void *d_out, size_
  * work(noutput_items, in, out) adapter calls (include/gr_sfe/): gr-simplefe's blocks hand
  * host buffers of scheduler-chosen length (gr-simplefe/lib/source_c_impl.cc:134-153). */
 int sfe_dsp_fir_process_host(sfe_fir_t h, const void *in, void *out, size_t n);
+/* One stream cut into spans: before a span's first call, hand the handle the
+ * samples that precede the span -- d_prev[0 .. n_prev), float32 in the handle's element type, per
+ * channel at `stride` samples; n_prev >= n_taps-1 reproduces the uncut stream exactly, fewer are
+ * taken as preceded by zeros.  This is the reference's whole carried state: m_overlap is a
+ * function of exactly those n_taps-1 inputs (libdsp/blkconv.cxx:105-109).  With cuts on multiples
+ * of the transform advance (3840 for <= 257 taps) and n_prev >= the transform overlap (n_taps-1
+ * rounded up to a multiple of 256) the spans' outputs are bit-identical to the one-handle
+ * result; otherwise equal to float32 rounding.  Asynchronous on `stream`. */
+int sfe_dsp_fir_load_history(sfe_fir_t h, const void *d_prev, size_t n_prev, size_t stride,
+                             sfe_stream_t stream);
 int sfe_dsp_fir_set_algo(sfe_fir_t h, int algo);
 /* Fused receive converter: with SFE_FMT_U8 the bulk call reads the device
  * wire format directly -- u8 offset binary, one byte per real sample or an (I,Q) byte pair per
@@ -177,6 +187,16 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
 int sfe_dsp_rs_set_exact(sfe_rs_t h, int exact);
 /* As sfe_dsp_fir_set_input_format, for the integer-step bulk path (fused numerics). */
 int sfe_dsp_rs_set_input_format(sfe_rs_t h, int fmt);
+/* One stream cut into spans.  load_history: as sfe_dsp_fir_load_history (the resamplers'
+ * m_history, resample.h:49-59 / decimate.h:50-59; phase_len samples suffice).  seek: put the time
+ * state {pos, mu, leftover} (resample.h:55-59) where a reference object stands after consuming
+ * `first_sample` samples from a fresh start -- closed form, available only when fl(rate*upsample) is
+ * integer-valued (both BASELINE resampler configs); otherwise SFE_ESTATE: the float32 recurrence
+ * t += rate*U (resample.cxx:129-150) must be carried, which get_state / set_state do (a span's
+ * final state is the next span's initial one). */
+int sfe_dsp_rs_load_history(sfe_rs_t h, const void *d_prev, size_t n_prev, size_t stride,
+                            sfe_stream_t stream);
+int sfe_dsp_rs_seek(sfe_rs_t h, uint64_t first_sample, float rate);
 int sfe_dsp_rs_reset(sfe_rs_t h);
 int sfe_dsp_rs_destroy(sfe_rs_t h);
 
@@ -191,6 +211,12 @@ typedef struct {
 } sfe_rs_timestate;
 int sfe_dsp_rs_plan(sfe_rs_timestate *state, int upsample, int n_in, int out_len, float rate,
                     int32_t *rel_pos, float *mu, int cap, int *n_out);
+/* The handle's time state (m_pos, m_mu, m_is_leftover: libdsp/resample.h:55-59), read / written
+ * between calls: lets a stream be cut at ANY rate by carrying one span's final state to the next. */
+/* Host-only form of sfe_dsp_rs_seek (no handle, no GPU): the state after `first_sample` samples. */
+int sfe_dsp_rs_plan_seek(sfe_rs_timestate *state, int upsample, uint64_t first_sample, float rate);
+int sfe_dsp_rs_get_state(sfe_rs_t h, sfe_rs_timestate *state);
+int sfe_dsp_rs_set_state(sfe_rs_t h, const sfe_rs_timestate *state);
 
 /* ------------------------------------------- wire-format converters ("next" row N2)
  * RX: u8 offset-binary -> float32 (b-128)*(1/127)

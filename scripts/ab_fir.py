@@ -29,7 +29,9 @@ for r in range(rounds + 1):
     for v in variants:
         vd = v.split("+")
         os.environ["SFE_FIR_DIAG"] = vd[1] if len(vd) > 1 else "0"
-        vv = vd[0].split(":")
+        vg = vd[0].split("/")                        # X/16 = 16 ticket groups
+        os.environ["SFE_FIR_TGROUPS"] = vg[1] if len(vg) > 1 else "8"
+        vv = vg[0].split(":")
         os.environ["SFE_FIR_VARIANT"] = vv[0]
         if len(vv) > 1:
             os.environ["SFE_FIR_WG_PER_CU"] = vv[1]

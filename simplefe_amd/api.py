@@ -145,6 +145,12 @@ class Fir:
     def reset(self):
         check(self._L.sfe_dsp_fir_reset(self._h))
 
+    def load_history(self, d_prev, n_prev, stride=None, stream=None):
+        """Carried state from the n_prev samples that precede the next call's input (one stream cut
+        into spans): d_prev a DeviceArray or raw device pointer, float32 elements."""
+        p = d_prev.ptr if isinstance(d_prev, DeviceArray) else int(d_prev or 0)
+        check(self._L.sfe_dsp_fir_load_history(self._h, p, n_prev, n_prev if stride is None else stride, stream))
+
     def process_stream(self, d_in, d_out, n, in_stride=None, out_stride=None, stream=None):
         """d_in/d_out: DeviceArray or raw device pointers; n samples per channel."""
         pi = d_in.ptr if isinstance(d_in, DeviceArray) else int(d_in)
@@ -205,6 +211,23 @@ class Rs:
 
     def reset(self):
         check(self._L.sfe_dsp_rs_reset(self._h))
+
+    def load_history(self, d_prev, n_prev, stride=None, stream=None):
+        p = d_prev.ptr if isinstance(d_prev, DeviceArray) else int(d_prev or 0)
+        check(self._L.sfe_dsp_rs_load_history(self._h, p, n_prev, n_prev if stride is None else stride, stream))
+
+    def seek(self, first_sample, rate):
+        """Time state of a reference object that has consumed `first_sample` samples (integer-valued
+        steps only; raises SfeError(SFE_ESTATE) otherwise)."""
+        check(self._L.sfe_dsp_rs_seek(self._h, int(first_sample), float(rate)))
+
+    def get_state(self):
+        st = _l.TimeState()
+        check(self._L.sfe_dsp_rs_get_state(self._h, C.byref(st)))
+        return st
+
+    def set_state(self, st):
+        check(self._L.sfe_dsp_rs_set_state(self._h, C.byref(st)))
 
     def process(self, x, out_len, rate):
         """Host-pointer call == {resample,decimate}::process; returns (n_out, out_array)."""

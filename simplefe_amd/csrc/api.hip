@@ -343,6 +343,7 @@ struct Fir {
     int hl = 0;                 // carried history per channel, samples (multiple of 256)
     bool fft_ok = false;
     v2f *d_hs = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr;
+    unsigned *d_ticket = nullptr;   // work counter of the persistent FFT kernel (zero between launches)
     float *d_taps = nullptr;    // real taps for the direct kernel
     std::vector<float> h_taps;  // host copy (direct-kernel plan)
     PlanCache plans;
@@ -376,6 +377,7 @@ static void fir_free(Fir *f)
     if (f->d_hs) (void)hipFree(f->d_hs);
     if (f->d_tw1) (void)hipFree(f->d_tw1);
     if (f->d_tw2) (void)hipFree(f->d_tw2);
+    if (f->d_ticket) (void)hipFree(f->d_ticket);
     if (f->d_taps) (void)hipFree(f->d_taps);
     f->plans.clear();
     for (int i = 0; i < 2; i++)
@@ -440,6 +442,8 @@ static int fir_build_tables(Fir *f, const float *taps)
     SFE_HIP(hipMemcpy(f->d_hs, hs.data(), hs.size() * sizeof(v2f), hipMemcpyHostToDevice));
     SFE_HIP(hipMemcpy(f->d_tw1, tw1.data(), tw1.size() * sizeof(v2f), hipMemcpyHostToDevice));
     SFE_HIP(hipMemcpy(f->d_tw2, tw2.data(), tw2.size() * sizeof(v2f), hipMemcpyHostToDevice));
+    SFE_HIP(hipMalloc(&f->d_ticket, FIR_TICKET_GROUPS_MAX * 128));
+    SFE_HIP(hipMemset(f->d_ticket, 0, FIR_TICKET_GROUPS_MAX * 128));
     return SFE_OK;
 }
 
@@ -471,6 +475,8 @@ static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_st
         a.hl = f->hl;
         a.advance = FFT_N - f->hl;
         a.nblk = ((long long)n + a.advance - 1) / a.advance;
+        a.ticket = f->d_ticket;
+        a.total = 0;
         rc = launch_fir_fft(a, f->data_complex, f->out_complex, f->in_u8, f->out_tx10, f->n_channels, s);
     } else {
         if (f->taps_complex || f->in_u8 || f->out_tx10) {
@@ -922,6 +928,38 @@ int sfe_dsp_fir_process_host(sfe_fir_t h, const void *in, void *out, size_t n)
     return SFE_OK;
 }
 
+
+// Carried state from a halo: the stream is about to continue at a sample whose predecessors are
+// d_prev[0 .. n_prev) (float32, the handle's element type, per channel at `stride`) -- e.g. the
+// first call of a span when one long stream is cut across GPUs (blkconv.cxx:105-109: what the
+// reference carries in m_overlap is determined by exactly these n_taps-1 input samples).
+int sfe_dsp_fir_load_history(sfe_fir_t h, const void *d_prev, size_t n_prev, size_t stride, sfe_stream_t stream)
+{
+    Fir *f = as_fir(h);
+    if (!f || (n_prev && !d_prev)) {
+        set_error("fir_load_history: null handle or buffer");
+        return SFE_EINVAL;
+    }
+    if (f->n_channels > 1 && stride < n_prev) {
+        set_error("fir_load_history: channel stride smaller than n_prev");
+        return SFE_EINVAL;
+    }
+    if (reinterpret_cast<uintptr_t>(d_prev) & (f->data_complex ? 7 : 3)) {
+        set_error("fir_load_history: buffer must be aligned to its element");
+        return SFE_EINVAL;
+    }
+    SFE_ON_DEVICE(f->device);
+    hipStream_t s = (hipStream_t)stream;
+    SFE_HIP(hipMemsetAsync(f->d_hist[f->cur], 0, f->hist_bytes(), s));        // shorter halos: zeros in front
+    if (n_prev) {
+        int rc = launch_history_update(d_prev, (long long)n_prev, (long long)stride, f->d_hist[f->cur], f->d_hist[f->cur ^ 1],
+                                       f->hl, f->data_complex ? 2 : 1, f->n_channels, s, 0);
+        if (rc != SFE_OK) return rc;
+        f->cur ^= 1;
+    }
+    return SFE_OK;
+}
+
 int sfe_dsp_fir_set_input_format(sfe_fir_t h, int fmt)
 {
     Fir *f = as_fir(h);
@@ -961,6 +999,7 @@ int sfe_dsp_fir_reset(sfe_fir_t h)
     SFE_ON_DEVICE(f->device);
     SFE_HIP(hipDeviceSynchronize());
     for (int i = 0; i < 2; i++) SFE_HIP(hipMemset(f->d_hist[i], 0, f->hist_bytes()));
+    if (f->d_ticket) SFE_HIP(hipMemset(f->d_ticket, 0, FIR_TICKET_GROUPS_MAX * 128));
     return SFE_OK;
 }
 
@@ -1384,6 +1423,91 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
     if (rc != SFE_OK) return rc;
     r->cur ^= 1;
     return SFE_OK;
+}
+
+
+// ---- cutting one stream into spans -------------------------
+int sfe_dsp_rs_load_history(sfe_rs_t h, const void *d_prev, size_t n_prev, size_t stride, sfe_stream_t stream)
+{
+    Rs *r = as_rs(h);
+    if (!r || (n_prev && !d_prev)) {
+        set_error("rs_load_history: null handle or buffer");
+        return SFE_EINVAL;
+    }
+    if (r->n_channels > 1 && stride < n_prev) {
+        set_error("rs_load_history: channel stride smaller than n_prev");
+        return SFE_EINVAL;
+    }
+    if (reinterpret_cast<uintptr_t>(d_prev) & (size_t)(r->esz() - 1)) {
+        set_error("rs_load_history: buffer must be aligned to its element");
+        return SFE_EINVAL;
+    }
+    SFE_ON_DEVICE(r->device);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t hb = (size_t)r->n_channels * r->hl * r->esz();
+    SFE_HIP(hipMemsetAsync(r->d_hist[r->cur], 0, hb, s));
+    if (n_prev) {
+        int rc = launch_history_update(d_prev, (long long)n_prev, (long long)stride, r->d_hist[r->cur], r->d_hist[r->cur ^ 1],
+                                       r->hl, r->data_complex ? 2 : 1, r->n_channels, s, 0);
+        if (rc != SFE_OK) return rc;
+        r->cur ^= 1;
+    }
+    return SFE_OK;
+}
+
+int sfe_dsp_rs_get_state(sfe_rs_t h, sfe_rs_timestate *state)
+{
+    Rs *r = as_rs(h);
+    if (!r || !state) return SFE_EINVAL;
+    *state = r->ts;
+    return SFE_OK;
+}
+
+int sfe_dsp_rs_set_state(sfe_rs_t h, const sfe_rs_timestate *state)
+{
+    Rs *r = as_rs(h);
+    if (!r || !state || state->pos < -1 || !(state->mu >= 0.0f && state->mu < 1.0f)) {
+        set_error("rs_set_state: need pos >= -1 and 0 <= mu < 1");
+        return SFE_EINVAL;
+    }
+    r->ts = *state;
+    r->ts.leftover = state->leftover ? 1 : 0;
+    return SFE_OK;
+}
+
+// The time state a reference object has after consuming `first_sample` samples of a stream from a
+// fresh start, in closed form -- only when fl(rate*upsample) is integer-valued (then mu == 0 and the
+// float32 recurrence resample.cxx:129-150 is exact): output k sits at upsampled position k*S, the
+// object's m_pos is the first such position at or after first_sample*U - 1, relative to it, and a
+// position of exactly first_sample*U - 1 is the pending "leftover" output (resample.cxx:141-145).
+int sfe_dsp_rs_plan_seek(sfe_rs_timestate *state, int upsample, uint64_t first_sample, float rate)
+{
+    if (!state || upsample < 1) return SFE_EINVAL;
+    const float stepf = rate * (float)upsample;
+    if (!(stepf >= 1.0f && stepf == floorf(stepf) && stepf < 1.0e6f)) {
+        set_error("rs_seek: fl(rate*upsample) = %g is not integer-valued: the float32 time recurrence has no closed form "
+                  "(carry the state with sfe_dsp_rs_get_state / set_state instead)", (double)stepf);
+        return SFE_ESTATE;
+    }
+    const unsigned long long S = (unsigned long long)stepf, U = (unsigned long long)upsample;
+    if (first_sample == 0) {
+        *state = {0, 0.0f, 0};
+        return SFE_OK;
+    }
+    const unsigned long long edge = first_sample * U - 1;        // last upsampled position of the part before the cut
+    const unsigned long long k = (edge + S - 1) / S;             // first output at or after it
+    const long long rel = (long long)(k * S) - (long long)(first_sample * U);
+    state->leftover = rel == -1 ? 1 : 0;
+    state->pos = (int32_t)rel;
+    state->mu = 0.0f;
+    return SFE_OK;
+}
+
+int sfe_dsp_rs_seek(sfe_rs_t h, uint64_t first_sample, float rate)
+{
+    Rs *r = as_rs(h);
+    if (!r) return SFE_EINVAL;
+    return sfe_dsp_rs_plan_seek(&r->ts, r->U, first_sample, rate);
 }
 
 int sfe_dsp_rs_set_input_format(sfe_rs_t h, int fmt)

@@ -53,7 +53,13 @@ struct FirFftArgs {
     int         hl;       // history rows * 256 = FFT_N - advance
     int         advance;  // valid outputs per transform
     long long   nblk;     // transforms per channel
+    unsigned   *ticket;   // [FIR_TICKET_GROUPS_MAX][32] device counters (128 bytes apart) the persistent workgroups
+                          // draw transforms from; zero between launches
+    unsigned    total;    // set by the launcher: transforms over all channels (channel-major tickets)
+    unsigned    tgroups;  // set by the launcher: counters in use (workgroup b draws from counter b % tgroups)
 };
+constexpr int FIR_TICKET_GROUPS = 8;        // one per XCD under round-robin workgroup placement
+constexpr int FIR_TICKET_GROUPS_MAX = 64;
 // in_u8: the input stream is the device wire format, u8 offset binary (one byte per real sample,
 // an (I, Q) byte pair per complex sample); it is converted on load, (b - 128) * (1/127)
 // (gr-simplefe/lib/source_c_impl.cc:121-132).  History stays float32.

@@ -94,16 +94,26 @@ __device__ __forceinline__ void store_group(unsigned char *d, unsigned u0, unsig
 // variant lost a resident workgroup to its 32 extra VGPRs).  F1 then reads its column from LDS.
 // Edge transforms (history in front, ragged end) keep the guarded register loads.
 template <bool IN_C, bool OUT_C, int WAVES, bool PREFETCH, bool SWZ, bool HREG = false, bool IN_U8 = false, bool PAIR = false,
-          bool OUT_TX10 = false, bool DMA = false, int DIAG = 0>
+          bool OUT_TX10 = false, bool DMA = false, int DIAG = 0, bool TICKET = true>
 __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 {
+    // TICKET: the persistent workgroups do not walk a fixed stride (blockIdx.x, +gridDim.x, ...) but
+    // draw the next transform from one device-wide counter, channel-major.  Whatever the speed of
+    // individual workgroups, the transforms in flight are then always the ~1000 NEXT ones of the
+    // stream: one compact, advancing window of reads and one of writes, as a one-workgroup-per-
+    // transform grid gives (HBM moves that pattern 10 % faster than 1000 drifting fixed-stride
+    // walks: the kernel's bare access pattern 0.716 against 0.792 ms, profiles/r02) -- without
+    // re-loading the 44 twiddle / spectrum registers per transform.  The draw for transform i+1 is
+    // issued early in transform i (one lane; its latency runs under two exchange stages).
     // DIAG (instantiated under -DSFE_DIAG only, scripts/ablate.py): bit 0 = input loads replaced by
     // constants, bit 1 = output stores folded into one never-taken store -- compile-time, so the
     // product kernel's instruction stream and register allocation are untouched.
     static_assert(!DMA || (IN_C && !IN_U8 && !PAIR && !SWZ && !PREFETCH), "LDS-DMA input: complex float32, padded layout");
+    static_assert(!TICKET || !PREFETCH, "the register prefetch looks ahead by a fixed stride");
     __shared__ v2f lds[FFT_ROWS * LDS_K2_STRIDE];
+    __shared__ unsigned s_next;       // TICKET: the next transform drawn by lane 0
     const unsigned t = threadIdx.x;   // unsigned: lets loads/stores use SGPR base + 32-bit VGPR offset
-    const int ch = blockIdx.y;
+    int ch = TICKET ? 0 : blockIdx.y;
     const unsigned lo = t & 15, hi = t >> 4;
     // LDS cell of element (k2, a, n0), a = n1 or k1:
     //   padded  (SWZ=0): [k2][n1][n0] -> 272 k2 + 16 n1 + n0,  [k2][k1][n0] -> 272 k2 + 17 k1 + n0
@@ -124,10 +134,16 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
     auto fresh_c = [&]() { if (SWZ) asm volatile("" : "+v"(base_c)); };
 
     constexpr int ISZ = IN_U8 ? (IN_C ? 2 : 1) : (IN_C ? 8 : 4);   // bytes per input sample
-    const char *in_c = static_cast<const char *>(a.in) + (size_t)ch * a.in_stride * ISZ;
-    // 10-bit output: the channel's floats (2 per complex sample) in whole groups of 4 -> 5 bytes
-    char *out_c = static_cast<char *>(a.out) + (OUT_TX10 ? (size_t)ch * (a.out_stride * (OUT_C ? 2 : 1) / 4) * 5 : (size_t)ch * a.out_stride * (OUT_C ? 8 : 4));
-    const char *hist_c = static_cast<const char *>(a.hist) + (size_t)ch * a.hl * (IN_C ? 8 : 4);
+    const char *in_c, *hist_c;
+    char *out_c;
+    auto in_of = [&](int c) -> const char * { return static_cast<const char *>(a.in) + (size_t)c * a.in_stride * ISZ; };
+    auto set_channel = [&](int c) {
+        in_c = in_of(c);
+        // 10-bit output: the channel's floats (2 per complex sample) in whole groups of 4 -> 5 bytes
+        out_c = static_cast<char *>(a.out) + (OUT_TX10 ? (size_t)c * (a.out_stride * (OUT_C ? 2 : 1) / 4) * 5 : (size_t)c * a.out_stride * (OUT_C ? 8 : 4));
+        hist_c = static_cast<const char *>(a.hist) + (size_t)c * a.hl * (IN_C ? 8 : 4);
+    };
+    set_channel(ch);
 
     // Per-thread twiddle bases, resident for the whole launch.  A twiddle with exponent
     // e*(4a+b) is applied as q[a]*p[b], q[a] = W^(4 e a), p[b] = W^(e b): 12 complex registers
@@ -142,16 +158,31 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
     }
 
     const int row0 = a.hl >> 8;   // rows discarded by overlap-save
-    // state carry-over fused in (one workgroup per channel): next call's history = the last hl
-    // input samples, converted to float32 if the stream is u8
-    if (a.hist_out && blockIdx.x == 0) {
+    // state carry-over fused in (the workgroup that takes a channel's transform 0): next call's
+    // history = the last hl input samples, converted to float32 if the stream is u8
+    auto carry_history = [&]() {
         char *ho = static_cast<char *>(a.hist_out) + (size_t)ch * a.hl * (IN_C ? 8 : 4);
         for (int r = 0; r < row0; r++) {
             const v2f s = load_sample<IN_C, IN_U8>(in_c + (a.n - a.hl + 256 * r) * ISZ, t);
             if constexpr (IN_C) reinterpret_cast<v2f *>(ho)[256 * r + t] = s;
             else reinterpret_cast<float *>(ho)[256 * r + t] = s.x;
         }
-    }
+    };
+    // one draw from the launch's counter; the launch's LAST draw (every workgroup draws exactly one
+    // ticket beyond the end) puts the counter back to zero for the next launch on this handle
+    // (one address serves an atomic every ~13 ns -- 70 000 draws from ONE counter take as long as the
+    // whole launch -- so the workgroups are dealt into a.tgroups groups, group g drawing the
+    // transforms g, g + tgroups, ... from its own counter, 128 bytes apart)
+    const unsigned tg = a.tgroups, grp = blockIdx.x % tg;
+    unsigned *const my_ticket = a.ticket + 32u * grp;
+    const unsigned last_draw = (a.total > grp ? (a.total - grp + tg - 1u) / tg : 0u) + (gridDim.x - grp + tg - 1u) / tg - 1u;
+    auto draw = [&]() -> unsigned {
+        const unsigned c = __hip_atomic_fetch_add(my_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c == last_draw) __hip_atomic_store(my_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long k = (unsigned long long)c * tg + grp;
+        return k < a.total ? (unsigned)k : 0xFFFFFFFFu;
+    };
+    const unsigned nblk32 = (unsigned)a.nblk;
     v2f hreg[16];
     if (HREG) {
 #pragma unroll
@@ -261,8 +292,8 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         const long long base = blk * a.advance - a.hl;
         return base >= 0 && base + FFT_N <= a.n;
     };
-    auto dma_rows = [&](long long blk) {
-        const char *g = in_c + (blk * a.advance - a.hl) * 8;      // uniform
+    auto dma_rows = [&](const char *chan, long long blk) {
+        const char *g = chan + (blk * a.advance - a.hl) * 8;      // uniform
 #pragma unroll
         for (int p = 0; p < 8; p++) {
             const unsigned row = 4u * wv + (p >> 1), half = p & 1;
@@ -278,15 +309,27 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
     // transform i (where register pressure peaks) and land while its two inverse stages and
     // its stores run; F1 of the next iteration consumes them.
     v2f nx[16];
-    if (PREFETCH && (long long)blockIdx.x < a.nblk) load_rows(nx, blockIdx.x);
+    long long blk = blockIdx.x;
+    unsigned kt_next = 0;
+    if constexpr (TICKET) {
+        if (t == 0) s_next = draw();
+        lds_barrier();
+        const unsigned kt = __builtin_amdgcn_readfirstlane(s_next);
+        if (kt >= a.total) return;            // uniform: more workgroups than transforms
+        ch = (int)(kt / nblk32);
+        blk = kt - (unsigned)ch * nblk32;
+        set_channel(ch);
+    } else if (blk >= a.nblk) return;
+    if (PREFETCH) load_rows(nx, blk);
     bool landed = false;         // DMA: this transform's rows were requested by the previous iteration
     bool counted = false;        // ... and exactly 15 stores were issued after them (vmcnt(15) suffices)
-    if (DMA && (long long)blockIdx.x < a.nblk && interior(blockIdx.x)) {
-        dma_rows(blockIdx.x);
+    if (DMA && interior(blk)) {
+        dma_rows(in_c, blk);
         landed = true;
     }
-    for (long long blk = blockIdx.x; blk < a.nblk; blk += gridDim.x) {
+    for (;;) {
         v2f v[16];
+        if (a.hist_out && blk == 0) carry_history();
         if (DMA && landed) {
             // the DMA pieces are older than the previous transform's stores: waiting for all but the
             // 15 youngest vector-memory operations retires them and leaves the stores in flight
@@ -307,6 +350,8 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             lds[base_a + k * LDS_K2_STRIDE] = x;
         }
         lds_barrier();
+        unsigned drawn = 0;
+        if (TICKET && t == 0) drawn = draw();      // consumed two stages further down
         // ---- F2: gather n1 for (k2=hi, n0=lo)
         fresh_b();
 #pragma unroll
@@ -341,8 +386,22 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 #pragma unroll
             for (int k = 0; k < 16; k++) lds[cell_c(k)] = v[k];
         }
+        if (TICKET && t == 0) s_next = drawn;
         lds_barrier();
-        if (PREFETCH && blk + gridDim.x < a.nblk) load_rows(nx, blk + gridDim.x);   // see above
+        if (TICKET) kt_next = __builtin_amdgcn_readfirstlane(s_next);
+        // the transform after this one: (nch, nb), uniform
+        bool more;
+        int nch = ch;
+        long long nb;
+        if constexpr (TICKET) {
+            more = kt_next < a.total;
+            nch = (int)(kt_next / nblk32);
+            nb = kt_next - (unsigned)nch * nblk32;
+        } else {
+            nb = blk + gridDim.x;
+            more = nb < a.nblk;
+        }
+        if (PREFETCH && more) load_rows(nx, nb);   // see above
         // ---- I2: gather k1 for (k2=hi, n0=lo)
         fresh_b();
 #pragma unroll
@@ -373,9 +432,8 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             // all I3 reads done -> the buffer is free: request the next transform's rows NOW, under
             // this transform's last DFT16 and its stores
             lds_barrier();
-            const long long nb = blk + gridDim.x;
-            landed = nb < a.nblk && interior(nb);
-            if (landed) dma_rows(nb);
+            landed = more && interior(nb);
+            if (landed) dma_rows(in_of(nch), nb);
             counted = landed && !OUT_TX10 && row0 == 1 && blk * a.advance + a.advance <= a.n;
             dft16<+1>(v);
         } else {
@@ -412,8 +470,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
                     __builtin_nontemporal_store(y.y, reinterpret_cast<float *>(out_c + (oB + 256 * r) * 4) + t);
                 }
             }
-            continue;
-        }
+        } else {
         const long long obase = blk * a.advance - a.hl;   // uniform; + 256*row + t
         constexpr int OSZ = OUT_C ? 8 : 4;
         const bool whole = blk * a.advance + a.advance <= a.n;
@@ -447,6 +504,14 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 #pragma unroll
             for (int r = 1; r < 16; r++) acc += v[r];
             if (acc.x == 1.2345e38f) reinterpret_cast<v2f *>(out_c)[t] = acc;
+        }
+        }
+        // ---- on to the next transform (drawn two stages ago, or blockIdx.x + k gridDim.x)
+        if (!more) break;
+        blk = nb;
+        if (TICKET && nch != ch) {
+            ch = nch;
+            set_channel(ch);
         }
     }
 }
@@ -500,23 +565,60 @@ __global__ __launch_bounds__(256, WAVES) void fir_copy_pattern16_kernel(FirFftAr
     }
 }
 
-template <int WAVES>
+template <int WAVES, bool TICKET>
 __global__ __launch_bounds__(256, WAVES) void fir_copy_pattern_nt_kernel(FirFftArgs a)
 {
+    __shared__ unsigned s_next;
     const unsigned t = threadIdx.x;
-    const char *in_c = static_cast<const char *>(a.in) + (size_t)blockIdx.y * a.in_stride * 8;
-    char *out_c = static_cast<char *>(a.out) + (size_t)blockIdx.y * a.out_stride * 8;
     const int row0 = a.hl >> 8;
-    for (long long blk = blockIdx.x; blk < a.nblk; blk += gridDim.x) {
+    const unsigned nblk32 = (unsigned)a.nblk;
+    // (one address serves an atomic every ~13 ns -- 70 000 draws from ONE counter take as long as the
+    // whole launch -- so the workgroups are dealt into a.tgroups groups, group g drawing the
+    // transforms g, g + tgroups, ... from its own counter, 128 bytes apart)
+    const unsigned tg = a.tgroups, grp = blockIdx.x % tg;
+    unsigned *const my_ticket = a.ticket + 32u * grp;
+    const unsigned last_draw = (a.total > grp ? (a.total - grp + tg - 1u) / tg : 0u) + (gridDim.x - grp + tg - 1u) / tg - 1u;
+    auto draw = [&]() -> unsigned {
+        const unsigned c = __hip_atomic_fetch_add(my_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c == last_draw) __hip_atomic_store(my_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long k = (unsigned long long)c * tg + grp;
+        return k < a.total ? (unsigned)k : 0xFFFFFFFFu;
+    };
+    unsigned kt = 0;
+    long long blk = blockIdx.x;
+    int ch = TICKET ? 0 : blockIdx.y;
+    if (TICKET) {
+        if (t == 0) s_next = draw();
+        lds_barrier();
+        kt = __builtin_amdgcn_readfirstlane(s_next);
+        lds_barrier();
+    }
+    for (;;) {
+        if (TICKET) {
+            if (kt >= a.total) break;
+            ch = (int)(kt / nblk32);
+            blk = kt - (unsigned)ch * nblk32;
+        } else if (blk >= a.nblk) break;
+        const char *in_c = static_cast<const char *>(a.in) + (size_t)ch * a.in_stride * 8;
+        char *out_c = static_cast<char *>(a.out) + (size_t)ch * a.out_stride * 8;
         const long long base = blk * a.advance - a.hl;
-        if (base < 0 || base + FFT_N > a.n) continue;
-        v2f v[16];
+        unsigned drawn = 0;
+        if (TICKET && t == 0) drawn = draw();
+        if (base >= 0 && base + FFT_N <= a.n) {
+            v2f v[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++)
-            v[r] = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(in_c + (base + 256 * r) * 8) + t);
+            for (int r = 0; r < 16; r++)
+                v[r] = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(in_c + (base + 256 * r) * 8) + t);
 #pragma unroll
-        for (int r = 0; r < 16; r++)
-            if (r >= row0) __builtin_nontemporal_store(v[r], reinterpret_cast<v2f *>(out_c + (base + 256 * r) * 8) + t);
+            for (int r = 0; r < 16; r++)
+                if (r >= row0) __builtin_nontemporal_store(v[r], reinterpret_cast<v2f *>(out_c + (base + 256 * r) * 8) + t);
+        }
+        if (TICKET) {
+            if (t == 0) s_next = drawn;
+            lds_barrier();
+            kt = __builtin_amdgcn_readfirstlane(s_next);
+            lds_barrier();
+        } else blk += gridDim.x;
     }
 }
 
@@ -602,46 +704,68 @@ int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in
 #endif
     long long nb = pair ? (a.nblk + 1) / 2 : a.nblk;
     a.nblk = nb;
+    // ticketed kernels: ONE grid dimension, transforms of all channels drawn channel-major from a.ticket
+    const long long total = nb * n_channels;
+    long long gt = total < 256LL * wg_per_cu ? total : 256LL * wg_per_cu;
+    if (total + gt >= 0xFFFFFFFFLL || !a.ticket) {
+        set_error("fir_fft: %lld transforms in one launch exceed the ticket counter", total);
+        return SFE_ERANGE;
+    }
+    a.total = (unsigned)total;
+    a.tgroups = FIR_TICKET_GROUPS;
+#ifdef SFE_DIAG
+    if (const char *e = getenv("SFE_FIR_TGROUPS")) a.tgroups = atoi(e) >= 1 && atoi(e) <= FIR_TICKET_GROUPS_MAX ? atoi(e) : a.tgroups;
+#endif
+    if ((long long)a.tgroups > gt) a.tgroups = (unsigned)gt;      // every group needs a workgroup to draw for it
+    const dim3 grid((unsigned)gt), block(256);
+#define SFE_K(...) hipLaunchKernelGGL((fir_fft4096_kernel<__VA_ARGS__>), grid, block, 0, s, a)
+#ifdef SFE_DIAG
+    // fixed-stride walk (round 1): blockIdx.x, + gridDim.x, ... per channel on a 2-D grid
     long long gx = nb;
     const long long cap = (256LL * wg_per_cu + n_channels - 1) / n_channels;
     if (gx > cap) gx = cap < 1 ? 1 : cap;
-    const dim3 grid((unsigned)gx, (unsigned)n_channels), block(256);
-#define SFE_K(...) hipLaunchKernelGGL((fir_fft4096_kernel<__VA_ARGS__>), grid, block, 0, s, a)
+    const dim3 grid2((unsigned)gx, (unsigned)n_channels);
+#define SFE_K2(...) hipLaunchKernelGGL((fir_fft4096_kernel<__VA_ARGS__>), grid2, block, 0, s, a)
+#endif
 #ifdef SFE_DIAG
     if (ev && in_complex && out_complex && !in_u8 && !out_tx10) {
+        // round-1 kernels: fixed-stride walk, register loads  <waves><p|n>[s][h]
+#define SFE_STATIC(W, PF, SW, HR, DG) SFE_K2(true, true, W, PF, SW, HR, false, false, false, false, DG, false)
+        // D = LDS-DMA + fixed stride, T = tickets + register loads, X = tickets + LDS-DMA (the product kernel)
+#define SFE_NEW(DM, TK, DG) do { if (TK) SFE_K(true, true, 4, false, false, true, false, false, false, DM, DG, TK); \
+                                 else SFE_K2(true, true, 4, false, false, true, false, false, false, DM, DG, TK); } while (0)
+#define SFE_NEW_DG(DM, TK) do { if (diag == 1) SFE_NEW(DM, TK, 1); else if (diag == 2) SFE_NEW(DM, TK, 2); \
+                                else if (diag == 3) SFE_NEW(DM, TK, 3); else SFE_NEW(DM, TK, 0); } while (0)
         bool done = true;
-        if (ev[0] == 'c') hipLaunchKernelGGL((fir_copy_pattern_kernel<4>), grid, block, 0, s, a);
-        else if (ev[0] == 'd') hipLaunchKernelGGL((fir_copy_pattern16_kernel<4>), grid, block, 0, s, a);
-        else if (ev[0] == 'e') hipLaunchKernelGGL((fir_copy_pattern_nt_kernel<4>), grid, block, 0, s, a);
-        else if (ev[0] == 'g') hipLaunchKernelGGL((fir_copy_pattern_dma_kernel<4>), grid, block, 0, s, a);
-        else if (ev[0] == 'D') {                                                                     // LDS-DMA early request
-            if (diag == 1) SFE_K(true, true, 4, false, false, true, false, false, false, true, 1);
-            else if (diag == 2) SFE_K(true, true, 4, false, false, true, false, false, false, true, 2);
-            else if (diag == 3) SFE_K(true, true, 4, false, false, true, false, false, false, true, 3);
-            else SFE_K(true, true, 4, false, false, true, false, false, false, true);
-        } else if (ev[0] == '4' && diag) {                                                           // ablations of "4n.h"
-            if (diag == 1) SFE_K(true, true, 4, false, false, true, false, false, false, false, 1);
-            else if (diag == 2) SFE_K(true, true, 4, false, false, true, false, false, false, false, 2);
-            else SFE_K(true, true, 4, false, false, true, false, false, false, false, 3);
-        }
-        else if (ev[0] >= '2' && ev[0] <= '4') {
+        if (ev[0] == 'c') hipLaunchKernelGGL((fir_copy_pattern_kernel<4>), grid2, block, 0, s, a);
+        else if (ev[0] == 'd') hipLaunchKernelGGL((fir_copy_pattern16_kernel<4>), grid2, block, 0, s, a);
+        else if (ev[0] == 'e') hipLaunchKernelGGL((fir_copy_pattern_nt_kernel<4, false>), grid2, block, 0, s, a);
+        else if (ev[0] == 'E') hipLaunchKernelGGL((fir_copy_pattern_nt_kernel<4, true>), grid, block, 0, s, a);
+        else if (ev[0] == 'g') hipLaunchKernelGGL((fir_copy_pattern_dma_kernel<4>), grid2, block, 0, s, a);
+        else if (ev[0] == 'D') SFE_NEW_DG(true, false);
+        else if (ev[0] == 'T') SFE_NEW_DG(false, true);
+        else if (ev[0] == 'X') SFE_NEW_DG(true, true);
+        else if (ev[0] == '4' && diag) {                                                           // ablations of "4n.h"
+            if (diag == 1) SFE_STATIC(4, false, false, true, 1);
+            else if (diag == 2) SFE_STATIC(4, false, false, true, 2);
+            else SFE_STATIC(4, false, false, true, 3);
+        } else if (ev[0] >= '2' && ev[0] <= '4') {
             const int w = ev[0] - '0', pf = ev[1] == 'p', sw = ev[1] && ev[2] == 's';
             const int hr = (ev[1] && ev[2] == 'h') || (ev[1] && ev[2] && ev[3] == 'h');
             switch (w * 8 + pf * 4 + sw * 2 + hr) {
-            case 3 * 8 + 0: SFE_K(true, true, 3, false, false); break;
-            case 3 * 8 + 1: SFE_K(true, true, 3, false, false, true); break;
-            case 3 * 8 + 2: SFE_K(true, true, 3, false, true); break;
-            case 3 * 8 + 3: SFE_K(true, true, 3, false, true, true); break;
-            case 3 * 8 + 4: SFE_K(true, true, 3, true, false); break;
-            case 3 * 8 + 5: SFE_K(true, true, 3, true, false, true); break;
-            case 3 * 8 + 6: SFE_K(true, true, 3, true, true); break;
-            case 4 * 8 + 0: SFE_K(true, true, 4, false, false); break;
-            case 4 * 8 + 2: SFE_K(true, true, 4, false, true); break;
-            case 4 * 8 + 3: SFE_K(true, true, 4, false, true, true); break;
-            case 4 * 8 + 6: SFE_K(true, true, 4, true, true); break;
-            default: SFE_K(true, true, 4, false, false, true); break;
+            case 3 * 8 + 0: SFE_STATIC(3, false, false, false, 0); break;
+            case 3 * 8 + 1: SFE_STATIC(3, false, false, true, 0); break;
+            case 3 * 8 + 3: SFE_STATIC(3, false, true, true, 0); break;
+            case 3 * 8 + 4: SFE_STATIC(3, true, false, false, 0); break;
+            case 3 * 8 + 5: SFE_STATIC(3, true, false, true, 0); break;
+            case 4 * 8 + 0: SFE_STATIC(4, false, false, false, 0); break;
+            case 4 * 8 + 3: SFE_STATIC(4, false, true, true, 0); break;
+            default: SFE_STATIC(4, false, false, true, 0); break;
             }
         } else done = false;
+#undef SFE_STATIC
+#undef SFE_NEW
+#undef SFE_NEW_DG
         if (done) {
             SFE_HIP(hipGetLastError());
             return SFE_OK;

@@ -49,6 +49,12 @@ SIGNATURES = {
     "sfe_dsp_fir_process_stream": (i32, [vp, vp, vp, sz, sz, sz, vp]),
     "sfe_dsp_fir_process_host": (i32, [vp, vp, vp, sz]),
     "sfe_dsp_fir_set_algo": (i32, [vp, i32]),
+    "sfe_dsp_fir_load_history": (i32, [vp, vp, sz, sz, vp]),
+    "sfe_dsp_rs_load_history": (i32, [vp, vp, sz, sz, vp]),
+    "sfe_dsp_rs_seek": (i32, [vp, C.c_uint64, f32]),
+    "sfe_dsp_rs_plan_seek": (i32, [C.POINTER(TimeState), i32, C.c_uint64, f32]),
+    "sfe_dsp_rs_get_state": (i32, [vp, C.POINTER(TimeState)]),
+    "sfe_dsp_rs_set_state": (i32, [vp, C.POINTER(TimeState)]),
     "sfe_dsp_fir_set_input_format": (i32, [vp, i32]),
     "sfe_dsp_fir_set_output_format": (i32, [vp, i32]),
     "sfe_dsp_rs_set_input_format": (i32, [vp, i32]),

@@ -15,6 +15,42 @@ def channel_block(n_channels, world, rank):
     return first, base + (1 if rank < extra else 0)
 
 
+def span_block(n_samples, world, rank, quantum=1):
+    """(first, count) of the contiguous span of ONE stream that rank `rank` filters when the stream is
+    cut across `world` GPUs.  Cuts fall on multiples of `quantum` samples: with
+    quantum = the FIR transform advance (3840 for <= 257 taps) the spans' outputs are bit-identical
+    to the uncut stream's; any quantum is correct to rounding.  The last rank takes the ragged end."""
+    n, world, q = int(n_samples), int(world), max(1, int(quantum))
+    per = ((n + world - 1) // world + q - 1) // q * q
+    first = min(rank * per, n)
+    return first, max(0, min(per, n - first))
+
+
+def halo_from_left(tail, halo_len, device=None):
+    """The one data exchange a cut stream needs: every rank sends the last `halo_len` samples of its
+    span to its right neighbour (n_taps-1 samples, 2 KiB for 256 taps cf32) and receives its own
+    halo from the left; rank 0 gets zeros (stream start).  `tail`: 1-D float32 tensor holding AT
+    LEAST the span's last halo_len elements (on the GPU under RCCL, on the host under gloo).
+    Point-to-point over xGMI (RCCL send/recv), not a collective."""
+    import torch
+    import torch.distributed as dist
+    halo = torch.zeros(halo_len, dtype=tail.dtype, device=tail.device)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return halo
+    rank, world = dist.get_rank(), dist.get_world_size()
+    send = tail[-halo_len:].contiguous() if tail.numel() >= halo_len else torch.cat(
+        [torch.zeros(halo_len - tail.numel(), dtype=tail.dtype, device=tail.device), tail])
+    ops = []
+    if rank + 1 < world:
+        ops.append(dist.P2POp(dist.isend, send, rank + 1))
+    if rank > 0:
+        ops.append(dist.P2POp(dist.irecv, halo, rank - 1))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return halo
+
+
 def env_ranks():
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
             int(os.environ.get("WORLD_SIZE", "1")))

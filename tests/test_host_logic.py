@@ -229,3 +229,26 @@ def test_product_library_has_no_diagnostic_kernels_or_switches():
         assert needle not in blob, needle
     for f in ("simplefe_amd/api.py", "simplefe_amd/lib.py", "bench.py", "__graft_entry__.py"):
         assert "libsfe_dsp_diag" not in open(os.path.join(ROOT, f)).read(), f
+
+
+def test_seek_state_equals_the_replayed_recurrence():
+    """sfe_dsp_rs_plan_seek (closed form, integer-valued steps) against the literal replay of the
+    reference's float32 time law chunk by chunk (sfe_dsp_rs_plan == resample.cxx:119-150): the
+    state after n samples must be identical whatever the chunking -- including cuts that leave a
+    pending leftover output (position n*U - 1)."""
+    from simplefe_amd import api, lib
+    L = lib.load()
+    for U, S in ((3, 5), (1, 8), (4, 6), (2, 7), (1, 1), (3, 3)):
+        rate = float(np.float32(S) / np.float32(U))
+        for n in list(range(0, 40)) + [1000, 1001, 4095, 4096, 12345]:
+            st = lib.TimeState(0, 0.0, 0)
+            left = n
+            while left > 0:
+                m = min(left, 997)
+                api.rs_plan(st, U, m, m * U // S + 8, rate)
+                left -= m
+            got = lib.TimeState(7, 0.5, 1)
+            assert L.sfe_dsp_rs_plan_seek(C.byref(got), U, n, rate) == lib.SFE_OK
+            assert (got.pos, got.mu, got.leftover) == (st.pos, st.mu, st.leftover), (U, S, n)
+    st = lib.TimeState(0, 0.0, 0)
+    assert L.sfe_dsp_rs_plan_seek(C.byref(st), 4, 100, 1.77) == lib.SFE_ESTATE     # no closed form: must be carried
