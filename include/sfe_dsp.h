@@ -47,6 +47,7 @@ extern "C" {
 
 typedef void *sfe_stream_t;   /* hipStream_t */
 typedef void *sfe_fir_t;      /* opaque: one FIR stream (blkconv) */
+typedef void *sfe_pipe_t;     /* opaque: pipelined host streaming over one FIR handle */
 typedef void *sfe_rs_t;       /* opaque: one resample/decimate stream */
 typedef void *sfe_timer_t;    /* opaque: a pair of HIP events */
 
@@ -124,6 +125,24 @@ int sfe_dsp_fir_process_host(sfe_fir_t h, const void *in, void *out, size_t n);
 int sfe_dsp_fir_load_history(sfe_fir_t h, const void *d_prev, size_t n_prev, size_t stride,
                              sfe_stream_t stream);
 int sfe_dsp_fir_set_algo(sfe_fir_t h, int algo);
+/* Pipelined host streaming for scheduler-sized calls.  A GNU Radio scheduler
+ * hands a block a few thousand items per work() call (gr-simplefe/lib/sink_c_impl.cc:157-174,
+ * source_c_impl.cc:134-153); one synchronous round trip per call is launch/sync bound.  A pipe
+ * over a single-channel float32 FIR handle collects pushed items in pinned batches of
+ * `batch_items` (0 = 262144) and keeps up to four batches in flight on three streams (copy in,
+ * filter, copy out); pull hands out finished items in order.  Item k out is the filter's output
+ * for item k in: no delay is inserted, only latency.  While a pipe exists, drive its handle only
+ * through the pipe.
+ *   push  copies up to n_items in; *n_taken < n_items means every batch is in flight: pull first.
+ *   pull  copies up to max_items finished items out.  wait = 0: only what has already arrived;
+ *         1: block for the oldest batch in flight; 2: also send a partly filled batch on its way
+ *         and block for it (end of stream / drain).
+ *   pending  items pushed and not yet pulled. */
+int sfe_dsp_fir_pipe_create(sfe_fir_t fir, size_t batch_items, sfe_pipe_t *out);
+int sfe_dsp_pipe_push(sfe_pipe_t p, const void *in, size_t n_items, size_t *n_taken);
+int sfe_dsp_pipe_pull(sfe_pipe_t p, void *out, size_t max_items, int wait, size_t *n_got);
+int sfe_dsp_pipe_pending(sfe_pipe_t p, size_t *items);
+int sfe_dsp_pipe_destroy(sfe_pipe_t p);
 /* Fused receive converter: with SFE_FMT_U8 the bulk call reads the device
  * wire format directly -- u8 offset binary, one byte per real sample or an (I,Q) byte pair per
  * complex sample -- converting (b-128)*(1/127) on load exactly as fill_rx_buffer does

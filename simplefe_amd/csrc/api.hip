@@ -1566,3 +1566,254 @@ int sfe_dsp_tx_f32_to_10bit(const void *d_floats, void *d_bytes, size_t n_floats
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------ pipelined host streaming
+// A GNU Radio scheduler hands a block a few thousand items per work() call
+// (gr-simplefe/lib/sink_c_impl.cc:157-174, source_c_impl.cc:134-153); one synchronous H2D ->
+// kernel -> D2H round trip per call is launch/sync bound (27 us per 3841 samples).  The pipe
+// collects pushed items in pinned batches and keeps up to SFE_PIPE_SLOTS batches in flight on
+// three streams (copy in / filter / copy out overlap, PCIe is full duplex); pull hands out finished
+// items in order.  Sample alignment is untouched: item k out is the filter's output for item k in.
+#include <immintrin.h>
+namespace sfe {
+// Host copies into / out of the pinned batches are what bounds the pipe (the GPU side of a batch
+// is ~30 us, the two copies ~60): stream them past the cache -- the pinned side is touched next by
+// the DMA engine, not by this core.  Falls back to memcpy without AVX2 or for small / odd pieces.
+__attribute__((target("avx2"))) static void copy_stream_avx2(char *dst, const char *src, size_t n)
+{
+    while (n && (reinterpret_cast<uintptr_t>(dst) & 31u)) {
+        *dst++ = *src++;
+        n--;
+    }
+    for (; n >= 128; n -= 128, dst += 128, src += 128) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src));
+        const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + 32));
+        const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + 64));
+        const __m256i d = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + 96));
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst), a);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + 32), b);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + 64), c);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + 96), d);
+    }
+    _mm_sfence();
+    if (n) memcpy(dst, src, n);
+}
+static void copy_stream(void *dst, const void *src, size_t n)
+{
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2 && n >= 4096) copy_stream_avx2(static_cast<char *>(dst), static_cast<const char *>(src), n);
+    else memcpy(dst, src, n);
+}
+
+constexpr int PIPE_SLOTS = 4;
+struct FirPipe {
+    uint32_t magic = 0x50495031u;   // 'PIP1'
+    Fir *f = nullptr;
+    size_t batch = 0, in_e = 0, out_e = 0;
+    struct Slot {
+        char *h_in = nullptr, *h_out = nullptr;
+        void *d_in = nullptr, *d_out = nullptr;
+        size_t n = 0;               // items submitted in this slot
+        hipEvent_t ev_in = nullptr, ev_k = nullptr, ev_out = nullptr;
+        bool busy = false;          // submitted and not yet fully pulled
+    } slot[PIPE_SLOTS];
+    hipStream_t s_in = nullptr, s_k = nullptr, s_out = nullptr;
+    int head = 0;                   // slot being filled
+    size_t fill = 0;                // items in it
+    int tail = 0;                   // oldest busy slot
+    size_t out_off = 0;             // items already pulled from it
+    bool tail_ready = false;        // its ev_out has been seen complete
+};
+
+static FirPipe *as_pipe(void *h)
+{
+    FirPipe *p = static_cast<FirPipe *>(h);
+    if (p && p->magic != 0x50495031u) {
+        set_error("not a live pipe handle");
+        return nullptr;
+    }
+    return p;
+}
+
+static void pipe_free(FirPipe *p)
+{
+    if (!p) return;
+    p->magic = 0;
+    DeviceGuard g(p->f ? p->f->device : 0);
+    for (auto &sl : p->slot) {
+        if (sl.h_in) (void)hipHostFree(sl.h_in);
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+        if (sl.d_in) (void)hipFree(sl.d_in);
+        if (sl.d_out) (void)hipFree(sl.d_out);
+        if (sl.ev_in) (void)hipEventDestroy(sl.ev_in);
+        if (sl.ev_k) (void)hipEventDestroy(sl.ev_k);
+        if (sl.ev_out) (void)hipEventDestroy(sl.ev_out);
+    }
+    if (p->s_in) (void)hipStreamDestroy(p->s_in);
+    if (p->s_k) (void)hipStreamDestroy(p->s_k);
+    if (p->s_out) (void)hipStreamDestroy(p->s_out);
+    delete p;
+}
+
+static int pipe_submit(FirPipe *p)
+{
+    FirPipe::Slot &sl = p->slot[p->head];
+    sl.n = p->fill;
+    SFE_HIP(hipMemcpyAsync(sl.d_in, sl.h_in, sl.n * p->in_e, hipMemcpyHostToDevice, p->s_in));
+    SFE_HIP(hipEventRecord(sl.ev_in, p->s_in));
+    SFE_HIP(hipStreamWaitEvent(p->s_k, sl.ev_in, 0));
+    // a slot's device buffers are reused PIPE_SLOTS batches later: by then its copy-out has been
+    // waited for (the slot was pulled), so no further ordering is needed on s_k
+    int rc = fir_run(p->f, sl.d_in, sl.d_out, sl.n, sl.n, sl.n, p->s_k);
+    if (rc != SFE_OK) return rc;
+    SFE_HIP(hipEventRecord(sl.ev_k, p->s_k));
+    SFE_HIP(hipStreamWaitEvent(p->s_out, sl.ev_k, 0));
+    SFE_HIP(hipMemcpyAsync(sl.h_out, sl.d_out, sl.n * p->out_e, hipMemcpyDeviceToHost, p->s_out));
+    SFE_HIP(hipEventRecord(sl.ev_out, p->s_out));
+    sl.busy = true;
+    p->head = (p->head + 1) % PIPE_SLOTS;
+    p->fill = 0;
+    return SFE_OK;
+}
+}  // namespace sfe
+
+extern "C" {
+
+int sfe_dsp_fir_pipe_create(sfe_fir_t fir, size_t batch_items, sfe_pipe_t *out)
+{
+    if (!out) return SFE_EINVAL;
+    *out = nullptr;
+    Fir *f = as_fir(fir);
+    if (!f || f->n_channels != 1 || f->in_u8 || f->out_tx10) {
+        set_error("fir_pipe_create: needs a single-channel float32 FIR handle");
+        return SFE_EINVAL;
+    }
+    if (batch_items == 0) batch_items = (size_t)1 << 18;
+    if (batch_items < 256 || batch_items > ((size_t)1 << 26)) {
+        set_error("fir_pipe_create: batch of %zu items out of range (256 .. 2^26)", batch_items);
+        return SFE_EINVAL;
+    }
+    SFE_ON_DEVICE(f->device);
+    FirPipe *p = new (std::nothrow) FirPipe;
+    if (!p) return SFE_ENOMEM;
+    p->f = f;
+    p->batch = batch_items;
+    p->in_e = f->data_complex ? 8 : 4;
+    p->out_e = f->out_complex ? 8 : 4;
+    auto fail = [&](hipError_t e, const char *what) { int rc = hip_fail(e, what); pipe_free(p); return rc; };
+#define TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(e__, #call); } while (0)
+    TRY(hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking));
+    TRY(hipStreamCreateWithFlags(&p->s_k, hipStreamNonBlocking));
+    TRY(hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
+    for (auto &sl : p->slot) {
+        TRY(hipHostMalloc((void **)&sl.h_in, batch_items * p->in_e));
+        TRY(hipHostMalloc((void **)&sl.h_out, batch_items * p->out_e));
+        TRY(hipMalloc(&sl.d_in, batch_items * p->in_e));
+        TRY(hipMalloc(&sl.d_out, batch_items * p->out_e));
+        TRY(hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
+        TRY(hipEventCreateWithFlags(&sl.ev_k, hipEventDisableTiming));
+        TRY(hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming));
+    }
+#undef TRY
+    *out = p;
+    return SFE_OK;
+}
+
+int sfe_dsp_pipe_push(sfe_pipe_t h, const void *in, size_t n_items, size_t *n_taken)
+{
+    FirPipe *p = as_pipe(h);
+    if (!p || !n_taken || (n_items && !in)) return SFE_EINVAL;
+    *n_taken = 0;
+    SFE_ON_DEVICE(p->f->device);
+    const char *src = static_cast<const char *>(in);
+    while (n_items) {
+        FirPipe::Slot &sl = p->slot[p->head];
+        if (sl.busy) break;                                   // every slot in flight: pull first (backpressure)
+        size_t m = p->batch - p->fill;
+        if (m > n_items) m = n_items;
+        copy_stream(sl.h_in + p->fill * p->in_e, src, m * p->in_e);
+        p->fill += m;
+        src += m * p->in_e;
+        n_items -= m;
+        *n_taken += m;
+        if (p->fill == p->batch) {
+            int rc = pipe_submit(p);
+            if (rc != SFE_OK) return rc;
+        }
+    }
+    return SFE_OK;
+}
+
+int sfe_dsp_pipe_pull(sfe_pipe_t h, void *out, size_t max_items, int wait, size_t *n_got)
+{
+    FirPipe *p = as_pipe(h);
+    if (!p || !n_got || (max_items && !out)) return SFE_EINVAL;
+    *n_got = 0;
+    SFE_ON_DEVICE(p->f->device);
+    char *dst = static_cast<char *>(out);
+    bool block_now = wait != 0;          // wait == 1 blocks for the oldest batch only, wait == 2 for all of them
+    while (max_items) {
+        FirPipe::Slot &sl = p->slot[p->tail];
+        if (!sl.busy) {
+            // nothing submitted: with wait == 2 a partly filled batch is sent on its way (end of stream / drain)
+            if (wait == 2 && p->fill > 0 && p->tail == p->head) {
+                int rc = pipe_submit(p);
+                if (rc != SFE_OK) return rc;
+                continue;
+            }
+            break;
+        }
+        if (!p->tail_ready) {
+            if (block_now) {
+                SFE_HIP(hipEventSynchronize(sl.ev_out));
+                if (wait == 1) block_now = false;
+            } else {
+                hipError_t e = hipEventQuery(sl.ev_out);
+                if (e == hipErrorNotReady) break;
+                if (e != hipSuccess) return hip_fail(e, "hipEventQuery");
+            }
+            p->tail_ready = true;
+        }
+        size_t m = sl.n - p->out_off;
+        if (m > max_items) m = max_items;
+        copy_stream(dst, sl.h_out + p->out_off * p->out_e, m * p->out_e);
+        dst += m * p->out_e;
+        p->out_off += m;
+        max_items -= m;
+        *n_got += m;
+        if (p->out_off == sl.n) {
+            sl.busy = false;
+            p->tail = (p->tail + 1) % PIPE_SLOTS;
+            p->out_off = 0;
+            p->tail_ready = false;
+        }
+    }
+    return SFE_OK;
+}
+
+int sfe_dsp_pipe_pending(sfe_pipe_t h, size_t *items)
+{
+    FirPipe *p = as_pipe(h);
+    if (!p || !items) return SFE_EINVAL;
+    size_t n = p->fill;
+    for (int i = 0; i < PIPE_SLOTS; i++)
+        if (p->slot[i].busy) n += p->slot[i].n - (i == p->tail ? p->out_off : 0);
+    *items = n;
+    return SFE_OK;
+}
+
+int sfe_dsp_pipe_destroy(sfe_pipe_t h)
+{
+    FirPipe *p = as_pipe(h);
+    if (!p) return SFE_OK;
+    {
+        DeviceGuard g(p->f->device);
+        (void)hipStreamSynchronize(p->s_in);
+        (void)hipStreamSynchronize(p->s_k);
+        (void)hipStreamSynchronize(p->s_out);
+    }
+    pipe_free(p);
+    return SFE_OK;
+}
+
+}  // extern "C"

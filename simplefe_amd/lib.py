@@ -49,6 +49,11 @@ SIGNATURES = {
     "sfe_dsp_fir_process_stream": (i32, [vp, vp, vp, sz, sz, sz, vp]),
     "sfe_dsp_fir_process_host": (i32, [vp, vp, vp, sz]),
     "sfe_dsp_fir_set_algo": (i32, [vp, i32]),
+    "sfe_dsp_fir_pipe_create": (i32, [vp, sz, C.POINTER(vp)]),
+    "sfe_dsp_pipe_push": (i32, [vp, vp, sz, C.POINTER(sz)]),
+    "sfe_dsp_pipe_pull": (i32, [vp, vp, sz, i32, C.POINTER(sz)]),
+    "sfe_dsp_pipe_pending": (i32, [vp, C.POINTER(sz)]),
+    "sfe_dsp_pipe_destroy": (i32, [vp]),
     "sfe_dsp_fir_load_history": (i32, [vp, vp, sz, sz, vp]),
     "sfe_dsp_rs_load_history": (i32, [vp, vp, sz, sz, vp]),
     "sfe_dsp_rs_seek": (i32, [vp, C.c_uint64, f32]),

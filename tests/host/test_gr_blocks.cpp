@@ -1,7 +1,10 @@
 // Drives include/gr_sfe/blocks.h the way the GNU Radio scheduler drives a block: repeated
 // work()/general_work() calls with scheduler-sized item counts.  Needs a GPU to run.
-//   test_gr_blocks <fir|decimate|resample|decimate_f|resample_f> <taps.f32> <x> <y> [decim] [interp]
+//   test_gr_blocks <fir|fir_sync|fir_f|decimate|resample|decimate_f|resample_f> <taps.f32> <x> <y> [decim] [interp]
+//   test_gr_blocks rate <taps.f32> <x> <y>     4096-item calls through fir_ccf (batched) and fir_ccf_sync;
+//                                              prints "<items/s batched> <items/s sync>"; y = batched output
 // (_f: float items, otherwise gr_complex items)
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -65,6 +68,37 @@ static std::vector<float> run_resample(const std::vector<float> &taps, const std
     return y;
 }
 
+// general_work the way the scheduler calls it: whatever input is left (at most `call` items), room
+// for `call` outputs; after the input ends, calls with no input until everything has come out
+template <class Block, int W>
+static bool run_fir_batched_into(typename Block::sptr b, const std::vector<float> &x, std::vector<float> &y, const int *call_sizes, int n_sizes)
+{
+    const int n = (int)(x.size() / W);
+    int off = 0, produced = 0, si = 0;
+    while (produced < n) {
+        const int room = call_sizes[si++ % n_sizes];
+        gr_vector_int req(1, 0);
+        b->forecast(room, req);
+        int avail = n - off < room ? n - off : room;
+        if (avail < req[0]) return false;      // the block asks for input that will never come
+        gr_vector_int nin(1, avail);
+        gr_vector_const_void_star in(1, x.data() + W * (size_t)off);
+        gr_vector_void_star out(1, y.data() + W * (size_t)produced);
+        int r = b->general_work(room < n - produced ? room : n - produced, nin, in, out);
+        off += b->consumed();
+        produced += r;
+    }
+    return true;
+}
+
+template <class Block, int W>
+static std::vector<float> run_fir_batched(typename Block::sptr b, const std::vector<float> &x, const int *call_sizes, int n_sizes)
+{
+    std::vector<float> y(x.size());
+    if (!run_fir_batched_into<Block, W>(b, x, y, call_sizes, n_sizes)) y.clear();
+    return y;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 5) return 2;
@@ -73,7 +107,32 @@ int main(int argc, char **argv)
     std::vector<float> y;
     int si = 0;
     if (!strcmp(argv[1], "fir")) {
-        gr::sfe::fir_ccf::sptr b = gr::sfe::fir_ccf::make(taps);
+        y = run_fir_batched<gr::sfe::fir_ccf, 2>(gr::sfe::fir_ccf::make(taps, 8192), x, sizes, 5);
+    } else if (!strcmp(argv[1], "fir_f")) {
+        y = run_fir_batched<gr::sfe::fir_fff, 1>(gr::sfe::fir_fff::make(taps, 4096), x, sizes, 5);
+    } else if (!strcmp(argv[1], "rate")) {
+        static const int k4096[] = {4096};
+        gr::sfe::fir_ccf::sptr warm = gr::sfe::fir_ccf::make(taps);
+        run_fir_batched<gr::sfe::fir_ccf, 2>(warm, x, k4096, 1);
+        gr::sfe::fir_ccf::sptr bb = gr::sfe::fir_ccf::make(taps);     // pinned batches are allocated here, not in the timed part
+        y.assign(x.size(), 0.0f);                                        // output pages touched before timing, as for the sync run
+        auto t0 = std::chrono::steady_clock::now();
+        if (!run_fir_batched_into<gr::sfe::fir_ccf, 2>(bb, x, y, k4096, 1)) return 3;
+        const double tb = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        gr::sfe::fir_ccf_sync::sptr bs = gr::sfe::fir_ccf_sync::make(taps);
+        std::vector<float> ys(x.size(), 0.0f);
+        t0 = std::chrono::steady_clock::now();
+        for (int off = 0; off < n;) {
+            int m = 4096 < n - off ? 4096 : n - off;
+            gr_vector_const_void_star in(1, x.data() + 2 * (size_t)off);
+            gr_vector_void_star out(1, ys.data() + 2 * (size_t)off);
+            if (bs->work(m, in, out) != m) return 1;
+            off += m;
+        }
+        const double ts = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("%.6g %.6g\n", n / tb, n / ts);
+    } else if (!strcmp(argv[1], "fir_sync")) {
+        gr::sfe::fir_ccf_sync::sptr b = gr::sfe::fir_ccf_sync::make(taps);
         y.resize(x.size());
         for (int off = 0; off < n;) {
             int m = sizes[si++ % 5];
@@ -92,6 +151,7 @@ int main(int argc, char **argv)
     } else {
         y = run_resample<gr::sfe::rational_resampler_ccf, 2>(taps, x, (unsigned)atoi(argv[5]), (unsigned)atoi(argv[6]));
     }
+    if (y.empty()) return 3;
     const size_t W = (strlen(argv[1]) > 2 && !strcmp(argv[1] + strlen(argv[1]) - 2, "_f")) ? 1 : 2;
     FILE *f = fopen(argv[4], "wb");
     fwrite(y.data(), 4, y.size(), f);
