@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Interleaved A/B of the transform-domain resample kernel's variants (5/3, 381 taps, 2^28 cf32) in
+ONE process through the DIAGNOSTIC library.  Usage: ab_rs.py s t l L
+  s = fixed-stride walk (round 1)   t = passes drawn from work counters (product, single channel)
+  l = t + next pass requested after S3   L = s + late request"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from simplefe_amd import build, lib  # noqa: E402
+lib.LIB_PATH = build.build_lib(diag=True)
+from simplefe_amd import api, synth  # noqa: E402
+
+variants = sys.argv[1:] or ["s", "t"]
+rounds = int(os.environ.get("ROUNDS", "8"))
+n = 1 << 28
+x = api.DeviceArray(2 * n)
+x.fill_synth(synth.SEED)
+cap = int(n * 3 / 5) + 8
+y = api.DeviceArray(2 * cap)
+r = api.Rs(synth.taps_cfg3(), 3, 4096, mode=lib.RS_RESAMPLE, data_complex=True)
+t = api.Timer()
+res = {v: [] for v in variants}
+for k in range(rounds + 1):
+    for v in variants:
+        os.environ["SFE_RS_VARIANT"] = v
+        t.start()
+        for _ in range(5):
+            r.process_stream(x, n, y, cap, 5.0 / 3.0)
+        t.stop()
+        if k:
+            res[v].append(t.elapsed_ms() / 5)
+alg = 8.0 * n + 8.0 * (3 * n // 5)
+for v in variants:
+    a = np.array(res[v])
+    print(f"{v:4s} median {np.median(a):.4f} ms  min {a.min():.4f}  max {a.max():.4f}  -> {alg / np.median(a) / 1e6 / 80:.1f}% of 8 TB/s")

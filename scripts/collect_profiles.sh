@@ -1,20 +1,37 @@
 #!/bin/bash
 # Round profile collection on the GPU box: kernel-trace stats + separate FETCH_SIZE / WRITE_SIZE
-# passes for each bench workload.  Output under gpurun_out/prof_<tag>/; summarised into
-# profiles/ by scripts/summarise_profiles.py (run in the authoring container).
+# passes for each bench workload (counters never combined with tracing), SQ/LDS counter passes for
+# the two transform kernels, and the variant / ablation tables from the diagnostic library.
+# Output under gpurun_out/prof_<tag>_*/; summarised into profiles/ by scripts/summarise_profiles.py
+# (run in the authoring container).   usage: scripts/collect_profiles.sh [tag]
 TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp; export TMPDIR=/tmp
 for WL in fir decimate resample; do
   O=$R/gpurun_out/prof_${TAG}_${WL}
   mkdir -p $O
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --workload $WL --no-cpu > $O/kt.log 2>&1 || exit 1
-  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu > $O/fetch.log 2>&1 || exit 1
-  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu > $O/write.log 2>&1 || exit 1
-  tail -1 $O/kt.log | cut -c1-160
+  # --no-others: the headline kernel alone (the default line's other_configs legs launch the same
+  # kernel name on other shapes, which would mix into the per-name average)
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --workload $WL --no-cpu --no-others > $O/kt.log 2>&1 || exit 1
+  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu --no-others > $O/fetch.log 2>&1 || exit 1
+  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu --no-others > $O/write.log 2>&1 || exit 1
+  tail -1 $O/kt.log | cut -c1-200
 done
-# ablation / variant tables from the diagnostic library (regenerable: scripts/ablate.py, scripts/ab_fir.py)
-mkdir -p $R/gpurun_out/prof_${TAG}_tables
+# the driver's own command shape (all legs in one process)
+O=$R/gpurun_out/prof_${TAG}_default
+mkdir -p $O
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu > $O/kt.log 2>&1 || exit 1
+tail -1 $O/kt.log | cut -c1-200
+# SQ / LDS / TCC counters of the two transform kernels
 cd $R
+bash scripts/prof_pmc.sh prof_${TAG}_sq_fir fir_fft4096 -- python3 $R/bench.py --workload fir --steps 3 --warmup 1 --no-cpu --no-others > /dev/null 2>&1 || exit 1
+bash scripts/prof_pmc.sh prof_${TAG}_sq_resample poly_fft256 -- python3 $R/bench.py --workload resample --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1 || exit 1
+# ablation / variant tables from the diagnostic library (regenerable: scripts/ablate.py, scripts/ab_fir.py, scripts/ab_rs.py)
+mkdir -p $R/gpurun_out/prof_${TAG}_tables
 timeout -k 10 300 python3 scripts/ablate.py fir > gpurun_out/prof_${TAG}_tables/fir_variants_ab.txt 2>&1 || exit 1
 timeout -k 10 300 python3 scripts/ablate.py resample > gpurun_out/prof_${TAG}_tables/resample_fft_ablation.txt 2>&1 || exit 1
+ROUNDS=8 timeout -k 10 300 python3 scripts/ab_fir.py 4n.h D T X e:8 E e:300 > gpurun_out/prof_${TAG}_tables/fir_walk_vs_tickets.txt 2>&1 || exit 1
+timeout -k 10 300 python3 scripts/ab_rs.py s t l w > gpurun_out/prof_${TAG}_tables/resample_walk_vs_tickets.txt 2>&1 || exit 1
+timeout -k 10 120 scripts/probes/hbm_mix > gpurun_out/prof_${TAG}_tables/hbm_mix.txt 2>&1
+timeout -k 10 200 python3 scripts/time_pipe.py > gpurun_out/prof_${TAG}_tables/host_pipe.txt 2>&1
+echo collected

@@ -541,6 +541,7 @@ struct Rs {
     PlanCache plans;
     MfmaCache mfma_plans;
     FftPlanCache fft_plans;
+    unsigned *d_ticket = nullptr;          // work counters of the transform-domain kernel
     void *d_hist[2] = {nullptr, nullptr};
     int cur = 0;
     sfe_rs_timestate ts = {0, 0.0f, 0};
@@ -578,6 +579,7 @@ static void rs_free(Rs *r)
     r->plans.clear();
     r->mfma_plans.clear();
     r->fft_plans.clear();
+    if (r->d_ticket) (void)hipFree(r->d_ticket);
     for (int i = 0; i < 2; i++)
         if (r->d_hist[i]) (void)hipFree(r->d_hist[i]);
     if (r->d_in) (void)hipFree(r->d_in);
@@ -1080,6 +1082,8 @@ int sfe_dsp_rs_create(const float *taps, int n_taps, int upsample, int blksize, 
         TRY(hipMemset(r->d_hist[i], 0, hb));
     }
     TRY(hipMalloc(&r->d_in, (size_t)blksize * r->esz()));
+    TRY(hipMalloc(&r->d_ticket, POLY_TICKET_GROUPS * 128));
+    TRY(hipMemset(r->d_ticket, 0, POLY_TICKET_GROUPS * 128));
     TRY(hipDeviceSynchronize());
 #undef TRY
     *out = r;
@@ -1268,6 +1272,7 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
             fa.e_max = fp->e_max;
             fa.ovl = fp->Li - 1;
             fa.V = 256 - fa.ovl;
+            fa.ticket = r->d_ticket;
             rc = launch_poly_fft(*fp, fa, r->data_complex, r->in_u8, r->n_channels, s);
         } else if (mp) {
             PolyMfmaArgs ma;
@@ -1534,6 +1539,7 @@ int sfe_dsp_rs_reset(sfe_rs_t h)
     SFE_HIP(hipDeviceSynchronize());
     const size_t hb = (size_t)r->n_channels * r->hl * r->esz();
     for (int i = 0; i < 2; i++) SFE_HIP(hipMemset(r->d_hist[i], 0, hb));
+    if (r->d_ticket) SFE_HIP(hipMemset(r->d_ticket, 0, POLY_TICKET_GROUPS * 128));
     r->ts.pos = 0;
     r->ts.mu = 0.0f;
     r->ts.leftover = 0;

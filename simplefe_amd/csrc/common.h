@@ -151,7 +151,10 @@ struct PolyFftArgs {
     long long   n_in, in_stride, out_stride, n_out;
     long long   n_pass;          // set by the launcher: passes of R segments
     int         hl, e_max, ovl, V;
+    unsigned   *ticket;          // [POLY_TICKET_GROUPS][32] work counters, zero between launches (null: fixed-stride walk)
+    unsigned    tgroups;         // set by the launcher
 };
+constexpr unsigned POLY_TICKET_GROUPS = 8;
 // returns SFE_ESTATE when (SP, UP) has no instantiation
 int launch_poly_fft(const PolyFftPlan &plan, const PolyFftArgs &a, int data_complex, int in_u8, int n_channels, hipStream_t s);
 // segments per pass for (SP, UP), 0 when the shape has no instantiation

@@ -52,13 +52,17 @@ static_assert(pf_swz(7) < 16, "the swizzle must stay inside a row of 16");
 // what a complex one does per sample pair.
 // DIAG (instantiated under -DSFE_DIAG only, scripts/ablate.py): bit 0 = input loads replaced by
 // constants, bit 1 = output stores folded into one never-taken store, bit 2 = no spectrum stage.
-template <int SP, int UP, int R, bool IN_U8, bool PAIR, int DIAG = 0>
-__global__ __launch_bounds__(256, 4) void poly_fft256_kernel(PolyFftArgs a)
+// TICKET: passes are drawn from per-XCD work counters instead of walked at a fixed stride
+// (fir_fft.hip has the reasoning and the measurements); single-channel launches only.
+// LATE (diagnostic): the next pass's samples are requested after S3 instead of before it.
+template <int SP, int UP, int R, bool IN_U8, bool PAIR, int DIAG = 0, bool TICKET = false, bool LATE = false, int WPS = 4>
+__global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
 {
     constexpr int F = R * SP, I = R * UP;
     static_assert(F + I <= 16, "one lane group per transform");
     static_assert(SP <= 8, "pf_swz covers components 0..7");
     __shared__ v2f lds[16 * PF_AREA + 96];     // 16 group areas + the six twiddle bases per lane
+    __shared__ unsigned s_next;
     const unsigned t = threadIdx.x, l = t & 15u, g = t >> 4;
     const int ch = blockIdx.y;
     // Which transform a lane group runs.  Areas are indexed by JOB (forward job f = seg*SP + c' ->
@@ -184,6 +188,26 @@ __global__ __launch_bounds__(256, 4) void poly_fft256_kernel(PolyFftArgs a)
         }
     };
 
+    // work counters: group g = blockIdx.x % tgroups draws the passes g, g + tgroups, ... from its own
+    // counter (128 bytes apart); the launch's last draw of a group zeroes it for the next launch
+    const unsigned tg = a.tgroups, grp = TICKET ? blockIdx.x % tg : 0u;
+    const unsigned np32 = (unsigned)a.n_pass;
+    const unsigned last_draw = TICKET ? (np32 > grp ? (np32 - grp + tg - 1u) / tg : 0u) + (gridDim.x - grp + tg - 1u) / tg - 1u : 0u;
+    auto draw = [&]() -> unsigned {
+        unsigned *const ctr = a.ticket + 32u * grp;
+        const unsigned c = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c == last_draw) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long k = (unsigned long long)c * tg + grp;
+        return k < np32 ? (unsigned)k : 0xFFFFFFFFu;
+    };
+    long long first = blockIdx.x;
+    if constexpr (TICKET) {
+        if (t == 0) s_next = draw();
+        lds_barrier();
+        const unsigned k = __builtin_amdgcn_readfirstlane(s_next);
+        first = k == 0xFFFFFFFFu ? a.n_pass : (long long)k;
+        lds_barrier();
+    }
     long long prev = -1;       // pass whose inverse transforms run in this iteration
     v2f s[R * SP];
     v4u raw[R];
@@ -192,12 +216,12 @@ __global__ __launch_bounds__(256, 4) void poly_fft256_kernel(PolyFftArgs a)
     // passes instead (so the overlap re-read hits L2) measured 8 % SLOWER: a thousand separate
     // read/write streams cost HBM more than the 5 % of re-read bytes they save.
     bool cur_wide = false;
-    if ((long long)blockIdx.x < a.n_pass) {
-        cur_wide = pass_is_wide(blockIdx.x);
-        if (cur_wide) load_pass_wide(raw, blockIdx.x);
-        else if (!WIDE) load_pass(s, blockIdx.x);
+    if (first < a.n_pass) {
+        cur_wide = pass_is_wide(first);
+        if (cur_wide) load_pass_wide(raw, first);
+        else if (!WIDE) load_pass(s, first);
     }
-    for (long long pass = blockIdx.x;; pass += gridDim.x) {
+    for (long long pass = first;;) {
         const bool cur = pass < a.n_pass;
         if (!cur && prev < 0) break;
         // ---- S0: stage this pass's input (requested during the last iteration's S3), transposed by component
@@ -232,6 +256,8 @@ __global__ __launch_bounds__(256, 4) void poly_fft256_kernel(PolyFftArgs a)
                 }
         }
         lds_barrier();
+        unsigned drawn = 0xFFFFFFFFu;
+        if (TICKET && cur && t == 0) drawn = draw();       // published before the barrier that ends S2
         // ---- S1: the transform (forward groups: staged samples; inverse groups: Y of the last pass)
         v2f v[16];
         asm volatile("" : "+v"(cell_in), "+v"(cell0));
@@ -311,14 +337,23 @@ __global__ __launch_bounds__(256, 4) void poly_fft256_kernel(PolyFftArgs a)
                 if (l == 0 && a.ovl == 0 && lim > 0) __builtin_nontemporal_store(v[P16(0)], reinterpret_cast<v2f *>(out_c + ko0 * 8));
             }
         }
+        if (TICKET && t == 0) s_next = drawn;
         lds_barrier();
+        long long next = pass + gridDim.x;
+        if constexpr (TICKET) {
+            const unsigned k = __builtin_amdgcn_readfirstlane(s_next);
+            next = k == 0xFFFFFFFFu ? a.n_pass : (long long)k;
+        }
         // request the next pass's samples now: v[] is dead, they land while S3 and the barrier run
         // (requesting them a whole pass ahead instead measured the same: latency is not what binds)
-        if (pass + gridDim.x < a.n_pass) {
-            cur_wide = pass_is_wide(pass + gridDim.x);
-            if (cur_wide) load_pass_wide(raw, pass + gridDim.x);
-            else if (!WIDE) load_pass(s, pass + gridDim.x);
-        }
+        auto request_next = [&]() {
+            if (next < a.n_pass) {
+                cur_wide = pass_is_wide(next);
+                if (cur_wide) load_pass_wide(raw, next);
+                else if (!WIDE) load_pass(s, next);
+            }
+        };
+        if (!LATE) request_next();
         // ---- S3: bin t of every segment of this pass
         if (cur && !(DIAG & 4)) {
 #pragma unroll
@@ -335,18 +370,21 @@ __global__ __launch_bounds__(256, 4) void poly_fft256_kernel(PolyFftArgs a)
             }
         }
         lds_barrier();
+        if (LATE) request_next();
         prev = cur ? pass : -1;
+        pass = next;
     }
 }
 
-template <int SP, int UP, int R, bool IN_U8, bool PAIR, int DIAG = 0>
-int launch_one(const PolyFftArgs &a, int n_channels, hipStream_t s)
+template <int SP, int UP, int R, bool IN_U8, bool PAIR, int DIAG = 0, bool TICKET = false, bool LATE = false, int WPS = 4>
+int launch_one(const PolyFftArgs &a0, int n_channels, hipStream_t s)
 {
+    PolyFftArgs a = a0;
     static int resident = 0;
     if (!resident) {
         int dev = 0, cus = 0, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, poly_fft256_kernel<SP, UP, R, IN_U8, PAIR, DIAG>, 256, 0) != hipSuccess || per_cu < 1)
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, poly_fft256_kernel<SP, UP, R, IN_U8, PAIR, DIAG, TICKET, LATE, WPS>, 256, 0) != hipSuccess || per_cu < 1)
             return hip_fail(hipGetLastError(), "poly_fft occupancy");
         resident = cus * per_cu;
     }
@@ -355,7 +393,11 @@ int launch_one(const PolyFftArgs &a, int n_channels, hipStream_t s)
     long long cap = (2LL * resident + n_channels - 1) / n_channels;
     if (cap < 1) cap = 1;
     dim3 grid((unsigned)(a.n_pass < cap ? a.n_pass : cap), (unsigned)n_channels);
-    hipLaunchKernelGGL((poly_fft256_kernel<SP, UP, R, IN_U8, PAIR, DIAG>), grid, dim3(256), 0, s, a);
+    if (TICKET) {
+        if (n_channels != 1 || !a.ticket || a.n_pass + grid.x >= 0xFFFFFFFFLL) return SFE_ESTATE;
+        a.tgroups = POLY_TICKET_GROUPS < grid.x ? POLY_TICKET_GROUPS : grid.x;
+    }
+    hipLaunchKernelGGL((poly_fft256_kernel<SP, UP, R, IN_U8, PAIR, DIAG, TICKET, LATE, WPS>), grid, dim3(256), 0, s, a);
     hipError_t err = hipGetLastError();
     return err == hipSuccess ? SFE_OK : hip_fail(err, "poly_fft launch");
 }
@@ -402,12 +444,27 @@ int launch_poly_fft(const PolyFftPlan &plan, const PolyFftArgs &a0, int data_com
     const long long n_seg = (m_count + a.V - 1) / a.V;
     const long long n_xf = data_complex ? n_seg : (n_seg + 1) / 2;      // real data: two segments per transform
     a.n_pass = (n_xf + R - 1) / R;
+#ifdef SFE_DIAG
+    // SFE_RS_VARIANT: s = fixed-stride walk (round 1), t = tickets (the product's single-channel kernel), l = tickets + late request
+    if (const char *e = getenv("SFE_RS_VARIANT")) {
+        if (plan.SP == 5 && plan.UP == 3 && data_complex && !in_u8 && n_channels == 1) {
+            if (e[0] == 's') return launch_one<5, 3, 2, false, false, 0, false, false>(a, n_channels, s);
+            if (e[0] == 't') return launch_one<5, 3, 2, false, false, 0, true, false>(a, n_channels, s);
+            if (e[0] == 'l') return launch_one<5, 3, 2, false, false, 0, true, true>(a, n_channels, s);
+            if (e[0] == 'L') return launch_one<5, 3, 2, false, false, 0, false, true>(a, n_channels, s);
+            if (e[0] == 'w') return launch_one<5, 3, 2, false, false, 0, true, false, 3>(a, n_channels, s);     // 3 workgroups per CU, 168 VGPRs: no spill
+        }
+    }
+#endif
+    const bool tk = n_channels == 1 && a.ticket != nullptr;
+#define SFE_PF1(sp, up, r, U8, PR) (tk ? launch_one<sp, up, r, U8, PR, 0, true>(a, n_channels, s) : launch_one<sp, up, r, U8, PR>(a, n_channels, s))
 #define SFE_PF(sp, up, r)                                                                         \
     if (plan.SP == sp && plan.UP == up)                                                           \
-        return data_complex ? (in_u8 ? launch_one<sp, up, r, true, false>(a, n_channels, s) : launch_one<sp, up, r, false, false>(a, n_channels, s)) \
-                            : (in_u8 ? launch_one<sp, up, r, true, true>(a, n_channels, s) : launch_one<sp, up, r, false, true>(a, n_channels, s));
+        return data_complex ? (in_u8 ? SFE_PF1(sp, up, r, true, false) : SFE_PF1(sp, up, r, false, false)) \
+                            : (in_u8 ? SFE_PF1(sp, up, r, true, true) : SFE_PF1(sp, up, r, false, true));
     SFE_PF_SHAPES(SFE_PF)
 #undef SFE_PF
+#undef SFE_PF1
     return SFE_ESTATE;
 }
 
