@@ -50,8 +50,10 @@ struct FirFftArgs {
     const v2f  *tw2;      // [7][16]    rows 1..3: W_256^(n0 k),  rows 4..6: W_256^(4 n0 k)
     long long   n;        // samples per channel in this call
     long long   in_stride, out_stride;   // samples
-    int         hl;       // history rows * 256 = FFT_N - advance
+    int         hl;       // overlap rows * 256 = FFT_N - advance (the taps this launch applies reach back hl samples)
     int         advance;  // valid outputs per transform
+    int         hist_len; // samples of history in front of `in` (per channel), multiple of 256, >= hl + shift
+    int         shift;    // this launch filters the stream delayed by `shift` samples (partition p: p * hl)
     long long   nblk;     // transforms per channel
     unsigned   *ticket;   // [FIR_TICKET_GROUPS_MAX][32] device counters (128 bytes apart) the persistent workgroups
                           // draw transforms from; zero between launches
@@ -64,8 +66,9 @@ constexpr int FIR_TICKET_GROUPS_MAX = 64;
 // an (I, Q) byte pair per complex sample); it is converted on load, (b - 128) * (1/127)
 // (gr-simplefe/lib/source_c_impl.cc:121-132).  History stays float32.
 // out_tx10: real output packed as 10-bit offset binary, 4 samples in 5 bytes (sink_f_impl.cc:117-143)
+// accumulate: add to the output instead of overwriting it (partitions after the first)
 int launch_fir_fft(const FirFftArgs &a, int in_complex, int out_complex, int in_u8, int out_tx10, int n_channels,
-                   hipStream_t s);
+                   hipStream_t s, int accumulate = 0);
 
 struct PolyArgs {
     const void *in;        // channel 0 input (n_in samples)

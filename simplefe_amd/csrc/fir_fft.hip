@@ -94,9 +94,14 @@ __device__ __forceinline__ void store_group(unsigned char *d, unsigned u0, unsig
 // variant lost a resident workgroup to its 32 extra VGPRs).  F1 then reads its column from LDS.
 // Edge transforms (history in front, ragged end) keep the guarded register loads.
 template <bool IN_C, bool OUT_C, int WAVES, bool PREFETCH, bool SWZ, bool HREG = false, bool IN_U8 = false, bool PAIR = false,
-          bool OUT_TX10 = false, bool DMA = false, int DIAG = 0, bool TICKET = true>
+          bool OUT_TX10 = false, bool DMA = false, int DIAG = 0, bool TICKET = true, bool ACC = false>
 __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 {
+    // ACC / a.shift (filters longer than one transform can overlap: partitioned convolution, api.hip
+    // fir_run): this launch applies ONE partition h_p = h[p*hl .. (p+1)*hl) of the taps to the stream
+    // delayed by a.shift = p*hl samples and, with ACC, adds its result to what the earlier partitions
+    // left in the output.  a.hist_len >= a.hl + a.shift samples of history precede the input.
+    static_assert(!ACC || (!OUT_TX10 && !DMA), "accumulating launches write float32 through the plain store path");
     // TICKET: the persistent workgroups do not walk a fixed stride (blockIdx.x, +gridDim.x, ...) but
     // draw the next transform from one device-wide counter, channel-major.  Whatever the speed of
     // individual workgroups, the transforms in flight are then always the ~1000 NEXT ones of the
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         in_c = in_of(c);
         // 10-bit output: the channel's floats (2 per complex sample) in whole groups of 4 -> 5 bytes
         out_c = static_cast<char *>(a.out) + (OUT_TX10 ? (size_t)c * (a.out_stride * (OUT_C ? 2 : 1) / 4) * 5 : (size_t)c * a.out_stride * (OUT_C ? 8 : 4));
-        hist_c = static_cast<const char *>(a.hist) + (size_t)c * a.hl * (IN_C ? 8 : 4);
+        hist_c = static_cast<const char *>(a.hist) + (size_t)c * a.hist_len * (IN_C ? 8 : 4);
     };
     set_channel(ch);
 
@@ -161,9 +166,9 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
     // state carry-over fused in (the workgroup that takes a channel's transform 0): next call's
     // history = the last hl input samples, converted to float32 if the stream is u8
     auto carry_history = [&]() {
-        char *ho = static_cast<char *>(a.hist_out) + (size_t)ch * a.hl * (IN_C ? 8 : 4);
-        for (int r = 0; r < row0; r++) {
-            const v2f s = load_sample<IN_C, IN_U8>(in_c + (a.n - a.hl + 256 * r) * ISZ, t);
+        char *ho = static_cast<char *>(a.hist_out) + (size_t)ch * a.hist_len * (IN_C ? 8 : 4);
+        for (int r = 0; r < (a.hist_len >> 8); r++) {
+            const v2f s = load_sample<IN_C, IN_U8>(in_c + (a.n - a.hist_len + 256 * r) * ISZ, t);
             if constexpr (IN_C) reinterpret_cast<v2f *>(ho)[256 * r + t] = s;
             else reinterpret_cast<float *>(ho)[256 * r + t] = s.x;
         }
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         constexpr int ESZ = IN_C ? 8 : 4;     // history is always float32
         if constexpr (PAIR) {
             // segment A = transform 2*blk of the real stream, segment B = transform 2*blk + 1
-            const long long baseA = 2 * blk * a.advance - a.hl, baseB = baseA + a.advance;
+            const long long baseA = 2 * blk * a.advance - a.hl - a.shift, baseB = baseA + a.advance;
             if constexpr (IN_U8 && !PREFETCH) {
                 // real u8 stream: each segment's 4 KiB as one 16-byte lane per thread, parked raw in
                 // LDS and picked up bytewise (the complex form is below)
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 #pragma unroll
                     for (int q = 0; q < 2; q++) {
                         const long long row = (q ? baseB : baseA) + 256 * r;   // uniform
-                        if (row + (long long)t < 0) p[q] = load_sample<false>(hist_c + (a.hl + row) * ESZ, t).x;
+                        if (row + (long long)t < 0) p[q] = load_sample<false>(hist_c + (a.hist_len + row) * ESZ, t).x;
                         else if (row + (long long)t < a.n) p[q] = load_sample<false, IN_U8>(in_c + row * ISZ, t).x;
                         else p[q] = 0.0f;
                     }
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             }
             return;
         }
-        const long long base = blk * a.advance - a.hl;   // stream index of transform element 0
+        const long long base = blk * a.advance - a.hl - a.shift;   // stream index of transform element 0
         if constexpr (DIAG & 1) {       // ablation: no input loads (values that keep the arithmetic alive)
             unsigned u = t + ((unsigned)blk << 12);
             asm volatile("" : "+v"(u));        // opaque per iteration: nothing of this is hoisted out of the loop
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const long long row = base + 256 * r;          // uniform
-                if (row + (long long)t < 0) x[r] = load_sample<IN_C>(hist_c + (a.hl + row) * ESZ, t);
+                if (row + (long long)t < 0) x[r] = load_sample<IN_C>(hist_c + (a.hist_len + row) * ESZ, t);
                 else if (row + (long long)t < a.n) x[r] = load_sample<IN_C, IN_U8>(in_c + row * ISZ, t);
                 else x[r] = (v2f){0.0f, 0.0f};
             }
@@ -289,11 +294,11 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
     const unsigned wv = __builtin_amdgcn_readfirstlane(t >> 6), lane16 = (t & 63u) * 16u;
     auto interior = [&](long long blk) -> bool {
         if constexpr (DIAG & 1) return false;
-        const long long base = blk * a.advance - a.hl;
+        const long long base = blk * a.advance - a.hl - a.shift;
         return base >= 0 && base + FFT_N <= a.n;
     };
     auto dma_rows = [&](const char *chan, long long blk) {
-        const char *g = chan + (blk * a.advance - a.hl) * 8;      // uniform
+        const char *g = chan + (blk * a.advance - a.hl - a.shift) * 8;      // uniform
 #pragma unroll
         for (int p = 0; p < 8; p++) {
             const unsigned row = 4u * wv + (p >> 1), half = p & 1;
@@ -464,10 +469,14 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
                         }
                     }
                 } else {
-                if (wholeA || oA + 256 * r + (long long)t < a.n)
-                    __builtin_nontemporal_store(y.x, reinterpret_cast<float *>(out_c + (oA + 256 * r) * 4) + t);
-                if (wholeB || oB + 256 * r + (long long)t < a.n)
-                    __builtin_nontemporal_store(y.y, reinterpret_cast<float *>(out_c + (oB + 256 * r) * 4) + t);
+                if (wholeA || oA + 256 * r + (long long)t < a.n) {
+                    float *q = reinterpret_cast<float *>(out_c + (oA + 256 * r) * 4) + t;
+                    __builtin_nontemporal_store(ACC ? y.x + *q : y.x, q);
+                }
+                if (wholeB || oB + 256 * r + (long long)t < a.n) {
+                    float *q = reinterpret_cast<float *>(out_c + (oB + 256 * r) * 4) + t;
+                    __builtin_nontemporal_store(ACC ? y.y + *q : y.y, q);
+                }
                 }
             }
         } else {
@@ -493,10 +502,15 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             }
             if constexpr (DIAG & 2) continue;      // ablation: no output stores (folded below)
             if (r >= row0 && (whole || orow + (long long)t < a.n)) {
-                const v2f y = v[P16(r)];
+                v2f y = v[P16(r)];
                 char *rp = out_c + orow * OSZ;               // uniform row pointer
-                if constexpr (OUT_C) __builtin_nontemporal_store(y, reinterpret_cast<v2f *>(rp) + t);
-                else __builtin_nontemporal_store(y.x, reinterpret_cast<float *>(rp) + t);
+                if constexpr (OUT_C) {
+                    if constexpr (ACC) y += reinterpret_cast<const v2f *>(rp)[t];
+                    __builtin_nontemporal_store(y, reinterpret_cast<v2f *>(rp) + t);
+                } else {
+                    if constexpr (ACC) y.x += reinterpret_cast<const float *>(rp)[t];
+                    __builtin_nontemporal_store(y.x, reinterpret_cast<float *>(rp) + t);
+                }
             }
         }
         if constexpr (DIAG & 2) {   // keeps every result alive behind one store that never happens
@@ -673,10 +687,14 @@ __global__ __launch_bounds__(256, WAVES) void fir_copy_pattern_dma_kernel(FirFft
 }  // namespace
 
 int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in_u8, int out_tx10, int n_channels,
-                   hipStream_t s)
+                   hipStream_t s, int accumulate)
 {
     FirFftArgs a = a0;
     if (a.nblk <= 0) return SFE_OK;
+    if (a.hist_len < a.hl + a.shift || (a.hist_len & 255) || (a.shift & 255) || ((accumulate || a.shift) && out_tx10)) {
+        set_error("fir_fft: bad partition arguments (hist_len=%d hl=%d shift=%d)", a.hist_len, a.hl, a.shift);
+        return SFE_EINVAL;
+    }
     if (a.hl <= 0 || (a.hl & 255) || a.hl >= FFT_N || a.advance != FFT_N - a.hl) {
         set_error("fir_fft: bad overlap rows (hl=%d advance=%d)", a.hl, a.advance);
         return SFE_EINVAL;
@@ -772,8 +790,18 @@ int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in
         }
     }
 #endif
-    //       IN_C   OUT_C  WAVES PREFETCH SWZ  HREG  IN_U8  PAIR   OUT_TX10
-    if (in_complex) {
+    //       IN_C   OUT_C  WAVES PREFETCH SWZ  HREG  IN_U8  PAIR   OUT_TX10 DMA DIAG TICKET ACC
+    if (accumulate) {           // partitions after the first: out += this partition's result
+        if (in_complex) {
+            if (in_u8) SFE_K(true, true, 4, false, false, true, true, false, false, false, 0, true, true);
+            else SFE_K(true, true, 4, false, false, true, false, false, false, false, 0, true, true);
+        } else if (out_complex) {
+            SFE_K(false, true, 4, false, false, true, false, false, false, false, 0, true, true);
+        } else {
+            if (in_u8) SFE_K(false, false, 4, false, false, true, true, true, false, false, 0, true, true);
+            else SFE_K(false, false, 4, false, false, true, false, true, false, false, 0, true, true);
+        }
+    } else if (in_complex) {
         if (in_u8 && out_tx10) SFE_K(true, true, 4, false, false, true, true, false, true);      // wire to wire
         else if (out_tx10) SFE_K(true, true, 4, false, false, true, false, false, true);
         else if (in_u8) SFE_K(true, true, 4, false, false, true, true);
