@@ -341,6 +341,8 @@ struct Fir {
     int device = 0, algo = SFE_FIR_ALGO_AUTO, in_u8 = 0, out_tx10 = 0;
     int blk = 0, block_hint = 0;
     int hl = 0;                 // carried history per channel, samples (multiple of 256)
+    int ovl = 0;                // overlap of one transform (multiple of 256): each launch applies `ovl` (+1) taps
+    int parts = 1;              // partitions of the tap vector, one launch each (filters longer than one overlap)
     bool fft_ok = false;
     v2f *d_hs = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr;
     unsigned *d_ticket = nullptr;   // work counter of the persistent FFT kernel (zero between launches)
@@ -395,33 +397,57 @@ static void fir_free(Fir *f)
 static int fir_build_tables(Fir *f, const float *taps)
 {
     const int N = FFT_N;
-    // spectrum of the zero-padded taps in double precision, scaled by 1/N (blkconv.cxx:50
+    // spectrum of each zero-padded tap partition in double precision, scaled by 1/N (blkconv.cxx:50
     // folds the same 1/fft_len into its multiply), permuted to the kernel's F3 thread order:
     // thread t (k1 = t&15, k2 = t>>4), register k0 -> bin k2 + 16 k1 + 256 k0.
-    std::vector<double> hr(N, 0.0), hi(N, 0.0);
-    std::vector<double> c(N), s(N);
-    for (int m = 0; m < N; m++) {
+    // Partition p holds taps [p*ovl, (p+1)*ovl) (a single partition: all n_taps <= ovl+1 of them).
+    std::vector<double> c(N / 2), sn(N / 2);
+    for (int m = 0; m < N / 2; m++) {
         c[m] = cos(-2.0 * M_PI * m / N);
-        s[m] = sin(-2.0 * M_PI * m / N);
+        sn[m] = sin(-2.0 * M_PI * m / N);
     }
-    for (int k = 0; k < N; k++) {
-        double ar = 0.0, ai = 0.0;
-        for (int n = 0; n < f->n_taps; n++) {
-            const double tr = f->taps_complex ? taps[2 * n] : taps[n];
-            const double ti = f->taps_complex ? taps[2 * n + 1] : 0.0;
-            const int m = (int)(((long long)n * k) & (N - 1));
-            ar += tr * c[m] - ti * s[m];
-            ai += tr * s[m] + ti * c[m];
+    // in-place radix-2 decimation-in-time FFT in double precision (forward sign): table construction
+    // only, so that a filter of many partitions does not cost N * n_taps trigonometric multiplies
+    auto fft = [&](std::vector<double> &re, std::vector<double> &im) {
+        for (int i = 1, j = 0; i < N; i++) {
+            int bit = N >> 1;
+            for (; j & bit; bit >>= 1) j ^= bit;
+            j ^= bit;
+            if (i < j) {
+                std::swap(re[i], re[j]);
+                std::swap(im[i], im[j]);
+            }
         }
-        hr[k] = ar / N;
-        hi[k] = ai / N;
+        for (int len = 2; len <= N; len <<= 1) {
+            const int half = len >> 1, step = N / len;
+            for (int base = 0; base < N; base += len)
+                for (int k = 0; k < half; k++) {
+                    const double wr = c[k * step], wi = sn[k * step];
+                    const int a = base + k, b = a + half;
+                    const double xr = re[b] * wr - im[b] * wi, xi = re[b] * wi + im[b] * wr;
+                    re[b] = re[a] - xr;
+                    im[b] = im[a] - xi;
+                    re[a] += xr;
+                    im[a] += xi;
+                }
+        }
+    };
+    std::vector<v2f> hs((size_t)f->parts * 16 * 256), tw1(7 * 256), tw2(7 * 16);
+    std::vector<double> hr(N), hi(N);
+    for (int p = 0; p < f->parts; p++) {
+        const int first = f->parts == 1 ? 0 : p * f->ovl;
+        const int count = f->parts == 1 ? f->n_taps : (f->n_taps - first < f->ovl ? f->n_taps - first : f->ovl);
+        for (int n = 0; n < N; n++) {
+            hr[n] = n < count ? (f->taps_complex ? taps[2 * (first + n)] : taps[first + n]) / (double)N : 0.0;
+            hi[n] = n < count && f->taps_complex ? taps[2 * (first + n) + 1] / (double)N : 0.0;
+        }
+        fft(hr, hi);
+        for (int t = 0; t < 256; t++)
+            for (int k0 = 0; k0 < 16; k0++) {
+                const int bin = (t >> 4) + 16 * (t & 15) + 256 * k0;
+                hs[((size_t)p * 16 + k0) * 256 + t] = (v2f){(float)hr[bin], (float)hi[bin]};
+            }
     }
-    std::vector<v2f> hs(16 * 256), tw1(7 * 256), tw2(7 * 16);
-    for (int t = 0; t < 256; t++)
-        for (int k0 = 0; k0 < 16; k0++) {
-            const int bin = (t >> 4) + 16 * (t & 15) + 256 * k0;
-            hs[k0 * 256 + t] = (v2f){(float)hr[bin], (float)hi[bin]};
-        }
     // twiddle bases: row k (1..3) = W^(e k), row k+3 = W^(4 e k); the kernel forms
     // W^(e (4a+b)) as row[a+3] * row[b]
     for (int k = 1; k < 4; k++)
@@ -447,6 +473,36 @@ static int fir_build_tables(Fir *f, const float *taps)
     return SFE_OK;
 }
 
+// How a tap count is cut for the 4096-point kernel.  One launch with overlap hl costs ~1/(4096-hl) per
+// output sample; P launches over partitions of `ovl` taps cost P/(4096-ovl) plus the read-modify-
+// write of the output for every launch after the first (8 more bytes per sample: ~1/4 of a launch's
+// traffic).  E.g. 3841 taps: one launch advances 256 samples per transform (16x the 256-tap work);
+// two partitions of 2048 advance 2048 (2.25x).  Returns false beyond FIR_MAX_PARTS partitions.
+constexpr int FIR_MAX_PARTS = 1024;       // ~3.9 million taps; 32 KiB of spectrum per partition
+static bool fir_choose_partition(int n_taps, int *ovl, int *parts)
+{
+    const int need = n_taps > 1 ? n_taps - 1 : 1;
+    double best = 1e300;
+    *parts = 0;
+    const int hl1 = ((need + 255) / 256) * 256;
+    if (hl1 < FFT_N) {
+        best = 1.0 / (FFT_N - hl1);
+        *ovl = hl1;
+        *parts = 1;
+    }
+    for (int o = 256; o < FFT_N; o += 256) {
+        const int P = (n_taps + o - 1) / o;
+        if (P < 2 || P > FIR_MAX_PARTS) continue;
+        const double cost = (P + 0.25 * (P - 1)) / (FFT_N - o);
+        if (cost < best) {
+            best = cost;
+            *ovl = o;
+            *parts = P;
+        }
+    }
+    return *parts > 0;
+}
+
 static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_stride,
                    size_t out_stride, hipStream_t s)
 {
@@ -457,7 +513,7 @@ static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_st
     bool hist_fused = false;
     if (algo == SFE_FIR_ALGO_FFT) {
         if (!f->fft_ok) {
-            set_error("fir: %d taps exceed what one 4096-point transform can overlap", f->n_taps);
+            set_error("fir: %d taps exceed %d partitions of the 4096-point kernel", f->n_taps, FIR_MAX_PARTS);
             return SFE_EINVAL;
         }
         FirFftArgs a;
@@ -465,19 +521,27 @@ static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_st
         a.out = d_out;
         a.hist = f->d_hist[f->cur];
         hist_fused = n >= (size_t)f->hl;                 // else the old history still contributes
-        a.hist_out = hist_fused ? f->d_hist[f->cur ^ 1] : nullptr;
-        a.hs = f->d_hs;
         a.tw1 = f->d_tw1;
         a.tw2 = f->d_tw2;
         a.n = (long long)n;
         a.in_stride = (long long)in_stride;
         a.out_stride = (long long)out_stride;
-        a.hl = f->hl;
-        a.advance = FFT_N - f->hl;
+        a.hl = f->ovl;
+        a.advance = FFT_N - f->ovl;
+        a.hist_len = f->hl;
         a.nblk = ((long long)n + a.advance - 1) / a.advance;
         a.ticket = f->d_ticket;
         a.total = 0;
-        rc = launch_fir_fft(a, f->data_complex, f->out_complex, f->in_u8, f->out_tx10, f->n_channels, s);
+        a.tgroups = 0;
+        rc = SFE_OK;
+        // one launch per tap partition: partition p filters the stream delayed by p*ovl samples and
+        // (p > 0) adds to what the earlier ones wrote
+        for (int p = 0; p < f->parts && rc == SFE_OK; p++) {
+            a.hs = f->d_hs + (size_t)p * 16 * 256;
+            a.shift = p * f->ovl;
+            a.hist_out = (p == 0 && hist_fused) ? f->d_hist[f->cur ^ 1] : nullptr;
+            rc = launch_fir_fft(a, f->data_complex, f->out_complex, f->in_u8, f->out_tx10, f->n_channels, s, p > 0);
+        }
     } else {
         if (f->taps_complex || f->in_u8 || f->out_tx10) {
             set_error("fir: the direct kernel takes real taps and float input/output; use SFE_FIR_ALGO_FFT");
@@ -791,9 +855,9 @@ int sfe_dsp_fir_create(const float *taps, int n_taps, int taps_complex, int data
     f->device = device;
     f->block_hint = block_hint;
     f->blk = block_hint ? block_hint + 1 - n_taps : 0;
-    const int ovl = n_taps - 1;
-    f->hl = ovl <= 0 ? 256 : ((ovl + 255) / 256) * 256;
-    f->fft_ok = f->hl < FFT_N;
+    f->fft_ok = fir_choose_partition(n_taps, &f->ovl, &f->parts);
+    if (f->fft_ok) f->hl = f->parts * f->ovl;                       // history the slowest partition reaches back to
+    else f->hl = ((n_taps - 1 + 255) / 256) * 256;                  // beyond FIR_MAX_PARTS partitions: direct kernel only
     auto fail = [&](int code) { fir_free(f); return code; };
 #define TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(hip_fail(e__, #call)); } while (0)
     TRY(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
@@ -978,8 +1042,9 @@ int sfe_dsp_fir_set_output_format(sfe_fir_t h, int fmt)
 {
     Fir *f = as_fir(h);
     if (!f || (fmt != SFE_FMT_F32 && fmt != SFE_FMT_TX10)) return SFE_EINVAL;
-    if (fmt == SFE_FMT_TX10 && (!f->fft_ok || f->data_complex != f->out_complex)) {
-        set_error("fir_set_output_format: 10-bit output needs the FFT kernel and a real->real or complex->complex stream");
+    if (fmt == SFE_FMT_TX10 && (!f->fft_ok || f->parts > 1 || f->data_complex != f->out_complex)) {
+        set_error("fir_set_output_format: 10-bit output needs the single-launch FFT kernel (a filter that one 4096-point "
+                  "transform can overlap) and a real->real or complex->complex stream");
         return SFE_ESTATE;
     }
     f->out_tx10 = fmt == SFE_FMT_TX10;

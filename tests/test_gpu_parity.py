@@ -587,18 +587,19 @@ def test_empty_and_tiny_inputs(api, L, orc):
     assert r.process_stream(d, 0, d2, 0, 8.0) == 0
 
 
-def test_long_filter_falls_back_to_time_domain(api, L):
-    """More than 3841 taps cannot overlap inside one 4096-point transform: AUTO uses the tiled
-    time-domain kernel (or the generic one) and stays correct; forcing FFT is an error."""
+def test_very_long_filter(api, L):
+    """A quarter of a million taps: 120 partitions through the FFT kernel, still the streaming
+    convolution; the time-domain kernel cannot hold such a filter and says so."""
     rng = np.random.default_rng(9)
-    taps = (rng.standard_normal(5000) / 70).astype(np.float32)
-    x = synth.synth_f32(30000)
+    n_taps = 64 * 3840 + 5
+    taps = (rng.standard_normal(n_taps) / 500).astype(np.float32)
+    x = synth.synth_f32(300000)
     y = api.Fir(taps, data_complex=False).filter(x)[0]
     from scipy.signal import fftconvolve
     ref = fftconvolve(x.astype(np.float64), taps.astype(np.float64))[: len(x)]
     assert synth.rel_rms(y, ref) <= TOL
     f = api.Fir(taps, data_complex=False)
-    f.set_algo(L.FIR_ALGO_FFT)
+    f.set_algo(L.FIR_ALGO_DIRECT)
     with pytest.raises(api.SfeError):
         f.filter(x)
 
@@ -748,3 +749,63 @@ def test_fir_wire_to_wire_u8_in_tx10_out(api, L, orc, cplx):
     f.process_stream(d_b, d_o, n)
     f0.process_stream(d_b, d_f, n)
     assert np.array_equal(d_o.to_numpy().view(np.uint8)[:n_bytes], orc.tx_f32_to_10bit(d_f.to_numpy()[: (n * w // 4) * 4]))
+
+
+# ------------------------------------------- filters longer than one transform can overlap
+@pytest.mark.parametrize("n_taps,cplx,nch", [(3000, True, 1), (3841, True, 1), (4096, True, 2), (8192, True, 1),
+                                             (10000, False, 1), (5000, False, 3), (551, True, 1)])
+def test_fir_long_filters_partitioned(api, L, n_taps, cplx, nch):
+    """blkconv accepts any n_taps that leaves a block (blkconv.cxx:47; the reference's bpsk example
+    offers a 551-tap prototype at fft 8192, examples/bpsk/bpsk.cxx:58-63).  Beyond what one
+    4096-point transform can overlap usefully the tap vector is cut into partitions, one launch
+    each, accumulated in the output (api.hip fir_choose_partition).  Against the float64
+    convolution; chunked calls shorter than the carried history exercise the unfused state update."""
+    from scipy.signal import fftconvolve
+    rng = np.random.default_rng(n_taps)
+    taps = (rng.standard_normal(n_taps) / np.sqrt(n_taps)).astype(np.float32)
+    n = 60000
+    w = 2 if cplx else 1
+    x = np.stack([(synth.synth_cf32(n, ch=c) if cplx else synth.synth_f32(n, ch=c)) for c in range(nch)])
+    f = api.Fir(taps, data_complex=cplx, n_channels=nch, algo=L.FIR_ALGO_FFT)
+    y = f.filter(x)
+    for c in range(nch):
+        for part in range(w):
+            r64 = fftconvolve(x[c, part::w].astype(np.float64), taps.astype(np.float64))[:n]
+            assert synth.rel_rms(y[c, part::w], r64) <= TOL, (c, part)
+    # the same stream in ragged chunks (some shorter than the history): carried state
+    f.reset()
+    outs = []
+    cuts = [0, 100, 4000, 4001, 30000, 52345, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        d_in = api.DeviceArray.from_numpy(np.ascontiguousarray(x[:, a * w: b * w]))
+        d_out = api.DeviceArray(nch * (b - a) * w)
+        f.process_stream(d_in, d_out, b - a)
+        outs.append(d_out.to_numpy().reshape(nch, -1))
+    y2 = np.concatenate(outs, axis=1)
+    assert synth.rel_rms(y2, y) <= 2e-6
+
+
+def test_fir_long_filter_u8_input_and_split(api, L):
+    """A partitioned filter reads the u8 wire format too, and one stream cut into spans with
+    load_history (history = parts x overlap samples) matches the uncut result."""
+    from scipy.signal import fftconvolve
+    rng = np.random.default_rng(5)
+    taps = (rng.standard_normal(6000) / np.sqrt(6000)).astype(np.float32)
+    n = 50000
+    b = _u8_stream(2 * n, 3)
+    xf = ((b.astype(np.float32) - 128.0) * np.float32(1.0 / 127.0))
+    f = api.Fir(taps, data_complex=True, algo=L.FIR_ALGO_FFT)
+    f.set_input_format(L.FMT_U8)
+    d_out = api.DeviceArray(2 * n)
+    f.process_stream(api.DeviceArray.from_bytes(b), d_out, n)
+    y = d_out.to_numpy()
+    for part in (0, 1):
+        assert synth.rel_rms(y[part::2], fftconvolve(xf[part::2].astype(np.float64), taps.astype(np.float64))[:n]) <= TOL
+    with pytest.raises(api.SfeError):
+        f.set_output_format(L.FMT_TX10)                  # packed output cannot be accumulated into
+    g = api.Fir(taps, data_complex=True, algo=L.FIR_ALGO_FFT)
+    cut = 23456
+    g.load_history(api.DeviceArray.from_numpy(xf[2 * (cut - 6000): 2 * cut]), 6000)
+    d2 = api.DeviceArray(2 * (n - cut))
+    g.process_stream(api.DeviceArray.from_numpy(xf[2 * cut:]), d2, n - cut)
+    assert synth.rel_rms(d2.to_numpy(), y[2 * cut:]) <= 2e-6
