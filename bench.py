@@ -157,11 +157,12 @@ def cpu_baseline_fir(taps, budget_s):
            "sample": f"{reps} x 2^20 cf32 samples, blkconv port fft_len 4096 (own float32 FFT; "
                      f"FFTW absent), I and Q as two real passes, {dt:.1f} s"}
 
-    nb = 1 << 23                                       # long enough that every core's span is many blocks
-    xb = synth.synth_cf32(nb)
-    br, bi = np.ascontiguousarray(xb[0::2]), np.ascontiguousarray(xb[1::2])
+    # long enough that every core's span is many blocks and thread start-up does not show: 2^19
+    # samples per core (a 256-core host: 2^27); the I and the Q pass run over the same real buffer
+    nb = 1 << min(27, max(23, (host_cores() - 1).bit_length() + 19))
+    br = np.tile(np.ascontiguousarray(synth.synth_cf32(1 << 21)[0::2]), nb >> 21)
     out["all_cores"] = _all_cores(lambda C: (orc.blkconv_stream_mt(taps, 4096, br, C, want_output=False),
-                                             orc.blkconv_stream_mt(taps, 4096, bi, C, want_output=False)),
+                                             orc.blkconv_stream_mt(taps, 4096, br, C, want_output=False)),
                                   nb, 0.4 * budget_s)
     out["host_cores"] = host_cores()
     return out
@@ -185,11 +186,10 @@ def cpu_baseline_rs(which, taps, U, rate, budget_s):
 
     S = int(round(rate * U))
     quantum = S // int(np.gcd(S, U))
-    nb = 1 << 21
-    xb = synth.synth_cf32(nb)
-    br, bi = np.ascontiguousarray(xb[0::2]), np.ascontiguousarray(xb[1::2])
+    nb = 1 << min(26, max(21, (host_cores() - 1).bit_length() + 17))
+    br = np.tile(np.ascontiguousarray(synth.synth_cf32(1 << 20)[0::2]), nb >> 20)
     out["all_cores"] = _all_cores(lambda C: (orc.rs_stream_mt(which, taps, U, B, rate, br, quantum, C, reference=use_ref),
-                                             orc.rs_stream_mt(which, taps, U, B, rate, bi, quantum, C, reference=use_ref)),
+                                             orc.rs_stream_mt(which, taps, U, B, rate, br, quantum, C, reference=use_ref)),
                                   nb, 0.4 * budget_s)
     out["host_cores"] = host_cores()
     return out
@@ -478,7 +478,7 @@ def main():
                   make_fir_leg(ctx, "fir_ctaps", (tr + 1j * ti).astype(np.complex64), 28, 1, x_share=head.x)]
     other_rows = []
     for leg in others:
-        el, kms = time_leg(ctx, leg, args.other_steps, 3)
+        el, kms = time_leg(ctx, leg, args.other_steps, 15 if leg is others[0] else 3)   # the first leg also takes the chip through its start-up clock transient
         other_rows.append({"workload": leg.workload, "steps": args.other_steps, "ms": kms,
                            "value": leg.n_gpu / (el / args.other_steps) / 1e6, "unit": "MS/s (input)",
                            "kernel": leg.kernel, "algorithmic_bytes_per_launch": leg.bytes_per_launch,

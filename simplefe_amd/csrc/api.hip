@@ -973,10 +973,22 @@ int sfe_dsp_fir_process_host(sfe_fir_t h, const void *in, void *out, size_t n)
     SFE_ON_DEVICE(f->device);
     const size_t in_e = f->data_complex ? 8 : 4, out_e = f->out_complex ? 8 : 4;
     const size_t CH = (size_t)1 << 20;            // samples per staged chunk
-    if (!f->h_stage) {
-        SFE_HIP(hipHostMalloc(&f->h_stage, CH * (in_e > out_e ? in_e : out_e)));
-        SFE_HIP(hipMalloc(&f->d_st_in, CH * in_e));
-        SFE_HIP(hipMalloc(&f->d_st_out, CH * out_e));
+    if (!f->h_stage || !f->d_st_in || !f->d_st_out) {
+        // allocate into locals and commit only when all three exist: a failed later allocation must
+        // not leave a half-built staging set behind for the next call to trip over
+        void *hs = nullptr, *di = nullptr, *dn = nullptr;
+        hipError_t e = hipHostMalloc(&hs, CH * (in_e > out_e ? in_e : out_e));
+        if (e == hipSuccess) e = hipMalloc(&di, CH * in_e);
+        if (e == hipSuccess) e = hipMalloc(&dn, CH * out_e);
+        if (e != hipSuccess) {
+            if (hs) (void)hipHostFree(hs);
+            if (di) (void)hipFree(di);
+            if (dn) (void)hipFree(dn);
+            return hip_fail(e, "fir_process_host staging");
+        }
+        f->h_stage = hs;
+        f->d_st_in = di;
+        f->d_st_out = dn;
         f->stage_samples = CH;
     }
     const char *ip = static_cast<const char *>(in);
