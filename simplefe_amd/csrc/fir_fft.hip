@@ -579,7 +579,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_copy_pattern16_kernel(FirFftAr
     }
 }
 
-template <int WAVES, bool TICKET>
+template <int WAVES, bool TICKET, bool BAR = false>
 __global__ __launch_bounds__(256, WAVES) void fir_copy_pattern_nt_kernel(FirFftArgs a)
 {
     __shared__ unsigned s_next;
@@ -623,6 +623,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_copy_pattern_nt_kernel(FirFftA
 #pragma unroll
             for (int r = 0; r < 16; r++)
                 v[r] = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(in_c + (base + 256 * r) * 8) + t);
+            if (BAR) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_barrier(); lds_barrier(); }
 #pragma unroll
             for (int r = 0; r < 16; r++)
                 if (r >= row0) __builtin_nontemporal_store(v[r], reinterpret_cast<v2f *>(out_c + (base + 256 * r) * 8) + t);
@@ -636,10 +637,54 @@ __global__ __launch_bounds__(256, WAVES) void fir_copy_pattern_nt_kernel(FirFftA
     }
 }
 
+// Diagnostic only (SFE_FIR_VARIANT=p): the 8-byte nontemporal pattern, software-pipelined -- the next
+// transform's 16 loads are issued BEFORE this transform's 15 stores, so no load is ever waited for
+// behind an older store of the same wave (vmcnt retires in issue order).
+template <int WAVES>
+__global__ __launch_bounds__(256, WAVES) void fir_copy_pattern_pipe_kernel(FirFftArgs a)
+{
+    const unsigned t = threadIdx.x;
+    const char *in_c = static_cast<const char *>(a.in) + (size_t)blockIdx.y * a.in_stride * 8;
+    char *out_c = static_cast<char *>(a.out) + (size_t)blockIdx.y * a.out_stride * 8;
+    const int row0 = a.hl >> 8;
+    // interior transforms only, walked at a fixed stride; ping-pong register sets (no copies: a copy
+    // would make the compiler wait for the loads it has just issued)
+    auto ok = [&](long long blk) { const long long b = blk * a.advance - a.hl; return blk < a.nblk && b >= 0 && b + FFT_N <= a.n; };
+    auto load = [&](v2f (&x)[16], long long blk) {
+        const long long base = blk * a.advance - a.hl;
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r] = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(in_c + (base + 256 * r) * 8) + t);
+    };
+    auto store = [&](const v2f (&x)[16], long long blk) {
+        const long long base = blk * a.advance - a.hl;
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            if (r >= row0) __builtin_nontemporal_store(x[r], reinterpret_cast<v2f *>(out_c + (base + 256 * r) * 8) + t);
+    };
+    long long blk = blockIdx.x + gridDim.x;            // skip transform 0 (history) and stay interior
+    const long long step = gridDim.x;
+    if (!ok(blk)) return;
+    v2f A[16], B[16];
+    load(A, blk);
+    for (;;) {
+        const long long b1 = blk + step;
+        const bool more1 = ok(b1);
+        if (more1) load(B, b1);
+        store(A, blk);
+        if (!more1) break;
+        const long long b2 = b1 + step;
+        const bool more2 = ok(b2);
+        if (more2) load(A, b2);
+        store(B, b1);
+        if (!more2) break;
+        blk = b2;
+    }
+}
+
 // Diagnostic only (SFE_FIR_VARIANT=g): the access pattern of the LDS-DMA variant -- rows requested by
 // global_load_lds_dwordx4 into the padded layout, picked up column-wise, stored with nontemporal
 // 8-byte lanes; the next transform's request goes out before this one's stores.
-template <int WAVES>
+template <int WAVES, bool NT>
 __global__ __launch_bounds__(256, WAVES) void fir_copy_pattern_dma_kernel(FirFftArgs a)
 {
     __shared__ v2f lds[FFT_ROWS * LDS_K2_STRIDE];
@@ -658,15 +703,23 @@ __global__ __launch_bounds__(256, WAVES) void fir_copy_pattern_dma_kernel(FirFft
             const unsigned dst = lds_base + (row * LDS_K2_STRIDE + half * 128u) * 8u;
             const unsigned off = (row * 256u + half * 128u) * 8u + lane16;
             unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(off), "s"(g), "s"(dst) : "memory");
+            if constexpr (NT)
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(off), "s"(g), "s"(dst) : "memory");
+            else
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(off), "s"(g), "s"(dst) : "memory");
         }
     };
     long long blk = blockIdx.x;
     while (blk < a.nblk && !ok(blk)) blk += gridDim.x;
     if (blk < a.nblk) dma_rows(blk);
+    bool first = true;
     while (blk < a.nblk) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // as the product kernel: the pieces are older than the previous transform's 15 stores
+        if (first || row0 != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+        first = false;
         lds_barrier();
         v2f v[16];
 #pragma unroll
@@ -759,7 +812,10 @@ int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in
         else if (ev[0] == 'd') hipLaunchKernelGGL((fir_copy_pattern16_kernel<4>), grid2, block, 0, s, a);
         else if (ev[0] == 'e') hipLaunchKernelGGL((fir_copy_pattern_nt_kernel<4, false>), grid2, block, 0, s, a);
         else if (ev[0] == 'E') hipLaunchKernelGGL((fir_copy_pattern_nt_kernel<4, true>), grid, block, 0, s, a);
-        else if (ev[0] == 'g') hipLaunchKernelGGL((fir_copy_pattern_dma_kernel<4>), grid2, block, 0, s, a);
+        else if (ev[0] == 'b') hipLaunchKernelGGL((fir_copy_pattern_nt_kernel<4, false, true>), grid2, block, 0, s, a);
+        else if (ev[0] == 'g') hipLaunchKernelGGL((fir_copy_pattern_dma_kernel<4, true>), grid2, block, 0, s, a);
+        else if (ev[0] == 'G') hipLaunchKernelGGL((fir_copy_pattern_dma_kernel<4, false>), grid2, block, 0, s, a);
+        else if (ev[0] == 'p') hipLaunchKernelGGL((fir_copy_pattern_pipe_kernel<4>), grid2, block, 0, s, a);
         else if (ev[0] == 'D') SFE_NEW_DG(true, false);
         else if (ev[0] == 'T') SFE_NEW_DG(false, true);
         else if (ev[0] == 'X') SFE_NEW_DG(true, true);
