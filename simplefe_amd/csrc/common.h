@@ -38,6 +38,8 @@ constexpr int FFT_N = 4096;         // in-LDS transform length (16 x 16 x 16)
 constexpr int FFT_ROWS = 16;        // rows of 256 samples; thread t owns column t
 constexpr int LDS_K2_STRIDE = 272;  // padded 256 (== 16 mod 32: conflict-free both layouts)
 constexpr int LDS_K1_STRIDE = 17;
+constexpr int WP_PITCH = 144;       // wave-private first/last layout: rows (i, i+8) of a wave's 64 columns, then 16 cells of pad
+constexpr int WP_REGION = 8 * WP_PITCH;   // cells per wave
 
 struct FirFftArgs {
     const void *in;       // channel 0 input

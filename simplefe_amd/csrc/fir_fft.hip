@@ -94,9 +94,20 @@ __device__ __forceinline__ void store_group(unsigned char *d, unsigned u0, unsig
 // variant lost a resident workgroup to its 32 extra VGPRs).  F1 then reads its column from LDS.
 // Edge transforms (history in front, ragged end) keep the guarded register loads.
 template <bool IN_C, bool OUT_C, int WAVES, bool PREFETCH, bool SWZ, bool HREG = false, bool IN_U8 = false, bool PAIR = false,
-          bool OUT_TX10 = false, bool DMA = false, int DIAG = 0, bool TICKET = true, bool ACC = false>
+          bool OUT_TX10 = false, bool DMA = false, int DIAG = 0, bool TICKET = true, bool ACC = false, bool WP = false>
 __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 {
+    // WP (with DMA): wave-private [n2|k2][column] layout.  Thread t touches column t of the first /
+    // last exchange layout in F1 (read + write), I3 (read) and nothing else does between the I2->I3
+    // barrier and the F1->F2 barrier; if every wave's 64 columns sit in a region of their own AND the
+    // wave's LDS-DMA pieces cover exactly that region, the path "I3 reads -> request the next
+    // transform -> (this transform's last DFT16 and stores) -> wait -> F1" involves no other wave:
+    // two of the eight workgroup barriers go, and the four waves issue their memory bursts when
+    // each is ready instead of together.  Cell of (row, column c): region c/64 (1152 cells), row
+    // r at 144 (r mod 8) + 64 (r / 8) -- one DMA piece = rows (i, i+8) of the wave's 64 columns
+    // (lanes 0-31 / 32-63), 128 contiguous cells, pieces 144 apart: 144 = 16 mod 32 keeps the F2
+    // reads / I2 writes (two adjacent k2 per 32 lanes) conflict-free exactly as 272 does.
+    static_assert(!WP || DMA, "the wave-private layout exists for the LDS-DMA path");
     // ACC / a.shift (filters longer than one transform can overlap: partitioned convolution, api.hip
     // fir_run): this launch applies ONE partition h_p = h[p*hl .. (p+1)*hl) of the taps to the stream
     // delayed by a.shift = p*hl samples and, with ACC, adds its result to what the earlier partitions
@@ -115,7 +126,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
     // product kernel's instruction stream and register allocation are untouched.
     static_assert(!DMA || (IN_C && !IN_U8 && !PAIR && !SWZ && !PREFETCH), "LDS-DMA input: complex float32, padded layout");
     static_assert(!TICKET || !PREFETCH, "the register prefetch looks ahead by a fixed stride");
-    __shared__ v2f lds[FFT_ROWS * LDS_K2_STRIDE];
+    __shared__ v2f lds[WP ? 4 * WP_REGION : FFT_ROWS * LDS_K2_STRIDE];
     __shared__ unsigned s_next;       // TICKET: the next transform drawn by lane 0
     const unsigned t = threadIdx.x;   // unsigned: lets loads/stores use SGPR base + 32-bit VGPR offset
     int ch = TICKET ? 0 : blockIdx.y;
@@ -126,10 +137,17 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
     // The swizzle keeps every access conflict-free AND makes each stage rewrite exactly the cells
     // it has just read, which removes the three write-after-read barriers (7 -> 4 per transform)
     // at the price of one v_xor per access in the two middle exchanges.
-    const unsigned base_a = SWZ ? ((t & ~15u) | ((t ^ (t >> 4)) & 15u)) : t;   // + 272 k2
+    const unsigned base_a = WP ? (t >> 6) * WP_REGION + (t & 63u)
+                               : (SWZ ? ((t & ~15u) | ((t ^ (t >> 4)) & 15u)) : t);   // + row_a(k2)
     unsigned base_b = hi * LDS_K2_STRIDE + lo;                   // SWZ: (base_b ^ a) + 16 a
     unsigned base_c = hi * LDS_K2_STRIDE + lo * LDS_K1_STRIDE;   // SWZ: base_c ^ n0
-    auto cell_b1 = [&](int a1) -> unsigned { return SWZ ? ((base_b ^ (unsigned)a1) + 16u * a1) : base_b + 16u * a1; };
+    const unsigned base_w = (hi & 7u) * WP_PITCH + (hi >> 3) * 64u + lo;      // WP: row hi of column lo (+ 16 n1)
+    // offset of row r in the first / last layout, relative to the thread's column
+    auto row_a = [](int r) -> unsigned { return WP ? (unsigned)((r & 7) * WP_PITCH + (r >> 3) * 64) : (unsigned)(r * LDS_K2_STRIDE); };
+    auto cell_b1 = [&](int a1) -> unsigned {
+        if (WP) return base_w + (unsigned)((a1 >> 2) * WP_REGION + 16 * (a1 & 3));     // column lo + 16 a1 of row hi
+        return SWZ ? ((base_b ^ (unsigned)a1) + 16u * a1) : base_b + 16u * a1;
+    };
     auto cell_b2 = [&](int a1) -> unsigned { return SWZ ? ((base_b ^ (unsigned)a1) + 16u * a1) : base_b + (unsigned)LDS_K1_STRIDE * a1; };
     auto cell_c = [&](int n0) -> unsigned { return SWZ ? (base_c ^ (unsigned)n0) : base_c + n0; };
     // Called before each group of swizzled accesses: makes the base opaque there, so the 16
@@ -292,6 +310,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
     // 272*row + 128*half -- the [n2][t] cells F1 reads.  M0 = the piece's LDS byte address.
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) v2f *)lds;
     const unsigned wv = __builtin_amdgcn_readfirstlane(t >> 6), lane16 = (t & 63u) * 16u;
+    const unsigned lane_wp = ((t >> 5) & 1u) * (8u * 256u * 8u) + (t & 31u) * 16u;    // WP: row +8 for the upper half-wave
     auto interior = [&](long long blk) -> bool {
         if constexpr (DIAG & 1) return false;
         const long long base = blk * a.advance - a.hl - a.shift;
@@ -301,9 +320,16 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         const char *g = chan + (blk * a.advance - a.hl - a.shift) * 8;      // uniform
 #pragma unroll
         for (int p = 0; p < 8; p++) {
-            const unsigned row = 4u * wv + (p >> 1), half = p & 1;
-            const unsigned dst = lds_base + (row * LDS_K2_STRIDE + half * 128u) * 8u;
-            const unsigned off = (row * 256u + half * 128u) * 8u + lane16;
+            unsigned dst, off;
+            if constexpr (WP) {
+                // piece p of wave wv: rows p (lanes 0-31) and p + 8 (lanes 32-63) of columns 64 wv .. 64 wv + 63
+                dst = lds_base + (wv * WP_REGION + (unsigned)p * WP_PITCH) * 8u;
+                off = ((unsigned)p * 256u + 64u * wv) * 8u + lane_wp;
+            } else {
+                const unsigned row = 4u * wv + (p >> 1), half = p & 1;
+                dst = lds_base + (row * LDS_K2_STRIDE + half * 128u) * 8u;
+                off = (row * 256u + half * 128u) * 8u + lane16;
+            }
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(off), "s"(g), "s"(dst) : "memory");
@@ -340,9 +366,9 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             // 15 youngest vector-memory operations retires them and leaves the stores in flight
             if (counted) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            lds_barrier();       // every wave's pieces have landed
+            if (!WP) lds_barrier();       // every wave's pieces have landed (WP: this wave's own are all it reads)
 #pragma unroll
-            for (int r = 0; r < 16; r++) nx[r] = lds[base_a + r * LDS_K2_STRIDE];
+            for (int r = 0; r < 16; r++) nx[r] = lds[base_a + row_a(r)];
         } else if (!PREFETCH) load_rows(nx, blk);
         // ---- F1: over n2, twiddle W_4096^(t k2), scatter to [k2][t]
         dft16<-1>(nx);
@@ -352,7 +378,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             if ((k >> 2) && (k & 3)) x = cmul2(x, q1[k >> 2], p1[k & 3]);
             else if (k >> 2) x = cmul(x, q1[k >> 2]);
             else if (k & 3) x = cmul(x, p1[k & 3]);
-            lds[base_a + k * LDS_K2_STRIDE] = x;
+            lds[base_a + row_a(k)] = x;
         }
         lds_barrier();
         unsigned drawn = 0;
@@ -427,7 +453,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         // ---- I3: gather k2 for n_lo = t
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            v2f x = lds[base_a + r * LDS_K2_STRIDE];
+            v2f x = lds[base_a + row_a(r)];
             if ((r >> 2) && (r & 3)) x = cmul2_conj(x, q1[r >> 2], p1[r & 3]);
             else if (r >> 2) x = cmul_conj(x, q1[r >> 2]);
             else if (r & 3) x = cmul_conj(x, p1[r & 3]);
@@ -435,8 +461,10 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         }
         if constexpr (DMA) {
             // all I3 reads done -> the buffer is free: request the next transform's rows NOW, under
-            // this transform's last DFT16 and its stores
-            lds_barrier();
+            // this transform's last DFT16 and its stores (WP: this wave's reads of its own region
+            // are all that has to be done -- lgkmcnt, no barrier)
+            if (WP) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else lds_barrier();
             landed = more && interior(nb);
             if (landed) dma_rows(in_of(nch), nb);
             counted = landed && !OUT_TX10 && row0 == 1 && blk * a.advance + a.advance <= a.n;
@@ -802,11 +830,11 @@ int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in
     if (ev && in_complex && out_complex && !in_u8 && !out_tx10) {
         // round-1 kernels: fixed-stride walk, register loads  <waves><p|n>[s][h]
 #define SFE_STATIC(W, PF, SW, HR, DG) SFE_K2(true, true, W, PF, SW, HR, false, false, false, false, DG, false)
-        // D = LDS-DMA + fixed stride, T = tickets + register loads, X = tickets + LDS-DMA (the product kernel)
-#define SFE_NEW(DM, TK, DG) do { if (TK) SFE_K(true, true, 4, false, false, true, false, false, false, DM, DG, TK); \
-                                 else SFE_K2(true, true, 4, false, false, true, false, false, false, DM, DG, TK); } while (0)
-#define SFE_NEW_DG(DM, TK) do { if (diag == 1) SFE_NEW(DM, TK, 1); else if (diag == 2) SFE_NEW(DM, TK, 2); \
-                                else if (diag == 3) SFE_NEW(DM, TK, 3); else SFE_NEW(DM, TK, 0); } while (0)
+        // D = LDS-DMA + fixed stride, T = tickets + register loads, X = tickets + LDS-DMA, W = X + wave-private layout
+#define SFE_NEW(DM, TK, DG, WPV) do { if (TK) SFE_K(true, true, 4, false, false, true, false, false, false, DM, DG, TK, false, WPV); \
+                                 else SFE_K2(true, true, 4, false, false, true, false, false, false, DM, DG, TK, false, WPV); } while (0)
+#define SFE_NEW_DG(DM, TK, WPV) do { if (diag == 1) SFE_NEW(DM, TK, 1, WPV); else if (diag == 2) SFE_NEW(DM, TK, 2, WPV); \
+                                else if (diag == 3) SFE_NEW(DM, TK, 3, WPV); else SFE_NEW(DM, TK, 0, WPV); } while (0)
         bool done = true;
         if (ev[0] == 'c') hipLaunchKernelGGL((fir_copy_pattern_kernel<4>), grid2, block, 0, s, a);
         else if (ev[0] == 'd') hipLaunchKernelGGL((fir_copy_pattern16_kernel<4>), grid2, block, 0, s, a);
@@ -816,9 +844,10 @@ int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in
         else if (ev[0] == 'g') hipLaunchKernelGGL((fir_copy_pattern_dma_kernel<4, true>), grid2, block, 0, s, a);
         else if (ev[0] == 'G') hipLaunchKernelGGL((fir_copy_pattern_dma_kernel<4, false>), grid2, block, 0, s, a);
         else if (ev[0] == 'p') hipLaunchKernelGGL((fir_copy_pattern_pipe_kernel<4>), grid2, block, 0, s, a);
-        else if (ev[0] == 'D') SFE_NEW_DG(true, false);
-        else if (ev[0] == 'T') SFE_NEW_DG(false, true);
-        else if (ev[0] == 'X') SFE_NEW_DG(true, true);
+        else if (ev[0] == 'D') SFE_NEW_DG(true, false, false);
+        else if (ev[0] == 'T') SFE_NEW_DG(false, true, false);
+        else if (ev[0] == 'X') SFE_NEW_DG(true, true, false);
+        else if (ev[0] == 'W') SFE_NEW_DG(true, true, true);           // + wave-private first/last layout
         else if (ev[0] == '4' && diag) {                                                           // ablations of "4n.h"
             if (diag == 1) SFE_STATIC(4, false, false, true, 1);
             else if (diag == 2) SFE_STATIC(4, false, false, true, 2);
