@@ -54,8 +54,9 @@ static_assert(pf_swz(7) < 16, "the swizzle must stay inside a row of 16");
 // constants, bit 1 = output stores folded into one never-taken store, bit 2 = no spectrum stage.
 // TICKET: passes are drawn from per-XCD work counters instead of walked at a fixed stride
 // (fir_fft.hip has the reasoning and the measurements); single-channel launches only.
-// LATE (diagnostic): the next pass's samples are requested after S3 instead of before it.
-template <int SP, int UP, int R, bool IN_U8, bool PAIR, int DIAG = 0, bool TICKET = false, bool LATE = false, int WPS = 4>
+// LATE (diagnostic): 1 = the next pass's samples are requested after S3 instead of before it,
+// 2 = the first half of its segments before S3 and the second half after.
+template <int SP, int UP, int R, bool IN_U8, bool PAIR, int DIAG = 0, bool TICKET = false, int LATE = 0, int WPS = 4>
 __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
 {
     constexpr int F = R * SP, I = R * UP;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
     };
     // the R*SP*256 staged samples of a pass, thread t: sample t + 256 i of each segment.  PAIR:
     // transform (pass*R + sg) carries real segments 2*(pass*R + sg) in .x and the next one in .y.
-    auto load_pass = [&](v2f (&s)[R * SP], long long pass) {
+    auto load_pass = [&](v2f (&s)[R * SP], long long pass, int sg_lo = 0, int sg_hi = R) {
         if constexpr (DIAG & 1) {       // ablation: no input loads
             unsigned u = t + ((unsigned)pass << 12);
             asm volatile("" : "+v"(u));
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
         }
 #pragma unroll
         for (int sg = 0; sg < R; sg++) {
+            if (sg < sg_lo || sg >= sg_hi) continue;
             // stream index of the segment's staged sample 0 (uniform)
             const long long sidx = (pass * R + sg) * (PAIR ? 2 : 1);
             const long long start = (sidx * a.V - a.ovl) * SP + a.e_max - (SP - 1);
@@ -346,14 +348,16 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
         }
         // request the next pass's samples now: v[] is dead, they land while S3 and the barrier run
         // (requesting them a whole pass ahead instead measured the same: latency is not what binds)
-        auto request_next = [&]() {
+        auto request_next = [&](int sg_lo, int sg_hi) {
             if (next < a.n_pass) {
                 cur_wide = pass_is_wide(next);
-                if (cur_wide) load_pass_wide(raw, next);
-                else if (!WIDE) load_pass(s, next);
+                if (cur_wide) {
+                    if (sg_lo == 0) load_pass_wide(raw, next);
+                } else if (!WIDE) load_pass(s, next, sg_lo, sg_hi);
             }
         };
-        if (!LATE) request_next();
+        if (LATE == 0) request_next(0, R);
+        if (LATE == 2) request_next(0, (R + 1) / 2);
         // ---- S3: bin t of every segment of this pass
         if (cur && !(DIAG & 4)) {
 #pragma unroll
@@ -370,13 +374,14 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
             }
         }
         lds_barrier();
-        if (LATE) request_next();
+        if (LATE == 1) request_next(0, R);
+        if (LATE == 2) request_next((R + 1) / 2, R);
         prev = cur ? pass : -1;
         pass = next;
     }
 }
 
-template <int SP, int UP, int R, bool IN_U8, bool PAIR, int DIAG = 0, bool TICKET = false, bool LATE = false, int WPS = 4>
+template <int SP, int UP, int R, bool IN_U8, bool PAIR, int DIAG = 0, bool TICKET = false, int LATE = 0, int WPS = 4>
 int launch_one(const PolyFftArgs &a0, int n_channels, hipStream_t s)
 {
     PolyFftArgs a = a0;
@@ -448,11 +453,12 @@ int launch_poly_fft(const PolyFftPlan &plan, const PolyFftArgs &a0, int data_com
     // SFE_RS_VARIANT: s = fixed-stride walk (round 1), t = tickets (the product's single-channel kernel), l = tickets + late request
     if (const char *e = getenv("SFE_RS_VARIANT")) {
         if (plan.SP == 5 && plan.UP == 3 && data_complex && !in_u8 && n_channels == 1) {
-            if (e[0] == 's') return launch_one<5, 3, 2, false, false, 0, false, false>(a, n_channels, s);
-            if (e[0] == 't') return launch_one<5, 3, 2, false, false, 0, true, false>(a, n_channels, s);
-            if (e[0] == 'l') return launch_one<5, 3, 2, false, false, 0, true, true>(a, n_channels, s);
-            if (e[0] == 'L') return launch_one<5, 3, 2, false, false, 0, false, true>(a, n_channels, s);
-            if (e[0] == 'w') return launch_one<5, 3, 2, false, false, 0, true, false, 3>(a, n_channels, s);     // 3 workgroups per CU, 168 VGPRs: no spill
+            if (e[0] == 's') return launch_one<5, 3, 2, false, false, 0, false, 0>(a, n_channels, s);
+            if (e[0] == 't') return launch_one<5, 3, 2, false, false, 0, true, 0>(a, n_channels, s);
+            if (e[0] == 'l') return launch_one<5, 3, 2, false, false, 0, true, 1>(a, n_channels, s);
+            if (e[0] == 'L') return launch_one<5, 3, 2, false, false, 0, false, 1>(a, n_channels, s);
+            if (e[0] == 'h') return launch_one<5, 3, 2, false, false, 0, true, 2>(a, n_channels, s);         // half before S3, half after
+            if (e[0] == 'w') return launch_one<5, 3, 2, false, false, 0, true, 0, 3>(a, n_channels, s);     // 3 workgroups per CU, 168 VGPRs: no spill
         }
     }
 #endif
