@@ -19,15 +19,15 @@ for wl, (key, ksub, alg) in KEYS.items():
     d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{wl}")
     if not os.path.isdir(d):
         continue
-    ks = glob.glob(d + "/kt/**/*_kernel_stats.csv", recursive=True)
+    ks = sorted(glob.glob(d + "/kt/**/*_kernel_stats.csv", recursive=True), key=os.path.getmtime)
     if ks:
-        shutil.copy(ks[0], os.path.join(ROOT, "profiles", tag, f"{wl}_kernel_stats.csv"))
+        shutil.copy(ks[-1], os.path.join(ROOT, "profiles", tag, f"{wl}_kernel_stats.csv"))       # the latest collection
     vals, rows_out = {}, []
     for c in ("fetch", "write"):
-        f = glob.glob(d + f"/{c}/**/*_counter_collection.csv", recursive=True)
+        f = sorted(glob.glob(d + f"/{c}/**/*_counter_collection.csv", recursive=True), key=os.path.getmtime)
         if not f:
             continue
-        for r in csv.DictReader(open(f[0])):
+        for r in csv.DictReader(open(f[-1])):
             rows_out.append({k: r[k] for k in ("Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size",
                                                "VGPR_Count", "SGPR_Count", "Counter_Name", "Counter_Value",
                                                "Start_Timestamp", "End_Timestamp")})
@@ -51,9 +51,9 @@ for wl, (key, ksub, alg) in KEYS.items():
 
 # the driver's command shape, SQ counter summaries and the tables
 d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_default")
-ks = glob.glob(d + "/kt/**/*_kernel_stats.csv", recursive=True)
+ks = sorted(glob.glob(d + "/kt/**/*_kernel_stats.csv", recursive=True), key=os.path.getmtime)
 if ks:
-    shutil.copy(ks[0], os.path.join(ROOT, "profiles", tag, "default_line_kernel_stats.csv"))
+    shutil.copy(ks[-1], os.path.join(ROOT, "profiles", tag, "default_line_kernel_stats.csv"))
 for wl in ("fir", "resample"):
     f = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_sq_{wl}", "summary.txt")
     if os.path.exists(f):
