@@ -93,6 +93,12 @@ int sfe_dsp_synth_fill(void *dptr, uint64_t n_floats, uint32_t seed, uint32_t ch
  *   device        HIP device ordinal. */
 int sfe_dsp_fir_create(const float *taps, int n_taps, int taps_complex, int data_complex,
                        int n_channels, int block_hint, int device, sfe_fir_t *out);
+/* Host-only (no GPU): how a tap count is served by the 4096-point kernel -- the overlap of one
+ * transform (a multiple of 256), the number of tap partitions (one launch each; 1 for any filter
+ * a single transform overlaps economically, i.e. up to ~2800 taps) and the samples a transform
+ * advances.  The reference's analogue is the caller's choice of fft_len (blkconv.cxx:47-48:
+ * blk = fft_len + 1 - n_taps); here it is chosen by cost.  SFE_ERANGE beyond 1024 partitions. */
+int sfe_dsp_fir_plan(int n_taps, int *overlap, int *partitions, int *advance);
 /* Replaces get_process_buf()/get_blksize()  libdsp/blkconv.h:40-47: a pinned host buffer
  * owned by the handle, stable for its lifetime; the caller writes and reads [0, blk). */
 int sfe_dsp_fir_host_buffer(sfe_fir_t h, float **buf, int *blk);

@@ -892,6 +892,20 @@ int sfe_dsp_fir_create(const float *taps, int n_taps, int taps_complex, int data
     return SFE_OK;
 }
 
+int sfe_dsp_fir_plan(int n_taps, int *overlap, int *partitions, int *advance)
+{
+    if (n_taps < 1) return SFE_EINVAL;
+    int o = 0, p = 0;
+    if (!fir_choose_partition(n_taps, &o, &p)) {
+        set_error("fir_plan: %d taps exceed %d partitions of the 4096-point kernel", n_taps, FIR_MAX_PARTS);
+        return SFE_ERANGE;
+    }
+    if (overlap) *overlap = o;
+    if (partitions) *partitions = p;
+    if (advance) *advance = FFT_N - o;
+    return SFE_OK;
+}
+
 int sfe_dsp_fir_host_buffer(sfe_fir_t h, float **buf, int *blk)
 {
     Fir *f = as_fir(h);

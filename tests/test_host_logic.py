@@ -263,3 +263,33 @@ def test_gr_adapters_follow_the_runtime_shared_pointer():
     r = subprocess.run(["g++", "-std=c++11", "-Wall", "-fsyntax-only", os.path.join(ROOT, "tests/host/test_gr_sptr.cpp")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_fir_partition_plan():
+    """sfe_dsp_fir_plan (host-only): every tap count gets an overlap that is a multiple of 256 and
+    enough partitions to hold the taps; short filters stay one launch with the smallest overlap;
+    the cost per output sample (launches / advance) never jumps the way a single 4096-point
+    transform's does near 3841 taps."""
+    from simplefe_amd import lib
+    L = lib.load()
+    o, p, a = C.c_int(), C.c_int(), C.c_int()
+
+    def plan(n):
+        assert L.sfe_dsp_fir_plan(n, C.byref(o), C.byref(p), C.byref(a)) == lib.SFE_OK
+        return o.value, p.value, a.value
+    assert plan(1) == (256, 1, 3840) and plan(256) == (256, 1, 3840) and plan(257) == (256, 1, 3840)
+    assert plan(258) == (512, 1, 3584) and plan(551)[1] == 1 and plan(2001) == (2048, 1, 2048)
+    prev = 0.0
+    for n in sorted(list(range(1, 9000, 37)) + [3841, 3842, 4096, 8192, 65536, 245765, 1 << 20]):
+        ov, parts, adv = plan(n)
+        assert ov % 256 == 0 and 256 <= ov < 4096 and adv == 4096 - ov
+        assert (parts == 1 and n <= ov + 1) or (parts > 1 and parts * ov >= n)
+        cost = (parts + 0.25 * (parts - 1)) / adv
+        single = 1.0 / (4096 - 256 * ((max(n - 1, 1) + 255) // 256)) if n <= 3841 else float("inf")
+        assert cost <= single * (1 + 1e-12)
+        if n > 1 and n < 9000:
+            assert cost >= prev * 0.999          # longer filters never get cheaper
+        if n < 9000:
+            prev = cost
+    assert plan(3841)[1] == 2 and plan(3841)[0] == 2048
+    assert L.sfe_dsp_fir_plan(5_000_000, None, None, None) == lib.SFE_ERANGE
