@@ -21,7 +21,8 @@ BEFORE anything touches the GPU and relays rank 0's line.  It never prints an n_
                 with HIP events on the launch stream inside the timed region; `traffic` is the
                 PMC-measured HBM bytes per launch from profiles/ (null if no pass was recorded).
 `other_configs` (N = 1, default workload) the other BASELINE.json configs at G = 1, each a short
-                timed leg of its own with parity: resample 5/3 (configs[2]), decimate by 8
+                timed leg of its own with parity: resample 5/3 (configs[2], in both readings of
+                "127-tap polyphase arm": the 381-tap prototype and the 127-tap prototype), decimate by 8
                 (configs[3]), the 64-channel FIR on one GPU (configs[4] at G = 1) and the
                 complex-tap FIR.  They run BEFORE the headline's warm-up so the
                 headline's timed steps sit on the chip's sustained clock, not on the power
@@ -304,14 +305,18 @@ def make_fir_leg(ctx, name, taps, log2n, nch, algo="auto", in_fmt="f32", out_fmt
     return leg
 
 
-def make_rs_leg(ctx, which, log2n, in_fmt="f32"):
+def make_rs_leg(ctx, which, log2n, in_fmt="f32", short_proto=False):
     torch, api, lib, synth = ctx["torch"], ctx["api"], ctx["lib"], ctx["synth"]
     dev, stream, L = ctx["dev"], ctx["stream"], ctx["L"]
     leg = Leg()
     leg.name, leg.kind = which, "rs"
     n = 1 << log2n
     leg.n, leg.nch, leg.n_gpu = n, 1, n
-    if which == "resample":
+    if which == "resample" and short_proto:
+        taps, U, S = synth.taps_cfg3_short(), 3, 5
+        leg.workload = "rational resample 5/3, 127-tap prototype (43 per arm), 2^%d cf32 in" % log2n
+        leg.key = "resample5o3_127_cf32_2p%d" % log2n
+    elif which == "resample":
         taps, U, S = synth.taps_cfg3(), 3, 5
         leg.workload = "rational resample 5/3, 381-tap prototype (127 per arm), 2^%d cf32 in" % log2n
         leg.key = "resample5o3_cf32_2p%d" % log2n
@@ -338,7 +343,7 @@ def make_rs_leg(ctx, which, log2n, in_fmt="f32"):
     if in_fmt == "u8":
         leg.obj.set_input_format(lib.FMT_U8)
     # the library picks the transform-domain kernel for long filters on cf32 streams (api.hip: get_fft_plan)
-    leg.kernel = "poly_fft256_kernel" if which == "resample" and os.environ.get("SFE_RS_FFT", "") != "0" else "poly_tiled_kernel"
+    leg.kernel = "poly_fft256_kernel" if which == "resample" and not short_proto and os.environ.get("SFE_RS_FFT", "") != "0" else "poly_tiled_kernel"
     leg.k_before = 0          # outputs produced by all calls before the most recent one
     leg.n_out = 0
     leg.calls = 0
@@ -473,7 +478,7 @@ def main():
     if world == 1 and wl == "fir" and not args.no_others and args.input == "f32" and args.output == "f32" \
             and args.algo == "auto" and not args.log2n and not args.channels:
         tr, ti = synth.complex_taps(256, 0.2)
-        others = [make_rs_leg(ctx, "resample", 28), make_rs_leg(ctx, "decimate", 30),
+        others = [make_rs_leg(ctx, "resample", 28), make_rs_leg(ctx, "resample", 28, short_proto=True), make_rs_leg(ctx, "decimate", 30),
                   make_fir_leg(ctx, "fir_64ch", synth.taps_cfg2(), 30, 64),
                   make_fir_leg(ctx, "fir_ctaps", (tr + 1j * ti).astype(np.complex64), 28, 1, x_share=head.x)]
     other_rows = []

@@ -25,7 +25,9 @@ t = api.Timer()
 res = {v: [] for v in variants}
 for k in range(rounds + 1):
     for v in variants:
-        os.environ["SFE_RS_VARIANT"] = v
+        vv = v.split(":")                                  # t:8 = grid of 8 x the resident workgroups
+        os.environ["SFE_RS_VARIANT"] = vv[0]
+        os.environ["SFE_RS_WG_FACTOR"] = vv[1] if len(vv) > 1 else "2"
         t.start()
         for _ in range(5):
             r.process_stream(x, n, y, cap, 5.0 / 3.0)

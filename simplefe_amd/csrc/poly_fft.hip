@@ -393,9 +393,15 @@ int launch_one(const PolyFftArgs &a0, int n_channels, hipStream_t s)
             return hip_fail(hipGetLastError(), "poly_fft occupancy");
         resident = cus * per_cu;
     }
-    // persistent workgroups, two per resident slot (1, 2, 3, 4, 8 measured within noise of each
-    // other), shared over the channels
-    long long cap = (2LL * resident + n_channels - 1) / n_channels;
+    // persistent workgroups, shared over the channels
+    // fixed-stride walk: two workgroups per resident slot (1, 2, 3, 4, 8 measured within noise of each
+    // other); work counters: exactly the resident count -- any further workgroup would start when
+    // the counters are already exhausted and only pay its prologue (grid x1 0.701, x2 0.714, x4 0.723 ms)
+    long long factor = TICKET ? 1 : 2;
+#ifdef SFE_DIAG
+    if (const char *e = getenv("SFE_RS_WG_FACTOR")) factor = atoi(e) > 0 ? atoi(e) : factor;
+#endif
+    long long cap = (factor * resident + n_channels - 1) / n_channels;
     if (cap < 1) cap = 1;
     dim3 grid((unsigned)(a.n_pass < cap ? a.n_pass : cap), (unsigned)n_channels);
     if (TICKET) {

@@ -73,6 +73,12 @@ def taps_cfg3():
     return lowpass_taps(381, 0.18, gain=3.0)
 
 
+def taps_cfg3_short():
+    """The other reading of configs[2]: a 127-tap PROTOTYPE for U=3 (43 taps per
+    polyphase arm), same cutoff and gain."""
+    return lowpass_taps(127, 0.18, gain=3.0)
+
+
 def taps_cfg4():
     return lowpass_taps(64, 0.9 / 8.0)
 
