@@ -47,6 +47,38 @@ constexpr int PF_AREA = 272;      // cells per lane group: 16 rows of 17 (exchan
 __host__ __device__ constexpr unsigned pf_swz(unsigned c) { return c < 4 ? 4u * c : 2u + 4u * (c - 4); }
 static_assert(pf_swz(7) < 16, "the swizzle must stay inside a row of 16");
 
+// Round 2: for the coalesced scatter (thread t stages sample t + 256 i) an ADDITIVE rotation inside
+// the row of 16 makes it conflict-free where the XOR cannot: sample j = SP k + c goes to cell
+// (k + rot(c)) mod 16 of its row, and rot is chosen so that this equals a j mod 16 with a odd -- 16
+// consecutive lanes then hit 16 different cells.  For odd SP a = SP^-1 mod 16 (rot(c) = a c); the even
+// ones were found by search.  The XOR form left every 16-lane ds_write_b64 group of the 5/3 shape
+// 2-way conflicted: SQ_LDS_BANK_CONFLICT = 160 cycles per pass = 9.8 % of the kernel's LDS cycles
+// (profiles/r02/resample_sq_counters.txt: 18.6 M = 116 207 passes x 160, to the count).  The u8
+// wide-lane scatter (8 consecutive samples per lane) keeps the XOR form: under the rotation its
+// lanes would fall 8 deep on two cells.
+template <int SP> struct PfRot;
+template <> struct PfRot<1> { static constexpr unsigned v[1] = {0}; };
+template <> struct PfRot<2> { static constexpr unsigned v[2] = {0, 8}; };
+template <> struct PfRot<3> { static constexpr unsigned v[3] = {0, 11, 6}; };
+template <> struct PfRot<4> { static constexpr unsigned v[4] = {0, 4, 8, 12}; };
+template <> struct PfRot<5> { static constexpr unsigned v[5] = {0, 13, 10, 7, 4}; };
+template <> struct PfRot<6> { static constexpr unsigned v[6] = {0, 8, 3, 11, 6, 14}; };
+template <> struct PfRot<7> { static constexpr unsigned v[7] = {0, 7, 14, 5, 12, 3, 10}; };
+template <> struct PfRot<8> { static constexpr unsigned v[8] = {0, 2, 4, 6, 8, 10, 12, 14}; };
+// cell (inside the group's area) of staged sample k of component c
+template <int SP, bool ROT>
+__device__ __forceinline__ unsigned pf_cell(unsigned c, unsigned k)
+{
+    if constexpr (ROT) {
+        unsigned r = 0;
+#pragma unroll
+        for (int q = 0; q < SP; q++) r = c == (unsigned)q ? PfRot<SP>::v[q] : r;
+        return (k & ~15u) | ((k + r) & 15u);
+    } else {
+        return k ^ pf_swz(c);
+    }
+}
+
 // PAIR (real data): the real and imaginary parts of a transform carry two CONSECUTIVE real
 // segments of the stream (the sub-filters are real, so they stay apart): a real stream costs
 // what a complex one does per sample pair.
@@ -89,7 +121,8 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
     const unsigned comp = is_fwd ? job % SP : job % UP;      // input component c' / output phase r
     const unsigned area = is_fwd ? job : (is_inv ? F + job : 15u);   // idle groups: a harmless area of their own
     unsigned cell0 = area * PF_AREA + l;                     // this lane's column of its job's area
-    unsigned cell_in = area * PF_AREA + (l ^ (is_fwd ? pf_swz(comp) : 0u));
+    constexpr bool ROT = !(IN_U8 && !PAIR && 32 * SP + 1 <= 256) && !(DIAG & 8);      // == !WIDE (defined below); DIAG bit 3: the round-1 XOR layout
+    unsigned cell_in = area * PF_AREA + (is_fwd ? pf_cell<SP, ROT>(comp, l) : l);
 
     constexpr int ISZ = (IN_U8 ? 2 : 8) / (PAIR ? 2 : 1);    // bytes per input sample
     constexpr int ESZ = PAIR ? 4 : 8;                         // bytes per float32 sample (history, output)
@@ -240,7 +273,7 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
                         const unsigned j = 8u * tt + e - (unsigned)delta;      // wraps for the samples before the start
                         if (j < 256u * SP) {
                             const unsigned c = j % SP, k = j / SP;
-                            lds[(sg * SP + c) * PF_AREA + (k ^ pf_swz(c))] = (v2f){u8_to_f32(w & 0xFFu), u8_to_f32((w >> 8) & 0xFFu)};
+                            lds[(sg * SP + c) * PF_AREA + pf_cell<SP, ROT>(c, k)] = (v2f){u8_to_f32(w & 0xFFu), u8_to_f32((w >> 8) & 0xFFu)};
                         }
                     }
                 }
@@ -249,12 +282,19 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
             if (WIDE) load_pass(s, pass);      // an edge pass of the wide variant: nothing was requested ahead
             unsigned tt = t;
             asm volatile("" : "+v"(tt));      // recompute the scatter cells here instead of keeping R*SP of them live
+            // low four bits of the cell: with the rotation they do not depend on i -- (k + rot(c)) mod 16
+            // = a j mod 16 = a t mod 16 for odd SP (256 i = 0 mod 16), and for SP = 2, 4, 8 both c and
+            // k mod 16 of sample t + 256 i are those of sample t
+            constexpr unsigned INV = SP == 3 ? 11u : SP == 5 ? 13u : SP == 7 ? 7u : 1u;      // SP^-1 mod 16
+            constexpr bool LOW_FIXED = ROT && (SP == 1 || SP == 2 || SP == 3 || SP == 4 || SP == 5 || SP == 7 || SP == 8);
+            const unsigned low = (SP & 1) ? (INV * tt) & 15u : pf_cell<SP, ROT>(tt % SP, tt / SP) & 15u;
 #pragma unroll
             for (int sg = 0; sg < R; sg++)
 #pragma unroll
                 for (int i = 0; i < SP; i++) {
                     const unsigned j = tt + 256u * i, c = j % SP, k = j / SP;
-                    lds[(sg * SP + c) * PF_AREA + (k ^ pf_swz(c))] = s[sg * SP + i];
+                    const unsigned cell = LOW_FIXED ? ((k & ~15u) | low) : pf_cell<SP, ROT>(c, k);
+                    lds[(sg * SP + c) * PF_AREA + cell] = s[sg * SP + i];
                 }
         }
         lds_barrier();
@@ -463,6 +503,7 @@ int launch_poly_fft(const PolyFftPlan &plan, const PolyFftArgs &a0, int data_com
             if (e[0] == 't') return launch_one<5, 3, 2, false, false, 0, true, 0>(a, n_channels, s);
             if (e[0] == 'l') return launch_one<5, 3, 2, false, false, 0, true, 1>(a, n_channels, s);
             if (e[0] == 'L') return launch_one<5, 3, 2, false, false, 0, false, 1>(a, n_channels, s);
+            if (e[0] == 'x') return launch_one<5, 3, 2, false, false, 8, true, 0>(a, n_channels, s);         // t with the round-1 XOR scatter layout
             if (e[0] == 'h') return launch_one<5, 3, 2, false, false, 0, true, 2>(a, n_channels, s);         // half before S3, half after
             if (e[0] == 'w') return launch_one<5, 3, 2, false, false, 0, true, 0, 3>(a, n_channels, s);     // 3 workgroups per CU, 168 VGPRs: no spill
         }
