@@ -10,7 +10,10 @@
  * Pinning status (see DESIGN.md "Oracle"):
  *   - orc_resample_* / orc_decimate_* : pinned BIT-EXACT against the unmodified
  *     reference sources compiled in place into oracle/_ref/ (tests/golden fixtures).
- *   - orc_blkconv_* : the reference's FFT arithmetic lives in FFTW 3.3.5 (libfftw3f),
+ *   - orc_blkconv_* : PARITY UNPINNED at the FFTW boundary (round-1 verdict: the hipFFTW-linked
+ *     reference build below counts as a stand-in library and pins nothing; no FFTW binary or
+ *     golden vector for blkconv exists in this image or in the reference tree).  What is checked:
+ *     the reference's FFT arithmetic lives in FFTW 3.3.5 (libfftw3f),
  *     which is not in this image and not vendored as source.  The reference class itself,
  *     blkconv.cxx unmodified, IS built -- against the reference's vendored fftw3.h and ROCm's
  *     libhipfftw.so (the FFTW3 API on hipFFT; runs on a GPU box only) -- and its outputs are
