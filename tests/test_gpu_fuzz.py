@@ -152,3 +152,47 @@ def test_blkconv_class_vs_compiled_reference_random(api, orc, seed):
             dst[off: off + blk] = b[:blk]
     assert synth.rel_rms(got, want) < 2e-6, (fft_len, n_taps)
     assert synth.rel_rms(rest, want) < 2e-6, (fft_len, n_taps)
+
+
+def test_two_thousand_launches_on_one_handle_keep_the_work_counters_clean(api, L):
+    """The FFT FIR kernel and the transform-domain resampler hand work to their persistent
+    workgroups through device counters that every launch must leave at zero (the launch's last
+    draw resets them).  2000 launches of random lengths -- one transform, fewer transforms than
+    counter groups, thousands of transforms; 1-3 channels -- on ONE handle each: the concatenated
+    outputs still equal one pass over the whole stream.  A counter left dirty would make the next
+    launch skip transforms."""
+    rng = np.random.default_rng(77)
+    taps = synth.taps_cfg2()
+    for nch in (1, 3):
+        lens = [int(v) for v in rng.choice([1, 17, 3839, 3840, 3841, 9000, 30721, 100000], size=1000)]
+        n = sum(lens)
+        x = np.stack([synth.synth_cf32(n, ch=30 + c) for c in range(nch)])
+        whole = api.Fir(taps, data_complex=True, n_channels=nch, algo=L.FIR_ALGO_FFT).filter(x)
+        f = api.Fir(taps, data_complex=True, n_channels=nch, algo=L.FIR_ALGO_FFT)
+        d_in = api.DeviceArray.from_numpy(x)
+        d_out = api.DeviceArray(2 * n * nch)
+        off = 0
+        for m in lens:                                       # every launch: its own slice of the resident stream
+            f.process_stream(d_in.ptr + 8 * off, d_out.ptr + 8 * off, m, in_stride=n, out_stride=n)
+            off += m
+        got = d_out.to_numpy().reshape(nch, 2 * n)
+        assert synth.rel_rms(got, whole) <= 2e-6
+        d_in.free()
+        d_out.free()
+    # the resampler's counters: 300 launches of the 5/3 shape, bulk default kernel
+    taps3 = synth.taps_cfg3()
+    lens = [int(v) for v in rng.choice([4096 * 5, 23105, 50000, 200000], size=300)]
+    n = sum(lens)
+    x = synth.synth_cf32(n, ch=40)
+    r0 = api.Rs(taps3, 3, 4096, mode=L.RS_RESAMPLE, data_complex=True)
+    whole = r0.resample_array(x[None, :], 5.0 / 3.0)[0]
+    r = api.Rs(taps3, 3, 4096, mode=L.RS_RESAMPLE, data_complex=True)
+    d_in = api.DeviceArray.from_numpy(x)
+    d_out = api.DeviceArray(2 * (n * 3 // 5 + 16))
+    off = k = 0
+    for m in lens:
+        k += r.process_stream(d_in.ptr + 8 * off, m, d_out.ptr + 8 * k, m * 3 // 5 + 8, 5.0 / 3.0)
+        off += m
+    assert abs(k - len(whole) // 2) <= 1
+    got = d_out.to_numpy(2 * min(k, len(whole) // 2))
+    assert synth.rel_rms(got, whole[: len(got)]) <= 2e-6
