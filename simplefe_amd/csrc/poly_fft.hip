@@ -179,21 +179,37 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
             // stream index of the segment's staged sample 0 (uniform)
             const long long sidx = (pass * R + sg) * (PAIR ? 2 : 1);
             const long long start = (sidx * a.V - a.ovl) * SP + a.e_max - (SP - 1);
-            const long long span = (long long)PF_M * SP + (PAIR ? (long long)a.V * SP : 0);
-            if (start >= 0 && start + span <= a.n_in) {
-                const char *p = in_c + start * ISZ;
+            // interior passes only (pass_interior): edge passes are staged straight into LDS in S0,
+            // so that their guarded 64-bit addressing is never live beside the prefetched samples and
+            // the spectra registers (it cost 14 spilled VGPRs in EVERY pass, round 1)
+            const char *p = in_c + start * ISZ;
 #pragma unroll
-                for (int i = 0; i < SP; i++) {
-                    s[sg * SP + i] = load_in(p, t + 256u * i);
-                    if constexpr (PAIR) s[sg * SP + i].y = load_in(p + (long long)a.V * SP * ISZ, t + 256u * i).x;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < SP; i++) {
-                    const long long idx = start + (long long)(t + 256u * i);
-                    s[sg * SP + i] = load_guarded(idx);
-                    if constexpr (PAIR) s[sg * SP + i].y = load_guarded(idx + (long long)a.V * SP).x;
-                }
+            for (int i = 0; i < SP; i++) {
+                s[sg * SP + i] = load_in(p, t + 256u * i);
+                if constexpr (PAIR) s[sg * SP + i].y = load_in(p + (long long)a.V * SP * ISZ, t + 256u * i).x;
+            }
+        }
+    };
+    auto pass_interior = [&](long long pass) -> bool {
+        if constexpr (DIAG & 1) return true;
+        const long long s0 = ((pass * R) * (PAIR ? 2 : 1) * a.V - a.ovl) * SP + a.e_max - (SP - 1);
+        const long long s1 = ((pass * R + R - 1) * (PAIR ? 2 : 1) * a.V - a.ovl) * SP + a.e_max - (SP - 1);
+        const long long span = (long long)PF_M * SP + (PAIR ? (long long)a.V * SP : 0);
+        return s0 >= 0 && s1 + span <= a.n_in;
+    };
+    // an edge pass (history in front, ragged end): every staged sample guarded, one at a time, into its cell
+    auto stage_edge_pass = [&](long long pass, auto cell_of) {
+#pragma unroll 1
+        for (int sg = 0; sg < R; sg++) {
+            const long long sidx = (pass * R + sg) * (PAIR ? 2 : 1);
+            const long long start = (sidx * a.V - a.ovl) * SP + a.e_max - (SP - 1);
+#pragma unroll 1
+            for (int i = 0; i < SP; i++) {
+                const unsigned j = t + 256u * i;
+                const long long idx = start + (long long)j;
+                v2f v = load_guarded(idx);
+                if constexpr (PAIR) v.y = load_guarded(idx + (long long)a.V * SP).x;
+                lds[(sg * SP + j % SP) * PF_AREA + cell_of(j % SP, j / SP)] = v;
             }
         }
     };
@@ -250,11 +266,15 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
     // workgroups read one compact window of the stream.  Giving each workgroup a contiguous run of
     // passes instead (so the overlap re-read hits L2) measured 8 % SLOWER: a thousand separate
     // read/write streams cost HBM more than the 5 % of re-read bytes they save.
-    bool cur_wide = false;
+    bool cur_wide = false;      // this pass's samples were requested ahead: as wide raw lanes (WIDE) ...
+    bool cur_fast = false;      // ... or as per-sample registers s[] (interior pass of a non-WIDE kernel)
     if (first < a.n_pass) {
         cur_wide = pass_is_wide(first);
         if (cur_wide) load_pass_wide(raw, first);
-        else if (!WIDE) load_pass(s, first);
+        else if (!WIDE) {
+            cur_fast = pass_interior(first);
+            if (cur_fast) load_pass(s, first);
+        }
     }
     for (long long pass = first;;) {
         const bool cur = pass < a.n_pass;
@@ -278,8 +298,10 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
                     }
                 }
             }
+        } else if (cur && !cur_fast) {
+            // an edge pass: nothing was requested ahead
+            stage_edge_pass(pass, [](unsigned c, unsigned k) { return pf_cell<SP, ROT>(c, k); });
         } else if (cur) {
-            if (WIDE) load_pass(s, pass);      // an edge pass of the wide variant: nothing was requested ahead
             unsigned tt = t;
             asm volatile("" : "+v"(tt));      // recompute the scatter cells here instead of keeping R*SP of them live
             // low four bits of the cell: with the rotation they do not depend on i -- (k + rot(c)) mod 16
@@ -393,7 +415,12 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
                 cur_wide = pass_is_wide(next);
                 if (cur_wide) {
                     if (sg_lo == 0) load_pass_wide(raw, next);
-                } else if (!WIDE) load_pass(s, next, sg_lo, sg_hi);
+                } else if (!WIDE) {
+                    cur_fast = pass_interior(next);
+                    if (cur_fast) load_pass(s, next, sg_lo, sg_hi);
+                }
+            } else {
+                cur_wide = cur_fast = false;
             }
         };
         if (LATE == 0) request_next(0, R);
