@@ -511,6 +511,9 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         const long long obase = blk * a.advance - a.hl;   // uniform; + 256*row + t
         constexpr int OSZ = OUT_C ? 8 : 4;
         const bool whole = blk * a.advance + a.advance <= a.n;
+        char *const obase_p = out_c + obase * OSZ;           // uniform
+        unsigned voff = t * OSZ;
+        asm volatile("" : "+v"(voff));                       // keep the row offsets in the vector register, not in scalar pointers
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const long long orow = obase + 256 * r;          // uniform
@@ -531,13 +534,17 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             if constexpr (DIAG & 2) continue;      // ablation: no output stores (folded below)
             if (r >= row0 && (whole || orow + (long long)t < a.n)) {
                 v2f y = v[P16(r)];
-                char *rp = out_c + orow * OSZ;               // uniform row pointer
+                // ONE uniform base for the transform + a per-lane byte offset that steps by a row: fifteen
+                // separate 64-bit row pointers would sit in 30 scalar registers across the store burst
+                // (the LDS-DMA kernel only: its eight landing addresses already fill the scalar file; the
+                // register-load kernels measured 5 % slower this way)
+                char *rp = DMA ? obase_p + (voff + (unsigned)(256 * r * OSZ)) : out_c + orow * OSZ + (size_t)t * OSZ;
                 if constexpr (OUT_C) {
-                    if constexpr (ACC) y += reinterpret_cast<const v2f *>(rp)[t];
-                    __builtin_nontemporal_store(y, reinterpret_cast<v2f *>(rp) + t);
+                    if constexpr (ACC) y += *reinterpret_cast<const v2f *>(rp);
+                    __builtin_nontemporal_store(y, reinterpret_cast<v2f *>(rp));
                 } else {
-                    if constexpr (ACC) y.x += reinterpret_cast<const float *>(rp)[t];
-                    __builtin_nontemporal_store(y.x, reinterpret_cast<float *>(rp) + t);
+                    if constexpr (ACC) y.x += *reinterpret_cast<const float *>(rp);
+                    __builtin_nontemporal_store(y.x, reinterpret_cast<float *>(rp));
                 }
             }
         }
