@@ -25,13 +25,15 @@ tail -1 $O/kt.log | cut -c1-200
 # SQ / LDS / TCC counters of the two transform kernels
 cd $R
 bash scripts/prof_pmc.sh prof_${TAG}_sq_fir fir_fft4096 -- python3 $R/bench.py --workload fir --steps 3 --warmup 1 --no-cpu --no-others > /dev/null 2>&1 || exit 1
+bash scripts/prof_pmc.sh prof_${TAG}_sq_decimate poly_tiled -- python3 $R/bench.py --workload decimate --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1 || exit 1
 bash scripts/prof_pmc.sh prof_${TAG}_sq_resample poly_fft256 -- python3 $R/bench.py --workload resample --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1 || exit 1
 # ablation / variant tables from the diagnostic library (regenerable: scripts/ablate.py, scripts/ab_fir.py, scripts/ab_rs.py)
 mkdir -p $R/gpurun_out/prof_${TAG}_tables
 timeout -k 10 300 python3 scripts/ablate.py fir > gpurun_out/prof_${TAG}_tables/fir_variants_ab.txt 2>&1 || exit 1
 timeout -k 10 300 python3 scripts/ablate.py resample > gpurun_out/prof_${TAG}_tables/resample_fft_ablation.txt 2>&1 || exit 1
-ROUNDS=8 timeout -k 10 300 python3 scripts/ab_fir.py 4n.h D T X e:8 E e:300 > gpurun_out/prof_${TAG}_tables/fir_walk_vs_tickets.txt 2>&1 || exit 1
-timeout -k 10 300 python3 scripts/ab_rs.py s t l w > gpurun_out/prof_${TAG}_tables/resample_walk_vs_tickets.txt 2>&1 || exit 1
+ROUNDS=8 timeout -k 10 300 python3 scripts/ab_fir.py 4n.h D T X W e:8 E e:300 > gpurun_out/prof_${TAG}_tables/fir_walk_vs_tickets.txt 2>&1 || exit 1
+ROUNDS=8 timeout -k 10 300 python3 scripts/ab_fir.py e:8 b:8 g:8 G:8 e:300 b:300 g:300 > gpurun_out/prof_${TAG}_tables/fir_pattern_sync.txt 2>&1 || exit 1
+timeout -k 10 300 python3 scripts/ab_rs.py s t x l w > gpurun_out/prof_${TAG}_tables/resample_walk_vs_tickets.txt 2>&1 || exit 1
 timeout -k 10 120 scripts/probes/hbm_mix > gpurun_out/prof_${TAG}_tables/hbm_mix.txt 2>&1
 timeout -k 10 200 python3 scripts/time_pipe.py > gpurun_out/prof_${TAG}_tables/host_pipe.txt 2>&1
 echo collected

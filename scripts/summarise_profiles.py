@@ -54,7 +54,7 @@ d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_default")
 ks = sorted(glob.glob(d + "/kt/**/*_kernel_stats.csv", recursive=True), key=os.path.getmtime)
 if ks:
     shutil.copy(ks[-1], os.path.join(ROOT, "profiles", tag, "default_line_kernel_stats.csv"))
-for wl in ("fir", "resample"):
+for wl in ("fir", "resample", "decimate"):
     f = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_sq_{wl}", "summary.txt")
     if os.path.exists(f):
         shutil.copy(f, os.path.join(ROOT, "profiles", tag, f"{wl}_sq_counters.txt"))
