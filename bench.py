@@ -287,9 +287,9 @@ def make_fir_leg(ctx, name, taps, log2n, nch, algo="auto", in_fmt="f32", out_fmt
                 else:
                     ref_r, ref_i = blk(tr, xr)[hlen:], blk(tr, xi)[hlen:]
                 if out_fmt == "tx10":
-                    # integer output: compare the packed bytes with the oracle's packing of the
-                    # GPU's own float result is not available here, so pack the oracle's floats and
-                    # count bytes that differ (a float that rounds across a code boundary moves 1 LSB)
+                    # packed 10-bit output: the oracle's floats are packed by the oracle's converter and the
+                    # bytes compared; the figure is the fraction of bytes that differ (a sample that sits
+                    # on a quantiser step can land one code apart: the two float32 FFTs round differently)
                     ref = np.empty(2 * W, np.float32)
                     ref[0::2], ref[1::2] = ref_r, ref_i
                     want = orc.tx_f32_to_10bit(ref)
