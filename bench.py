@@ -12,7 +12,8 @@ N > 1: one rank per GPU, every rank filters its own 8 independent channels of 2^
 the channel-sharded configs[4] shape, same per-GPU sample count, no data-path collective; the
 only cross-rank traffic is the barrier, the MAX of the elapsed time and of the worst parity
 figure, and the SUM of the per-rank output checksums {samples, sum re, sum im, sum |y|^2}
-(RCCL).  Started under torch.distributed.run the ranks are taken from the
+(RCCL); after the timed region the ranks also cut ONE stream into spans, exchange
+the 256-sample span tails and check the seams (`split_stream`).  Started under torch.distributed.run the ranks are taken from the
 environment; started bare (`python bench.py --gpus 4`) this script launches the N ranks itself
 BEFORE anything touches the GPU and relays rank 0's line.  It never prints an n_gpus=1 line for
 --gpus N > 1: a world size that does not match --gpus is an error.
@@ -428,6 +429,59 @@ def checksum(ctx, leg):
     return [float(leg.n_out * leg.nch), sre, sim, sq]
 
 
+def split_stream_check(ctx, taps):
+    """N > 1 only, outside every timed region: ONE stream cut into one span per rank (SURVEY.md 8(e)
+    row 3).  The ranks exchange the last 256 samples of their spans (an all-gather of 2 KiB per rank:
+    the path's one real exchange step; shard.halo_from_left is the point-to-point form), each loads
+    its left neighbour's as its handle's history and filters its span; the first window of every
+    span -- the samples that depend on the halo -- is checked against the oracle on the uncut
+    stream.  Never fatal and never one-sided: both collectives are reached by every rank whatever
+    happened locally, and a failure is reported in the line."""
+    import torch.distributed as dist
+    torch, api, synth, shard = ctx["torch"], ctx["api"], ctx["synth"], ctx["shard"]
+    L, dev, stream, rank, world = ctx["L"], ctx["dev"], ctx["stream"], ctx["rank"], ctx["world"]
+    n_total, HL, W = world << 22, 256, 4096
+    first, count = shard.span_block(n_total, world, rank, quantum=3840)
+    on_gpu = dist.get_backend() == "nccl"
+    cdev = dev if on_gpu else torch.device("cpu")
+    err, worst, x = None, float("inf"), None
+    tail = torch.zeros(2 * HL, dtype=torch.float32, device=cdev)
+    try:
+        x = torch.empty(2 * count, dtype=torch.float32, device=dev)
+        api.check(L.sfe_dsp_synth_fill(x.data_ptr(), 2 * count, synth.SEED, 77, 2 * first, stream))
+        torch.cuda.synchronize()
+        tail = x[-2 * HL:].to(cdev).contiguous()
+    except Exception as e:
+        err = "%s: %s" % (type(e).__name__, e)
+    tails = torch.zeros(world * 2 * HL, dtype=torch.float32, device=cdev)
+    dist.all_gather_into_tensor(tails, tail)                   # collective 1: every rank, always
+    try:
+        if err is None:
+            from oracle import binding as orc
+            f = api.Fir(taps, data_complex=True, device=ctx["local_rank"])
+            if rank > 0:
+                halo = tails[(rank - 1) * 2 * HL: rank * 2 * HL].to(dev).contiguous()
+                f.load_history(halo.data_ptr(), HL, stream=stream)
+            y = torch.empty(2 * count, dtype=torch.float32, device=dev)
+            f.process_stream(x.data_ptr(), y.data_ptr(), count, stream=stream)
+            torch.cuda.synchronize()
+            lo = max(0, first - (len(taps) - 1))
+            seg = synth.synth_cf32(first + W - lo, ch=77, first_sample=lo)      # the uncut stream around the cut
+            got = y[: 2 * W].cpu().numpy()
+            worst = 0.0
+            for part in (0, 1):
+                ref = orc.Blkconv(taps, 4096).stream(np.ascontiguousarray(seg[part::2]))[first - lo:]
+                worst = max(worst, synth.rel_rms(got[part::2], ref))
+    except Exception as e:
+        err, worst = "%s: %s" % (type(e).__name__, e), float("inf")
+    worst = shard.max_over_ranks(worst, ctx["red_dev"])       # collective 2: every rank, always
+    out = {"ok": bool(worst <= TOL), "rel_rms_max": worst if worst != float("inf") else None, "samples": n_total,
+           "spans": world, "halo_samples": HL, "exchange": "all-gather of the span tails (%s)" % dist.get_backend()}
+    if err:
+        out["error"] = err
+    return out
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -526,6 +580,8 @@ def main():
     }
     if other_rows:
         out["other_configs"] = other_rows
+    if world > 1 and head.kind == "fir" and not np.iscomplexobj(head.taps):
+        out["split_stream"] = split_stream_check(ctx, head.taps)
     if rank == 0 and world == 1 and not args.no_cpu:
         if head.kind == "fir":
             out["cpu_baseline"] = cpu_baseline_fir(np.real(head.taps).astype(np.float32), args.cpu_seconds)

@@ -34,6 +34,8 @@ def test_bench_gpus2_from_a_bare_shell_starts_two_ranks_and_checks_both():
     assert j2["n_gpus"] == 2 and j2["config"]["channels_per_gpu"] == 8
     assert j2["parity"]["ok"] and j2["parity"]["ranks_checked"] == 2 and j2["parity"]["windows"] == 8
     assert j2["checksum"]["samples"] == 2 * (1 << 22)
+    # one stream cut across the two ranks, halo exchanged point to point: the seam matches the uncut stream
+    assert j2["split_stream"]["ok"] and j2["split_stream"]["spans"] == 2, j2["split_stream"]
     r1, j1 = _bench("--gpus", "1", "--log2n", "23", "--channels", "16", "--steps", "3", "--warmup", "1", "--no-cpu")
     assert r1.returncode == 0, r1.stdout + r1.stderr
     assert j1["n_gpus"] == 1 and j1["checksum"]["samples"] == j2["checksum"]["samples"]
