@@ -8,10 +8,11 @@
 // hardware endpoints of a flowgraph; these are the filters that sit between them:
 //     simplefe::source_c -> gr::sfe::fir_ccf / decimate_ccf / rational_resampler_ccf -> simplefe::sink_c
 //
-// fir_ccf / fir_fff batch: the scheduler's few-thousand-item calls are collected into GPU-sized
-// pinned batches and up to four batches are in flight on three streams (sfe_dsp_fir_pipe_*), so a
-// call costs a memcpy, not a launch + two PCIe round trips.  They are gr::block's (general_work):
-// item k out is the filter's output for item k in, but it may come out a few calls later.
+// All of them batch: the scheduler's few-thousand-item calls are collected into GPU-sized pinned
+// batches and up to four batches are in flight on three streams (sfe_dsp_fir_pipe_* /
+// sfe_dsp_rs_pipe_*), so a call costs a memcpy, not a launch + two PCIe round trips.  They are
+// gr::block's (general_work): the output stream is exactly the reference classes', but an item may
+// come out a few calls after the inputs it depends on went in.
 // fir_ccf_sync / fir_fff_sync keep the one-round-trip-per-call sync_block form.
 #ifndef GR_SFE_BLOCKS_H_
 #define GR_SFE_BLOCKS_H_
@@ -142,124 +143,141 @@ typename fir_xxf_sync<CPLX>::sptr fir_xxf_sync<CPLX>::make(const std::vector<flo
 typedef fir_xxf_sync<true> fir_ccf_sync;
 typedef fir_xxf_sync<false> fir_fff_sync;
 
-// ------------------------------------------------------------------------------- decimation
-// Integer decimation by D with an anti-alias FIR: the `decimate` class at rate D, upsample 1
-// (libdsp/decimate.cxx:69-129).  A sync_decimator: work() consumes D*noutput_items inputs.
-// CPLX: gr_complex items (decimate_ccf) or float items (decimate_fff).
+// ------------------------------------------------------- decimation / rational resampling, batched
+// One pipe-backed block serves both classes: `decimate` at integer rate D with upsample 1
+// (libdsp/decimate.cxx:69-129) and `resample` at rate decim/interp with upsample = interp
+// (libdsp/resample.cxx:85-153).  gr::block's (general_work): the scheduler's calls are collected into
+// pinned batches of whole blksize-sample reference calls, four batches in flight
+// (sfe_dsp_rs_pipe_create); exact mode, so the items are the reference classes' bit for bit.
 template <bool CPLX>
-class decimate_xxf : virtual public gr::sync_decimator
+class rs_block_impl_base
+{
+protected:
+    rs_block_impl_base() : d_h(0), d_p(0) {}
+    ~rs_block_impl_base()
+    {
+        if (d_p) sfe_dsp_pipe_destroy(d_p);
+        if (d_h) sfe_dsp_rs_destroy(d_h);
+    }
+    void open(const std::vector<float> &taps, int upsample, int mode, float rate, int batch_items, int device, const char *what)
+    {
+        check(sfe_dsp_rs_create(taps.data(), (int)taps.size(), upsample, 4096, CPLX ? 1 : 0, 1, device, mode, &d_h), what);
+        check(sfe_dsp_rs_set_exact(d_h, 1), what);
+        check(sfe_dsp_rs_pipe_create(d_h, (size_t)(batch_items > 0 ? batch_items : 0), rate, &d_p), what);
+    }
+    // push what came in, pull what is finished; without progress wait for the oldest batch, or -- when
+    // the upstream has nothing for us -- send the partial batch on its way (end of stream / slow source)
+    int pump(int noutput_items, int ninput, const void *in, void *out, int *consumed, const char *what)
+    {
+        size_t taken = 0, got = 0;
+        if (ninput > 0) check(sfe_dsp_pipe_push(d_p, in, (size_t)ninput, &taken), what);
+        check(sfe_dsp_pipe_pull(d_p, out, (size_t)noutput_items, 0, &got), what);
+        if (taken == 0 && got == 0) check(sfe_dsp_pipe_pull(d_p, out, (size_t)noutput_items, ninput > 0 ? 1 : 2, &got), what);
+        *consumed = (int)taken;
+        return (int)got;
+    }
+    bool pending() const
+    {
+        size_t n = 0;
+        sfe_dsp_pipe_pending(d_p, &n);
+        return n != 0;
+    }
+    sfe_rs_t d_h;
+    sfe_pipe_t d_p;
+};
+
+// Integer decimation by D with an anti-alias FIR.  CPLX: gr_complex items (decimate_ccf) or float
+// items (decimate_fff).
+template <bool CPLX>
+class decimate_xxf : virtual public gr::block
 {
 public:
     typedef typename sptr_of<decimate_xxf>::type sptr;
-    static sptr make(const std::vector<float> &taps, unsigned decimation, int max_items = 1 << 16, int device = 0);
+    static sptr make(const std::vector<float> &taps, unsigned decimation, int batch_items = 0, int device = 0);
+    virtual unsigned decimation() const = 0;
 };
 
 template <bool CPLX>
-class decimate_xxf_impl : public decimate_xxf<CPLX>
+class decimate_xxf_impl : public decimate_xxf<CPLX>, private rs_block_impl_base<CPLX>
 {
 public:
-    decimate_xxf_impl(const std::vector<float> &taps, unsigned d, int max_items, int device)
-        : gr::sync_decimator(CPLX ? "sfe_decimate_ccf" : "sfe_decimate_fff",
-                             gr::io_signature::make(1, 1, CPLX ? sizeof(gr_complex) : sizeof(float)),
-                             gr::io_signature::make(1, 1, CPLX ? sizeof(gr_complex) : sizeof(float)), d),
-          d_h(0), d_blk(max_items), d_D(d)
+    decimate_xxf_impl(const std::vector<float> &taps, unsigned d, int batch_items, int device)
+        : gr::block(CPLX ? "sfe_decimate_ccf" : "sfe_decimate_fff",
+                    gr::io_signature::make(1, 1, CPLX ? sizeof(gr_complex) : sizeof(float)),
+                    gr::io_signature::make(1, 1, CPLX ? sizeof(gr_complex) : sizeof(float))), d_D(d)
     {
-        check(sfe_dsp_rs_create(taps.data(), (int)taps.size(), 1, max_items, CPLX ? 1 : 0, 1, device, SFE_RS_DECIMATE, &d_h), "decimate");
+        this->set_relative_rate(1.0 / d);
+        this->open(taps, 1, SFE_RS_DECIMATE, (float)d, batch_items, device, "decimate");
     }
-    ~decimate_xxf_impl() { sfe_dsp_rs_destroy(d_h); }
+    unsigned decimation() const { return d_D; }
 
-    int work(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &output_items)
+    void forecast(int noutput_items, gr_vector_int &req)
     {
-        const size_t W = CPLX ? 2 : 1;          // floats per item
-        const float *in = static_cast<const float *>(input_items[0]);
-        float *out = static_cast<float *>(output_items[0]);
-        int produced = 0, n_in = noutput_items * (int)d_D;
-        // the class call takes at most blksize inputs (decimate.cxx:79-82): feed it in pieces
-        for (int off = 0; off < n_in; off += d_blk) {
-            const int m = n_in - off < d_blk ? n_in - off : d_blk;
-            int n_out = 0;
-            check(sfe_dsp_rs_process(d_h, in + W * (size_t)off, m, out + W * (size_t)produced, noutput_items - produced + 1,
-                                     (float)d_D, &n_out), "decimate::work");
-            produced += n_out;
-        }
-        return produced;
+        for (size_t i = 0; i < req.size(); i++) req[i] = this->pending() ? 0 : (noutput_items > 0 ? 1 : 0);
+    }
+    int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
+                     gr_vector_void_star &output_items)
+    {
+        int consumed = 0;
+        const int got = this->pump(noutput_items, ninput_items[0], input_items[0], output_items[0], &consumed, "decimate::general_work");
+        this->consume_each(consumed);
+        return got;
     }
 
 private:
-    sfe_rs_t d_h;
-    int d_blk;
     unsigned d_D;
 };
 
 template <bool CPLX>
-typename decimate_xxf<CPLX>::sptr decimate_xxf<CPLX>::make(const std::vector<float> &taps, unsigned decimation, int max_items, int device)
+typename decimate_xxf<CPLX>::sptr decimate_xxf<CPLX>::make(const std::vector<float> &taps, unsigned decimation, int batch_items, int device)
 {
-    return typename decimate_xxf<CPLX>::sptr(new decimate_xxf_impl<CPLX>(taps, decimation, max_items, device));
+    return typename decimate_xxf<CPLX>::sptr(new decimate_xxf_impl<CPLX>(taps, decimation, batch_items, device));
 }
 typedef decimate_xxf<true> decimate_ccf;
 typedef decimate_xxf<false> decimate_fff;
 
-// ------------------------------------------------------------------------ rational resampler
-// `interp` outputs per `decim` inputs through a prototype designed at the upsampled rate -- the
-// `resample` class with upsample = interp, rate = decim/interp (libdsp/resample.cxx:85-153).
-// A general block: general_work() consumes what it is given.
+// `interp` outputs per `decim` inputs through a prototype designed at the upsampled rate.
 template <bool CPLX>
 class rational_resampler_xxf : virtual public gr::block
 {
 public:
     typedef typename sptr_of<rational_resampler_xxf>::type sptr;
-    static sptr make(unsigned interp, unsigned decim, const std::vector<float> &taps, int max_items = 1 << 16, int device = 0);
+    static sptr make(unsigned interp, unsigned decim, const std::vector<float> &taps, int batch_items = 0, int device = 0);
 };
 
 template <bool CPLX>
-class rational_resampler_xxf_impl : public rational_resampler_xxf<CPLX>
+class rational_resampler_xxf_impl : public rational_resampler_xxf<CPLX>, private rs_block_impl_base<CPLX>
 {
 public:
-    rational_resampler_xxf_impl(unsigned interp, unsigned decim, const std::vector<float> &taps, int max_items, int device)
+    rational_resampler_xxf_impl(unsigned interp, unsigned decim, const std::vector<float> &taps, int batch_items, int device)
         : gr::block(CPLX ? "sfe_rational_resampler_ccf" : "sfe_rational_resampler_fff",
                     gr::io_signature::make(1, 1, CPLX ? sizeof(gr_complex) : sizeof(float)),
-                    gr::io_signature::make(1, 1, CPLX ? sizeof(gr_complex) : sizeof(float))),
-          d_h(0), d_interp(interp), d_decim(decim), d_blk(max_items), d_rate((float)decim / (float)interp)
+                    gr::io_signature::make(1, 1, CPLX ? sizeof(gr_complex) : sizeof(float)))
     {
         this->set_relative_rate((double)interp / decim);
-        check(sfe_dsp_rs_create(taps.data(), (int)taps.size(), (int)interp, max_items, CPLX ? 1 : 0, 1, device, SFE_RS_RESAMPLE, &d_h),
-              "rational_resampler");
+        this->open(taps, (int)interp, SFE_RS_RESAMPLE, (float)decim / (float)interp, batch_items, device, "rational_resampler");
     }
-    ~rational_resampler_xxf_impl() { sfe_dsp_rs_destroy(d_h); }
 
     void forecast(int noutput_items, gr_vector_int &req)
     {
-        for (size_t i = 0; i < req.size(); i++) req[i] = (int)((long long)noutput_items * d_decim / d_interp) + 1;
+        for (size_t i = 0; i < req.size(); i++) req[i] = this->pending() ? 0 : (noutput_items > 0 ? 1 : 0);
     }
-
     int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
                      gr_vector_void_star &output_items)
     {
-        const float *in = static_cast<const float *>(input_items[0]);
-        float *out = static_cast<float *>(output_items[0]);
-        // take as many inputs as surely fit the output buffer
-        long long can = ((long long)(noutput_items - 1) * d_decim) / d_interp;
-        int n_in = ninput_items[0] < can ? ninput_items[0] : (int)can;
-        if (n_in > d_blk) n_in = d_blk;
-        if (n_in <= 0) { this->consume_each(0); return 0; }
-        int n_out = 0;
-        check(sfe_dsp_rs_process(d_h, in, n_in, out, noutput_items, d_rate, &n_out), "rational_resampler::general_work");
-        this->consume_each(n_in);
-        return n_out;
+        int consumed = 0;
+        const int got = this->pump(noutput_items, ninput_items[0], input_items[0], output_items[0], &consumed,
+                                   "rational_resampler::general_work");
+        this->consume_each(consumed);
+        return got;
     }
-
-private:
-    sfe_rs_t d_h;
-    unsigned d_interp, d_decim;
-    int d_blk;
-    float d_rate;
 };
 
 template <bool CPLX>
 typename rational_resampler_xxf<CPLX>::sptr rational_resampler_xxf<CPLX>::make(unsigned interp, unsigned decim, const std::vector<float> &taps,
-                                                                               int max_items, int device)
+                                                                               int batch_items, int device)
 {
-    return typename rational_resampler_xxf<CPLX>::sptr(new rational_resampler_xxf_impl<CPLX>(interp, decim, taps, max_items, device));
+    return typename rational_resampler_xxf<CPLX>::sptr(new rational_resampler_xxf_impl<CPLX>(interp, decim, taps, batch_items, device));
 }
 typedef rational_resampler_xxf<true> rational_resampler_ccf;
 typedef rational_resampler_xxf<false> rational_resampler_fff;

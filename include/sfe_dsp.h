@@ -145,6 +145,12 @@ int sfe_dsp_fir_set_algo(sfe_fir_t h, int algo);
  *         and block for it (end of stream / drain).
  *   pending  items pushed and not yet pulled. */
 int sfe_dsp_fir_pipe_create(sfe_fir_t fir, size_t batch_items, sfe_pipe_t *out);
+/* The same pipe over a single-channel float32 resample / decimate handle at a fixed `rate`
+ * ({resample,decimate}::process called chunk after chunk, resample.cxx:85-153): push takes input
+ * items, pull hands out the outputs of finished batches -- as many as the reference object would
+ * have produced for those inputs.  batch_items is rounded up to whole `blksize`-sample reference
+ * calls, so the result is the bulk call's (sfe_dsp_rs_process_stream, incl. sfe_dsp_rs_set_exact)
+ * for any rate.  Declared after sfe_rs_t below. */
 int sfe_dsp_pipe_push(sfe_pipe_t p, const void *in, size_t n_items, size_t *n_taken);
 int sfe_dsp_pipe_pull(sfe_pipe_t p, void *out, size_t max_items, int wait, size_t *n_got);
 int sfe_dsp_pipe_pending(sfe_pipe_t p, size_t *items);
@@ -222,6 +228,7 @@ int sfe_dsp_rs_set_input_format(sfe_rs_t h, int fmt);
 int sfe_dsp_rs_load_history(sfe_rs_t h, const void *d_prev, size_t n_prev, size_t stride,
                             sfe_stream_t stream);
 int sfe_dsp_rs_seek(sfe_rs_t h, uint64_t first_sample, float rate);
+int sfe_dsp_rs_pipe_create(sfe_rs_t rs, size_t batch_items, float rate, sfe_pipe_t *out);
 int sfe_dsp_rs_reset(sfe_rs_t h);
 int sfe_dsp_rs_destroy(sfe_rs_t h);
 

@@ -1705,12 +1705,16 @@ static void copy_stream(void *dst, const void *src, size_t n)
 constexpr int PIPE_SLOTS = 4;
 struct FirPipe {
     uint32_t magic = 0x50495031u;   // 'PIP1'
-    Fir *f = nullptr;
-    size_t batch = 0, in_e = 0, out_e = 0;
+    Fir *f = nullptr;               // the filter behind the pipe ...
+    void *rs = nullptr;             // ... or the resampler / decimator (sfe_rs_t), at `rate`
+    float rate = 1.0f;
+    int device = 0;
+    size_t batch = 0, out_cap = 0, in_e = 0, out_e = 0;     // batch: input items per slot; out_cap: output items a slot can hold
     struct Slot {
         char *h_in = nullptr, *h_out = nullptr;
         void *d_in = nullptr, *d_out = nullptr;
         size_t n = 0;               // items submitted in this slot
+        size_t n_out = 0;           // items it produces (== n behind a filter)
         hipEvent_t ev_in = nullptr, ev_k = nullptr, ev_out = nullptr;
         bool busy = false;          // submitted and not yet fully pulled
     } slot[PIPE_SLOTS];
@@ -1736,7 +1740,7 @@ static void pipe_free(FirPipe *p)
 {
     if (!p) return;
     p->magic = 0;
-    DeviceGuard g(p->f ? p->f->device : 0);
+    DeviceGuard g(p->device);
     for (auto &sl : p->slot) {
         if (sl.h_in) (void)hipHostFree(sl.h_in);
         if (sl.h_out) (void)hipHostFree(sl.h_out);
@@ -1761,11 +1765,19 @@ static int pipe_submit(FirPipe *p)
     SFE_HIP(hipStreamWaitEvent(p->s_k, sl.ev_in, 0));
     // a slot's device buffers are reused PIPE_SLOTS batches later: by then its copy-out has been
     // waited for (the slot was pulled), so no further ordering is needed on s_k
-    int rc = fir_run(p->f, sl.d_in, sl.d_out, sl.n, sl.n, sl.n, p->s_k);
+    int rc;
+    if (p->f) {
+        rc = fir_run(p->f, sl.d_in, sl.d_out, sl.n, sl.n, sl.n, p->s_k);
+        sl.n_out = sl.n;
+    } else {
+        // the output count is known on the host as soon as the launch is made (closed form for
+        // integer-valued steps, the replayed float32 recurrence otherwise): the copy-out is sized by it
+        rc = sfe_dsp_rs_process_stream(p->rs, sl.d_in, sl.n, sl.n, sl.d_out, p->out_cap, p->out_cap, p->rate, &sl.n_out, p->s_k);
+    }
     if (rc != SFE_OK) return rc;
     SFE_HIP(hipEventRecord(sl.ev_k, p->s_k));
     SFE_HIP(hipStreamWaitEvent(p->s_out, sl.ev_k, 0));
-    SFE_HIP(hipMemcpyAsync(sl.h_out, sl.d_out, sl.n * p->out_e, hipMemcpyDeviceToHost, p->s_out));
+    if (sl.n_out) SFE_HIP(hipMemcpyAsync(sl.h_out, sl.d_out, sl.n_out * p->out_e, hipMemcpyDeviceToHost, p->s_out));
     SFE_HIP(hipEventRecord(sl.ev_out, p->s_out));
     sl.busy = true;
     p->head = (p->head + 1) % PIPE_SLOTS;
@@ -1775,6 +1787,27 @@ static int pipe_submit(FirPipe *p)
 }  // namespace sfe
 
 extern "C" {
+
+static int pipe_alloc(FirPipe *p, sfe_pipe_t *out)
+{
+    auto fail = [&](hipError_t e, const char *what) { int rc = hip_fail(e, what); pipe_free(p); return rc; };
+#define TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(e__, #call); } while (0)
+    TRY(hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking));
+    TRY(hipStreamCreateWithFlags(&p->s_k, hipStreamNonBlocking));
+    TRY(hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
+    for (auto &sl : p->slot) {
+        TRY(hipHostMalloc((void **)&sl.h_in, p->batch * p->in_e));
+        TRY(hipHostMalloc((void **)&sl.h_out, p->out_cap * p->out_e));
+        TRY(hipMalloc(&sl.d_in, p->batch * p->in_e));
+        TRY(hipMalloc(&sl.d_out, p->out_cap * p->out_e));
+        TRY(hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
+        TRY(hipEventCreateWithFlags(&sl.ev_k, hipEventDisableTiming));
+        TRY(hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming));
+    }
+#undef TRY
+    *out = p;
+    return SFE_OK;
+}
 
 int sfe_dsp_fir_pipe_create(sfe_fir_t fir, size_t batch_items, sfe_pipe_t *out)
 {
@@ -1794,26 +1827,44 @@ int sfe_dsp_fir_pipe_create(sfe_fir_t fir, size_t batch_items, sfe_pipe_t *out)
     FirPipe *p = new (std::nothrow) FirPipe;
     if (!p) return SFE_ENOMEM;
     p->f = f;
-    p->batch = batch_items;
+    p->device = f->device;
+    p->batch = p->out_cap = batch_items;
     p->in_e = f->data_complex ? 8 : 4;
     p->out_e = f->out_complex ? 8 : 4;
-    auto fail = [&](hipError_t e, const char *what) { int rc = hip_fail(e, what); pipe_free(p); return rc; };
-#define TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(e__, #call); } while (0)
-    TRY(hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking));
-    TRY(hipStreamCreateWithFlags(&p->s_k, hipStreamNonBlocking));
-    TRY(hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
-    for (auto &sl : p->slot) {
-        TRY(hipHostMalloc((void **)&sl.h_in, batch_items * p->in_e));
-        TRY(hipHostMalloc((void **)&sl.h_out, batch_items * p->out_e));
-        TRY(hipMalloc(&sl.d_in, batch_items * p->in_e));
-        TRY(hipMalloc(&sl.d_out, batch_items * p->out_e));
-        TRY(hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
-        TRY(hipEventCreateWithFlags(&sl.ev_k, hipEventDisableTiming));
-        TRY(hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming));
+    return pipe_alloc(p, out);
+}
+
+int sfe_dsp_rs_pipe_create(sfe_rs_t rs, size_t batch_items, float rate, sfe_pipe_t *out)
+{
+    if (!out) return SFE_EINVAL;
+    *out = nullptr;
+    Rs *r = as_rs(rs);
+    if (!r || r->n_channels != 1 || r->in_u8) {
+        set_error("rs_pipe_create: needs a single-channel float32 resample/decimate handle");
+        return SFE_EINVAL;
     }
-#undef TRY
-    *out = p;
-    return SFE_OK;
+    if (r->mode == SFE_RS_RESAMPLE ? (rate < 1.0 / r->U) : (rate < 1.0)) {
+        set_error("rs_pipe_create: rate %g not accepted by this mode", (double)rate);
+        return SFE_EINVAL;
+    }
+    if (batch_items == 0) batch_items = (size_t)1 << 18;
+    // whole reference calls per batch: for a non-integer step the result depends on where the
+    // blksize-sample calls fall (resample.cxx:85-153), and they must fall where they would without the pipe
+    batch_items = (batch_items + (size_t)r->blksize - 1) / (size_t)r->blksize * (size_t)r->blksize;
+    if (batch_items < 256 || batch_items > ((size_t)1 << 26)) {
+        set_error("rs_pipe_create: batch of %zu items out of range (256 .. 2^26)", batch_items);
+        return SFE_EINVAL;
+    }
+    SFE_ON_DEVICE(r->device);
+    FirPipe *p = new (std::nothrow) FirPipe;
+    if (!p) return SFE_ENOMEM;
+    p->rs = rs;
+    p->rate = rate;
+    p->device = r->device;
+    p->batch = batch_items;
+    p->out_cap = (size_t)ceil((double)batch_items / (double)rate) + 8;
+    p->in_e = p->out_e = (size_t)r->esz();
+    return pipe_alloc(p, out);
 }
 
 int sfe_dsp_pipe_push(sfe_pipe_t h, const void *in, size_t n_items, size_t *n_taken)
@@ -1821,7 +1872,7 @@ int sfe_dsp_pipe_push(sfe_pipe_t h, const void *in, size_t n_items, size_t *n_ta
     FirPipe *p = as_pipe(h);
     if (!p || !n_taken || (n_items && !in)) return SFE_EINVAL;
     *n_taken = 0;
-    SFE_ON_DEVICE(p->f->device);
+    SFE_ON_DEVICE(p->device);
     const char *src = static_cast<const char *>(in);
     while (n_items) {
         FirPipe::Slot &sl = p->slot[p->head];
@@ -1846,7 +1897,7 @@ int sfe_dsp_pipe_pull(sfe_pipe_t h, void *out, size_t max_items, int wait, size_
     FirPipe *p = as_pipe(h);
     if (!p || !n_got || (max_items && !out)) return SFE_EINVAL;
     *n_got = 0;
-    SFE_ON_DEVICE(p->f->device);
+    SFE_ON_DEVICE(p->device);
     char *dst = static_cast<char *>(out);
     bool block_now = wait != 0;          // wait == 1 blocks for the oldest batch only, wait == 2 for all of them
     while (max_items) {
@@ -1871,14 +1922,14 @@ int sfe_dsp_pipe_pull(sfe_pipe_t h, void *out, size_t max_items, int wait, size_
             }
             p->tail_ready = true;
         }
-        size_t m = sl.n - p->out_off;
+        size_t m = sl.n_out - p->out_off;
         if (m > max_items) m = max_items;
         copy_stream(dst, sl.h_out + p->out_off * p->out_e, m * p->out_e);
         dst += m * p->out_e;
         p->out_off += m;
         max_items -= m;
         *n_got += m;
-        if (p->out_off == sl.n) {
+        if (p->out_off == sl.n_out) {
             sl.busy = false;
             p->tail = (p->tail + 1) % PIPE_SLOTS;
             p->out_off = 0;
@@ -1894,7 +1945,7 @@ int sfe_dsp_pipe_pending(sfe_pipe_t h, size_t *items)
     if (!p || !items) return SFE_EINVAL;
     size_t n = p->fill;
     for (int i = 0; i < PIPE_SLOTS; i++)
-        if (p->slot[i].busy) n += p->slot[i].n - (i == p->tail ? p->out_off : 0);
+        if (p->slot[i].busy) n += p->slot[i].n_out - (i == p->tail ? p->out_off : 0);
     *items = n;
     return SFE_OK;
 }
@@ -1904,7 +1955,7 @@ int sfe_dsp_pipe_destroy(sfe_pipe_t h)
     FirPipe *p = as_pipe(h);
     if (!p) return SFE_OK;
     {
-        DeviceGuard g(p->f->device);
+        DeviceGuard g(p->device);
         (void)hipStreamSynchronize(p->s_in);
         (void)hipStreamSynchronize(p->s_k);
         (void)hipStreamSynchronize(p->s_out);

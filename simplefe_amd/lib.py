@@ -51,6 +51,7 @@ SIGNATURES = {
     "sfe_dsp_fir_process_host": (i32, [vp, vp, vp, sz]),
     "sfe_dsp_fir_set_algo": (i32, [vp, i32]),
     "sfe_dsp_fir_pipe_create": (i32, [vp, sz, C.POINTER(vp)]),
+    "sfe_dsp_rs_pipe_create": (i32, [vp, sz, f32, C.POINTER(vp)]),
     "sfe_dsp_pipe_push": (i32, [vp, vp, sz, C.POINTER(sz)]),
     "sfe_dsp_pipe_pull": (i32, [vp, vp, sz, i32, C.POINTER(sz)]),
     "sfe_dsp_pipe_pending": (i32, [vp, C.POINTER(sz)]),

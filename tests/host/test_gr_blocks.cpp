@@ -27,45 +27,43 @@ static std::vector<float> slurp(const char *p)
 
 static const int sizes[] = {4096, 1000, 8191, 37, 16384};     // what a scheduler hands out
 
-template <class Block, int W>
-static std::vector<float> run_decimate(const std::vector<float> &taps, const std::vector<float> &x, unsigned D)
+// a pipe-backed rate-changing block driven the way the scheduler would: whatever input is left (at most
+// one call size), room for one call size of outputs; after the input ends, input-less calls until a
+// call produces nothing
+template <int W, class Sptr>
+static std::vector<float> run_rate_block(Sptr b, const std::vector<float> &x, size_t out_estimate)
 {
     const int n = (int)(x.size() / W);
-    typename Block::sptr b = Block::make(taps, D, 4096);
-    std::vector<float> y(x.size() / D + 64);
-    int produced = 0, si = 0;
-    for (int off = 0; off + (int)D <= n;) {
-        int m = sizes[si++ % 5] / (int)D;                // output items this call
-        if (m < 1) m = 1;
-        if ((long long)m * D > n - off) m = (n - off) / (int)D;
+    std::vector<float> y(W * (out_estimate + 4096));
+    int off = 0, produced = 0, si = 0, idle = 0;
+    while (idle < 2) {
+        const int room = sizes[si++ % 5];
+        gr_vector_int req(1, 0);
+        b->forecast(room, req);
+        const int avail = n - off < room ? n - off : room;
+        if (avail < req[0]) break;                        // nothing pending and no input left
+        gr_vector_int nin(1, avail);
         gr_vector_const_void_star in(1, x.data() + W * (size_t)off);
         gr_vector_void_star out(1, y.data() + W * (size_t)produced);
-        produced += b->work(m, in, out);
-        off += m * (int)D;
+        const int r = b->general_work(room, nin, in, out);
+        off += b->consumed();
+        produced += r;
+        idle = (r == 0 && b->consumed() == 0 && off == n) ? idle + 1 : 0;
     }
     y.resize(W * (size_t)produced);
     return y;
 }
 
 template <class Block, int W>
+static std::vector<float> run_decimate(const std::vector<float> &taps, const std::vector<float> &x, unsigned D)
+{
+    return run_rate_block<W>(Block::make(taps, D, 8192), x, x.size() / W / D);
+}
+
+template <class Block, int W>
 static std::vector<float> run_resample(const std::vector<float> &taps, const std::vector<float> &x, unsigned D, unsigned I)
 {
-    const int n = (int)(x.size() / W);
-    typename Block::sptr b = Block::make(I, D, taps, 4096);
-    std::vector<float> y((size_t)((double)W * n * I / D) + 1024);
-    int produced = 0, si = 0;
-    for (int off = 0; off < n;) {
-        int room = sizes[si++ % 5];
-        gr_vector_int nin(1, n - off);
-        gr_vector_const_void_star in(1, x.data() + W * (size_t)off);
-        gr_vector_void_star out(1, y.data() + W * (size_t)produced);
-        int r = b->general_work(room, nin, in, out);
-        produced += r;
-        if (b->consumed() == 0 && r == 0) { if (room < 8) continue; }
-        off += b->consumed();
-    }
-    y.resize(W * (size_t)produced);
-    return y;
+    return run_rate_block<W>(Block::make(I, D, taps, 8192), x, (size_t)((double)(x.size() / W) * I / D));
 }
 
 // general_work the way the scheduler calls it: whatever input is left (at most `call` items), room

@@ -35,7 +35,7 @@ static_assert(std::is_convertible<rational_resampler_ccf::sptr, gr::basic_block_
 // virtual inheritance from the runtime's block types, abstract public classes, private impl
 static_assert(std::is_base_of<gr::block, fir_ccf>::value && std::is_abstract<fir_ccf>::value, "");
 static_assert(std::is_base_of<gr::sync_block, fir_ccf_sync>::value && std::is_abstract<fir_ccf_sync>::value, "");
-static_assert(std::is_base_of<gr::sync_decimator, decimate_ccf>::value && std::is_abstract<decimate_ccf>::value, "");
+static_assert(std::is_base_of<gr::block, decimate_ccf>::value && std::is_abstract<decimate_ccf>::value, "");
 static_assert(std::is_base_of<fir_ccf, fir_xxf_impl<true>>::value && !std::is_abstract<fir_xxf_impl<true>>::value, "");
 
 static void connect(gr::basic_block_sptr) {}

@@ -809,3 +809,42 @@ def test_fir_long_filter_u8_input_and_split(api, L):
     d2 = api.DeviceArray(2 * (n - cut))
     g.process_stream(api.DeviceArray.from_numpy(xf[2 * cut:]), d2, n - cut)
     assert synth.rel_rms(d2.to_numpy(), y[2 * cut:]) <= 2e-6
+
+
+@pytest.mark.parametrize("U,rate,blk,n_taps,mode", [(3, 5.0 / 3.0, 4096, 381, "resample"), (1, 8.0, 4096, 64, "decimate"),
+                                                    (4, 1.77, 128, 31, "resample"), (4, 0.77, 128, 31, "resample")])
+def test_rs_pipe_equals_the_reference_stream(api, L, orc, U, rate, blk, n_taps, mode):
+    """sfe_dsp_rs_pipe_*: scheduler-sized pushes, pinned batches of whole blksize-sample reference
+    calls, four in flight.  What comes out of pull -- in order, nothing lost at the end -- is bit for
+    bit what the reference object produces when fed the stream blksize samples at a time
+    (resample.cxx:85-153), for integer-valued and general rates alike."""
+    import ctypes as C
+    rng = np.random.default_rng(int(rate * 100))
+    taps = (rng.standard_normal(n_taps) / np.sqrt(n_taps) * U).astype(np.float32)
+    n = 150001
+    x = synth.synth_f32(n, ch=11)
+    r = api.Rs(taps, U, blk, mode=L.RS_RESAMPLE if mode == "resample" else L.RS_DECIMATE)
+    r.set_exact(True)
+    lib = L.load()
+    p = C.c_void_p()
+    api.check(lib.sfe_dsp_rs_pipe_create(r._h, 10000, rate, C.byref(p)))       # rounded up to whole blksize calls
+    out = np.zeros(int(n / min(rate, 1e9)) + 4096, np.float32)
+    taken, got = C.c_size_t(0), C.c_size_t(0)
+    off = k = 0
+    sizes = [4096, 1000, 8191, 37, 16384]
+    i = 0
+    while off < n:
+        m = min(sizes[i % 5], n - off)
+        i += 1
+        api.check(lib.sfe_dsp_pipe_push(p, x.ctypes.data + 4 * off, m, C.byref(taken)))
+        off += taken.value
+        api.check(lib.sfe_dsp_pipe_pull(p, out.ctypes.data + 4 * k, 5000, 0 if taken.value else 1, C.byref(got)))
+        k += got.value
+    while True:                                                                # drain
+        api.check(lib.sfe_dsp_pipe_pull(p, out.ctypes.data + 4 * k, 5000, 2, C.byref(got)))
+        if got.value == 0:
+            break
+        k += got.value
+    lib.sfe_dsp_pipe_destroy(p)
+    ref, _ = getattr(orc, "Resample" if mode == "resample" else "Decimate")(taps, U, blk).stream(x, rate)
+    assert 0 <= len(ref) - k <= 1 and np.array_equal(out[:k], ref[:k])
