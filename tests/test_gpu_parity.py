@@ -848,3 +848,33 @@ def test_rs_pipe_equals_the_reference_stream(api, L, orc, U, rate, blk, n_taps, 
     lib.sfe_dsp_pipe_destroy(p)
     ref, _ = getattr(orc, "Resample" if mode == "resample" else "Decimate")(taps, U, blk).stream(x, rate)
     assert 0 <= len(ref) - k <= 1 and np.array_equal(out[:k], ref[:k])
+
+
+def test_stream_entry_points_reject_bad_buffers(api, L):
+    """sfe_dsp_rs_process_stream has the checks the FIR entry has -- channel strides that
+    would let channels overwrite each other, pointers not aligned to their element, input and
+    output ranges that overlap (partially, not only d_in == d_out) -- and returns SFE_EINVAL before
+    anything is launched; the FIR entry rejects partial overlap too."""
+    import ctypes as C
+    lib = L.load()
+    taps = synth.taps_cfg4()
+    buf = api.DeviceArray(1 << 16)
+    n_out = C.c_size_t(0)
+
+    def rs_call(r, d_in, n_in, in_stride, d_out, out_cap, out_stride):
+        return lib.sfe_dsp_rs_process_stream(r._h, d_in, n_in, in_stride, d_out, out_cap, out_stride, 8.0, C.byref(n_out), None)
+    r2 = api.Rs(taps, 1, 4096, mode=L.RS_DECIMATE, data_complex=True, n_channels=2)
+    base = buf.ptr
+    assert rs_call(r2, base, 4096, 4000, base + (1 << 17), 600, 600) == L.SFE_EINVAL      # in_stride < n_in
+    assert rs_call(r2, base, 4096, 4096, base + (1 << 17), 600, 520) == L.SFE_EINVAL      # out_stride < out_cap
+    assert rs_call(r2, base + 4, 4096, 4096, base + (1 << 17), 600, 600) == L.SFE_EINVAL  # cf32 input not 8-byte aligned
+    assert rs_call(r2, base, 4096, 4096, base + (1 << 17) + 4, 600, 600) == L.SFE_EINVAL  # output not aligned
+    assert rs_call(r2, base, 4096, 4096, base + 8 * 8000, 600, 600) == L.SFE_EINVAL       # output starts inside the input range
+    assert rs_call(r2, base, 4096, 4096, base, 600, 600) == L.SFE_EINVAL                  # same buffer
+    assert rs_call(r2, base, 4096, 4096, base + (1 << 17), 600, 600) == L.SFE_OK and n_out.value == 512
+    f = api.Fir(synth.taps_cfg2(), data_complex=True)
+    assert lib.sfe_dsp_fir_process_stream(f._h, base, base + 8 * 1000, 4096, 4096, 4096, None) == L.SFE_EINVAL   # partial overlap
+    assert lib.sfe_dsp_fir_process_stream(f._h, base + 2, base + (1 << 17), 4096, 4096, 4096, None) == L.SFE_EINVAL
+    assert b"overlap" in lib.sfe_dsp_last_error() or b"aligned" in lib.sfe_dsp_last_error()
+    assert lib.sfe_dsp_fir_process_stream(f._h, base, base + (1 << 17), 4096, 4096, 4096, None) == L.SFE_OK
+    api.sync()
