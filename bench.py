@@ -528,13 +528,19 @@ def main():
         head = make_rs_leg(ctx, wl, args.log2n or (28 if wl == "resample" else 30), in_fmt=args.input)
 
     # ---- the other BASELINE configs at G = 1 (short legs; built and timed before the headline)
-    others = []
+    others, other_errors = [], []
     if world == 1 and wl == "fir" and not args.no_others and args.input == "f32" and args.output == "f32" \
             and args.algo == "auto" and not args.log2n and not args.channels:
         tr, ti = synth.complex_taps(256, 0.2)
-        others = [make_rs_leg(ctx, "resample", 28), make_rs_leg(ctx, "resample", 28, short_proto=True), make_rs_leg(ctx, "decimate", 30),
-                  make_fir_leg(ctx, "fir_64ch", synth.taps_cfg2(), 30, 64),
-                  make_fir_leg(ctx, "fir_ctaps", (tr + 1j * ti).astype(np.complex64), 28, 1, x_share=head.x)]
+        makers = [lambda: make_rs_leg(ctx, "resample", 28), lambda: make_rs_leg(ctx, "resample", 28, short_proto=True),
+                  lambda: make_rs_leg(ctx, "decimate", 30),
+                  lambda: make_fir_leg(ctx, "fir_64ch", synth.taps_cfg2(), 30, 64),
+                  lambda: make_fir_leg(ctx, "fir_ctaps", (tr + 1j * ti).astype(np.complex64), 28, 1, x_share=head.x)]
+        for mk in makers:      # an extra leg that cannot be set up is reported, never allowed to take the headline with it
+            try:
+                others.append(mk())
+            except Exception as e:
+                other_errors.append({"error": "%s: %s" % (type(e).__name__, e)})
     other_rows = []
     for leg in others:
         el, kms = time_leg(ctx, leg, args.other_steps, 15 if leg is others[0] else 3)   # the first leg also takes the chip through its start-up clock transient
@@ -578,8 +584,8 @@ def main():
         "checksum": {"samples": csum[0], "sum_re": csum[1], "sum_im": csum[2], "sum_abs2": csum[3],
                      "over": "all ranks' last output (float64 sums, all-reduced)"},
     }
-    if other_rows:
-        out["other_configs"] = other_rows
+    if other_rows or other_errors:
+        out["other_configs"] = other_rows + other_errors
     if world > 1 and head.kind == "fir" and not np.iscomplexobj(head.taps):
         out["split_stream"] = split_stream_check(ctx, head.taps)
     if rank == 0 and world == 1 and not args.no_cpu:
