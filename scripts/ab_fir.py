@@ -27,7 +27,11 @@ t = api.Timer()
 res = {v: [] for v in variants}
 for r in range(rounds + 1):
     for v in variants:
-        vd = v.split("+")
+        vq = v.split("%")                            # e:8%7 = loads/stores gated on bit 7 of the device clock
+        os.environ.pop("SFE_FIR_GATE", None)
+        if len(vq) > 1:
+            os.environ["SFE_FIR_GATE"] = vq[1]
+        vd = vq[0].split("+")
         os.environ["SFE_FIR_DIAG"] = vd[1] if len(vd) > 1 else "0"
         vg = vd[0].split("/")                        # X/16 = 16 ticket groups
         os.environ["SFE_FIR_TGROUPS"] = vg[1] if len(vg) > 1 else "8"

@@ -614,11 +614,33 @@ __global__ __launch_bounds__(256, WAVES) void fir_copy_pattern16_kernel(FirFftAr
     }
 }
 
-template <int WAVES, bool TICKET, bool BAR = false>
+// SFE_FIR_TRACE=<file>: per workgroup of the e / E pattern kernels {start, end (100 MHz ticks), transforms
+// done, XCC_ID, HW_ID} -- where and when the launch's work was done (scripts/probes/fir_trace.py)
+#define FIR_TRACE_WGS 163840
+__device__ unsigned long long g_fir_trace[5 * FIR_TRACE_WGS];
+__device__ unsigned long long g_fir_tdone[FIR_TRACE_WGS];
+__device__ unsigned long long g_fir_tclk[FIR_TRACE_WGS];        // the same instant on the shader clock (s_memtime)
+__device__ int g_fir_gate;         // SFE_FIR_GATE=k: loads only while bit k of the 100 MHz device clock is 0, stores while it is 1
+__device__ int g_fir_order;        // SFE_FIR_ORDER: 0 in address order, 1 reversed, 2 scattered (x 48271 mod the count)       // per transform: when its rows had landed and its stores were issued
+
+template <int WAVES, bool TICKET, bool BAR = false, bool TRACE = false>
 __global__ __launch_bounds__(256, WAVES) void fir_copy_pattern_nt_kernel(FirFftArgs a)
 {
     __shared__ unsigned s_next;
     const unsigned t = threadIdx.x;
+    const unsigned long long t_start = TRACE ? wall_clock64() : 0ull;
+    const int gate = TRACE ? g_fir_gate : 0;          // the gate and the order switch exist in the traced build only
+    const int order = TRACE ? g_fir_order : 0;
+    unsigned n_done = 0;
+    const unsigned wg_lin = blockIdx.x + blockIdx.y * gridDim.x;
+    auto leave = [&]() {
+        if (TRACE && t == 0 && wg_lin < FIR_TRACE_WGS) {
+            unsigned long long *r = g_fir_trace + 5ull * wg_lin;
+            r[0] = t_start; r[1] = wall_clock64(); r[2] = n_done;
+            r[3] = __builtin_amdgcn_s_getreg(20 | (3 << 11));      // XCC_ID[3:0]
+            r[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));      // HW_ID
+        }
+    };
     const int row0 = a.hl >> 8;
     const unsigned nblk32 = (unsigned)a.nblk;
     // (one address serves an atomic every ~13 ns -- 70 000 draws from ONE counter take as long as the
@@ -650,19 +672,32 @@ __global__ __launch_bounds__(256, WAVES) void fir_copy_pattern_nt_kernel(FirFftA
         } else if (blk >= a.nblk) break;
         const char *in_c = static_cast<const char *>(a.in) + (size_t)ch * a.in_stride * 8;
         char *out_c = static_cast<char *>(a.out) + (size_t)ch * a.out_stride * 8;
-        const long long base = blk * a.advance - a.hl;
+        long long pblk = blk;
+        if (order == 1) pblk = a.nblk - 1 - blk;
+        else if (order == 2) pblk = (long long)(((unsigned long long)blk * 48271ull) % (unsigned long long)a.nblk);
+        const long long base = pblk * a.advance - a.hl;
         unsigned drawn = 0;
         if (TICKET && t == 0) drawn = draw();
         if (base >= 0 && base + FFT_N <= a.n) {
             v2f v[16];
+            if (gate) while (((wall_clock64() >> gate) & 1ull) != 0ull) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
             for (int r = 0; r < 16; r++)
                 v[r] = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(in_c + (base + 256 * r) * 8) + t);
             if (BAR) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_barrier(); lds_barrier(); }
+            if (gate) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                while (((wall_clock64() >> gate) & 1ull) != 1ull) __builtin_amdgcn_s_sleep(1);
+            }
 #pragma unroll
             for (int r = 0; r < 16; r++)
                 if (r >= row0) __builtin_nontemporal_store(v[r], reinterpret_cast<v2f *>(out_c + (base + 256 * r) * 8) + t);
+            if (TRACE && t == 0 && v[15].x != 1.2345e38f) {
+                const unsigned long long lin = (unsigned long long)ch * nblk32 + (unsigned long long)blk;
+                if (lin < FIR_TRACE_WGS) { g_fir_tdone[lin] = wall_clock64(); g_fir_tclk[lin] = clock64(); }
+            }
         }
+        n_done++;
         if (TICKET) {
             if (t == 0) s_next = drawn;
             lds_barrier();
@@ -670,6 +705,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_copy_pattern_nt_kernel(FirFftA
             lds_barrier();
         } else blk += gridDim.x;
     }
+    leave();
 }
 
 // Diagnostic only (SFE_FIR_VARIANT=p): the 8-byte nontemporal pattern, software-pipelined -- the next
@@ -843,8 +879,19 @@ int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in
 #define SFE_NEW_DG(DM, TK, WPV) do { if (diag == 1) SFE_NEW(DM, TK, 1, WPV); else if (diag == 2) SFE_NEW(DM, TK, 2, WPV); \
                                 else if (diag == 3) SFE_NEW(DM, TK, 3, WPV); else SFE_NEW(DM, TK, 0, WPV); } while (0)
         bool done = true;
+        // SFE_FIR_TRACE / _ORDER / _GATE select the instrumented build of the e / E pattern (its clock reads cost time:
+        // A/B timings use the plain one)
+        const bool traced = (ev[0] == 'e' || ev[0] == 'E') && (getenv("SFE_FIR_TRACE") || getenv("SFE_FIR_ORDER") || getenv("SFE_FIR_GATE"));
+        if (traced) {
+            const int order = getenv("SFE_FIR_ORDER") ? atoi(getenv("SFE_FIR_ORDER")) : 0;
+            SFE_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_fir_order), &order, sizeof order, 0, hipMemcpyHostToDevice, s));
+            const int gate = getenv("SFE_FIR_GATE") ? atoi(getenv("SFE_FIR_GATE")) : 0;
+            SFE_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_fir_gate), &gate, sizeof gate, 0, hipMemcpyHostToDevice, s));
+        }
         if (ev[0] == 'c') hipLaunchKernelGGL((fir_copy_pattern_kernel<4>), grid2, block, 0, s, a);
         else if (ev[0] == 'd') hipLaunchKernelGGL((fir_copy_pattern16_kernel<4>), grid2, block, 0, s, a);
+        else if (ev[0] == 'e' && traced) hipLaunchKernelGGL((fir_copy_pattern_nt_kernel<4, false, false, true>), grid2, block, 0, s, a);
+        else if (ev[0] == 'E' && traced) hipLaunchKernelGGL((fir_copy_pattern_nt_kernel<4, true, false, true>), grid, block, 0, s, a);
         else if (ev[0] == 'e') hipLaunchKernelGGL((fir_copy_pattern_nt_kernel<4, false>), grid2, block, 0, s, a);
         else if (ev[0] == 'E') hipLaunchKernelGGL((fir_copy_pattern_nt_kernel<4, true>), grid, block, 0, s, a);
         else if (ev[0] == 'b') hipLaunchKernelGGL((fir_copy_pattern_nt_kernel<4, false, true>), grid2, block, 0, s, a);
@@ -878,6 +925,27 @@ int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in
 #undef SFE_NEW_DG
         if (done) {
             SFE_HIP(hipGetLastError());
+            if (const char *tp = getenv("SFE_FIR_TRACE")) {          // e / E only: dump the per-workgroup trace of THIS launch
+                if (traced) {
+                    const size_t nwg = (ev[0] == 'E' ? (size_t)grid.x : (size_t)grid2.x * grid2.y);
+                    const size_t cnt = 5 * (nwg < FIR_TRACE_WGS ? nwg : FIR_TRACE_WGS);
+                    unsigned long long *h = (unsigned long long *)malloc(cnt * 8);
+                    SFE_HIP(hipStreamSynchronize(s));
+                    SFE_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fir_trace), cnt * 8));
+                    if (FILE *f = fopen(tp, "wb")) { fwrite(h, 8, cnt, f); fclose(f); }
+                    free(h);
+                    const size_t nt = a.total < FIR_TRACE_WGS ? a.total : FIR_TRACE_WGS;
+                    h = (unsigned long long *)malloc(nt * 8);
+                    SFE_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fir_tdone), nt * 8));
+                    char tp2[512];
+                    snprintf(tp2, sizeof tp2, "%s.done", tp);
+                    if (FILE *f = fopen(tp2, "wb")) { fwrite(h, 8, nt, f); fclose(f); }
+                    SFE_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fir_tclk), nt * 8));
+                    snprintf(tp2, sizeof tp2, "%s.clk", tp);
+                    if (FILE *f = fopen(tp2, "wb")) { fwrite(h, 8, nt, f); fclose(f); }
+                    free(h);
+                }
+            }
             return SFE_OK;
         }
     }
