@@ -27,7 +27,10 @@ t = api.Timer()
 res = {v: [] for v in variants}
 for r in range(rounds + 1):
     for v in variants:
-        vq = v.split("%")                            # e:8%7 = loads/stores gated on bit 7 of the device clock
+        vs = v.split("~")                            # Q:4~8 = eight idle steps (~0.5 us each) between pick-up and stores
+        os.environ["SFE_FIR_DELAY"] = vs[1] if len(vs) > 1 else "0"
+        v_ = vs[0]
+        vq = v_.split("%")                            # e:8%7 = loads/stores gated on bit 7 of the device clock
         os.environ.pop("SFE_FIR_GATE", None)
         if len(vq) > 1:
             os.environ["SFE_FIR_GATE"] = vq[1]

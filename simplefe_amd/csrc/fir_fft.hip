@@ -806,6 +806,70 @@ __global__ __launch_bounds__(256, WAVES) void fir_copy_pattern_dma_kernel(FirFft
         blk = nb;
     }
 }
+// Diagnostic only (SFE_FIR_VARIANT=q / Q): the LDS-DMA pattern with TWO landing areas: the
+// rows of transform i+1 are requested before transform i's are even waited for, so no wave ever waits for a load
+// that was not issued a whole transform earlier.  64 KiB of LDS per workgroup: two per CU.  DELAY: SFE_FIR_DELAY
+// microsecond-ish idle steps between pick-up and stores stand in for the transform's on-chip time (g takes it too).
+__device__ int g_fir_delay;
+template <int WAVES, bool DOUBLE>
+__global__ __launch_bounds__(256, WAVES) void fir_copy_pattern_dma2_kernel(FirFftArgs a)
+{
+    __shared__ v2f lds[(DOUBLE ? 2 : 1) * FFT_N];
+    const unsigned t = threadIdx.x;
+    const char *in_c = static_cast<const char *>(a.in) + (size_t)blockIdx.y * a.in_stride * 8;
+    char *out_c = static_cast<char *>(a.out) + (size_t)blockIdx.y * a.out_stride * 8;
+    const int row0 = a.hl >> 8;
+    const int delay = g_fir_delay;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) v2f *)lds;
+    const unsigned wv = __builtin_amdgcn_readfirstlane(t >> 6), lane16 = (t & 63u) * 16u;
+    auto ok = [&](long long blk) { const long long b = blk * a.advance - a.hl; return blk < a.nblk && b >= 0 && b + FFT_N <= a.n; };
+    auto dma_rows = [&](long long blk, unsigned area) {
+        const char *g = in_c + (blk * a.advance - a.hl) * 8;
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            const unsigned row = 4u * wv + (p >> 1), half = p & 1;
+            const unsigned dst = lds_base + (area * FFT_N + row * 256u + half * 128u) * 8u;
+            const unsigned off = (row * 256u + half * 128u) * 8u + lane16;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(off), "s"(g), "s"(dst) : "memory");
+        }
+    };
+    auto next_of = [&](long long blk) { long long nb = blk + gridDim.x; while (nb < a.nblk && !ok(nb)) nb += gridDim.x; return nb; };
+    long long blk = blockIdx.x;
+    while (blk < a.nblk && !ok(blk)) blk += gridDim.x;
+    if (blk < a.nblk) dma_rows(blk, 0);
+    unsigned cur = 0;
+    bool first = true;
+    while (blk < a.nblk) {
+        const long long nb = next_of(blk);
+        if constexpr (DOUBLE) {
+            // request i+1 FIRST; then i's eight pieces are older than (15 stores of i-1 +) the 8 just issued
+            if (nb < a.nblk) {
+                dma_rows(nb, cur ^ 1u);
+                if (first || row0 != 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(23)" ::: "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (first || row0 != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+        }
+        first = false;
+        lds_barrier();
+        v2f v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = lds[(DOUBLE ? cur * FFT_N : 0u) + t + r * 256u];
+        lds_barrier();
+        if constexpr (!DOUBLE) { if (nb < a.nblk) dma_rows(nb, 0); }
+        for (int d = 0; d < delay; d++) __builtin_amdgcn_s_sleep(32);
+        const long long base = blk * a.advance - a.hl;
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            if (r >= row0) __builtin_nontemporal_store(v[r], reinterpret_cast<v2f *>(out_c + (base + 256 * r) * 8) + t);
+        blk = nb;
+        cur ^= 1u;
+    }
+}
 #endif  // SFE_DIAG
 
 }  // namespace
@@ -897,6 +961,12 @@ int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in
         else if (ev[0] == 'b') hipLaunchKernelGGL((fir_copy_pattern_nt_kernel<4, false, true>), grid2, block, 0, s, a);
         else if (ev[0] == 'g') hipLaunchKernelGGL((fir_copy_pattern_dma_kernel<4, true>), grid2, block, 0, s, a);
         else if (ev[0] == 'G') hipLaunchKernelGGL((fir_copy_pattern_dma_kernel<4, false>), grid2, block, 0, s, a);
+        else if (ev[0] == 'q' || ev[0] == 'Q') {
+            const int delay = getenv("SFE_FIR_DELAY") ? atoi(getenv("SFE_FIR_DELAY")) : 0;
+            SFE_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_fir_delay), &delay, sizeof delay, 0, hipMemcpyHostToDevice, s));
+            if (ev[0] == 'q') hipLaunchKernelGGL((fir_copy_pattern_dma2_kernel<2, true>), grid2, block, 0, s, a);
+            else hipLaunchKernelGGL((fir_copy_pattern_dma2_kernel<4, false>), grid2, block, 0, s, a);
+        }
         else if (ev[0] == 'p') hipLaunchKernelGGL((fir_copy_pattern_pipe_kernel<4>), grid2, block, 0, s, a);
         else if (ev[0] == 'D') SFE_NEW_DG(true, false, false);
         else if (ev[0] == 'T') SFE_NEW_DG(false, true, false);
