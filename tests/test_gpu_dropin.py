@@ -232,3 +232,26 @@ def test_bpsk_pipeline_end_to_end(tmp_path, orc, g1):
     want = orc.tx_f32_to_10bit(y[: n_xfer * 2048])
     dv = np.abs(_unpack10(got) - _unpack10(want))
     assert dv.max() <= 1 and np.count_nonzero(dv) <= 0.002 * len(dv)
+
+
+@pytest.mark.gpu
+def test_pydsp_module_name_resolves_to_the_gpu_classes(g4):
+    """`from pydsp import *` as libdsp/test/test_decimate.py:8, with simplefe_amd/compat on the path:
+    the script's loop (test_decimate.py:17-25), checked against the compiled reference's outputs."""
+    import importlib
+    import sys
+    compat = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "simplefe_amd", "compat")
+    sys.path.insert(0, compat)
+    try:
+        pydsp = importlib.import_module("pydsp")
+    finally:
+        sys.path.remove(compat)
+    assert set(pydsp.__all__) >= {"resample", "decimate"}
+    N, B = 1024, 128
+    x0 = g4["x"][:N]
+    dec = pydsp.decimate(g4["taps"].tolist(), 4, B)
+    y = []
+    for b in range(N // B):
+        Ny, y0 = dec.process(x0[b * B:(b + 1) * B], 4 * B, float(g4["rate_1p77"]))
+        y += y0[0:Ny].tolist()
+    assert np.array_equal(np.array(y, dtype=np.float32), g4["y_1p77"][:len(y)]) and len(y) == int(np.sum(g4["n_1p77"]))
