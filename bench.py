@@ -455,6 +455,8 @@ def split_stream_check(ctx, taps):
         err = "%s: %s" % (type(e).__name__, e)
     tails = torch.zeros(world * 2 * HL, dtype=torch.float32, device=cdev)
     dist.all_gather_into_tensor(tails, tail)                   # collective 1: every rank, always
+    if on_gpu:
+        torch.cuda.synchronize()        # RCCL orders torch's stream only; the handle below runs on the library's
     try:
         if err is None:
             from oracle import binding as orc

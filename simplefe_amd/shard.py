@@ -48,6 +48,10 @@ def halo_from_left(tail, halo_len, device=None):
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+        # under RCCL wait() only orders torch's current stream behind the transfer; the library's
+        # handles run on streams of their own, so make the halo visible to every stream
+        if halo.is_cuda:
+            torch.cuda.current_stream(halo.device).synchronize()
     return halo
 
 
