@@ -354,9 +354,15 @@ struct Fir {
     // class-compatible host block path
     float *h_buf = nullptr;     // pinned, block_hint+2 floats (blkconv.cxx:44 sizes it so)
     void *d_blk_in = nullptr, *d_blk_out = nullptr;
+    void *h_blk_out = nullptr;  // pinned: the kernel's output of a zero-copy block (then copied over h_buf)
     // host-pointer streaming path (sfe_dsp_fir_process_host): chunked pinned + device staging
     void *h_stage = nullptr, *d_st_in = nullptr, *d_st_out = nullptr;
+    void *h_stage_out = nullptr;
     size_t stage_samples = 0;
+    // Calls of at most zc_max samples skip the two DMA copies: the kernel reads the pinned host buffer
+    // and writes a pinned host buffer itself (one launch + one wait instead of copy, launch, copy, wait).
+    // Only where the kernel reads its input once (parts == 1).  SFE_ZEROCOPY_MAX at create; 0 disables.
+    size_t zc_max = (size_t)1 << 20;
     hipStream_t stream = nullptr;
     size_t hist_bytes() const { return (size_t)n_channels * hl * (data_complex ? 8 : 4); }
 };
@@ -387,6 +393,8 @@ static void fir_free(Fir *f)
     if (f->h_buf) (void)hipHostFree(f->h_buf);
     if (f->d_blk_in) (void)hipFree(f->d_blk_in);
     if (f->d_blk_out) (void)hipFree(f->d_blk_out);
+    if (f->h_blk_out) (void)hipHostFree(f->h_blk_out);
+    if (f->h_stage_out) (void)hipHostFree(f->h_stage_out);
     if (f->h_stage) (void)hipHostFree(f->h_stage);
     if (f->d_st_in) (void)hipFree(f->d_st_in);
     if (f->d_st_out) (void)hipFree(f->d_st_out);
@@ -885,7 +893,9 @@ int sfe_dsp_fir_create(const float *taps, int n_taps, int taps_complex, int data
         memset(f->h_buf, 0, hb);
         TRY(hipMalloc(&f->d_blk_in, (size_t)f->blk * in_e * sizeof(float)));
         TRY(hipMalloc(&f->d_blk_out, (size_t)f->blk * out_e * sizeof(float)));
+        TRY(hipHostMalloc(&f->h_blk_out, hb));
     }
+    if (const char *e = getenv("SFE_ZEROCOPY_MAX")) f->zc_max = (size_t)atoll(e) > 0 ? (size_t)atoll(e) : 0;
     TRY(hipDeviceSynchronize());
 #undef TRY
     *out = f;
@@ -928,6 +938,13 @@ int sfe_dsp_fir_process_block(sfe_fir_t h)
     SFE_ON_DEVICE(f->device);
     const size_t in_b = (size_t)f->blk * (f->data_complex ? 8 : 4);
     const size_t out_b = (size_t)f->blk * (f->out_complex ? 8 : 4);
+    if (f->parts == 1 && (size_t)f->blk <= f->zc_max) {
+        int rc = fir_run(f, f->h_buf, f->h_blk_out, (size_t)f->blk, (size_t)f->blk, (size_t)f->blk, f->stream);
+        if (rc != SFE_OK) return rc;
+        SFE_HIP(hipStreamSynchronize(f->stream));
+        memcpy(f->h_buf, f->h_blk_out, out_b);
+        return SFE_OK;
+    }
     SFE_HIP(hipMemcpyAsync(f->d_blk_in, f->h_buf, in_b, hipMemcpyHostToDevice, f->stream));
     int rc = fir_run(f, f->d_blk_in, f->d_blk_out, (size_t)f->blk, (size_t)f->blk, (size_t)f->blk, f->stream);
     if (rc != SFE_OK) return rc;
@@ -990,19 +1007,23 @@ int sfe_dsp_fir_process_host(sfe_fir_t h, const void *in, void *out, size_t n)
     if (!f->h_stage || !f->d_st_in || !f->d_st_out) {
         // allocate into locals and commit only when all three exist: a failed later allocation must
         // not leave a half-built staging set behind for the next call to trip over
-        void *hs = nullptr, *di = nullptr, *dn = nullptr;
+        void *hs = nullptr, *di = nullptr, *dn = nullptr, *ho = nullptr;
+        const size_t zc = f->zc_max < CH ? f->zc_max : CH;
         hipError_t e = hipHostMalloc(&hs, CH * (in_e > out_e ? in_e : out_e));
         if (e == hipSuccess) e = hipMalloc(&di, CH * in_e);
         if (e == hipSuccess) e = hipMalloc(&dn, CH * out_e);
+        if (e == hipSuccess && zc) e = hipHostMalloc(&ho, zc * out_e);
         if (e != hipSuccess) {
             if (hs) (void)hipHostFree(hs);
             if (di) (void)hipFree(di);
             if (dn) (void)hipFree(dn);
+            if (ho) (void)hipHostFree(ho);
             return hip_fail(e, "fir_process_host staging");
         }
         f->h_stage = hs;
         f->d_st_in = di;
         f->d_st_out = dn;
+        f->h_stage_out = ho;
         f->stage_samples = CH;
     }
     const char *ip = static_cast<const char *>(in);
@@ -1010,6 +1031,13 @@ int sfe_dsp_fir_process_host(sfe_fir_t h, const void *in, void *out, size_t n)
     for (size_t off = 0; off < n; off += CH) {
         const size_t m = n - off < CH ? n - off : CH;
         memcpy(f->h_stage, ip + off * in_e, m * in_e);
+        if (f->parts == 1 && f->h_stage_out && m <= f->zc_max) {          // small call: no DMA copies
+            int rc = fir_run(f, f->h_stage, f->h_stage_out, m, m, m, f->stream);
+            if (rc != SFE_OK) return rc;
+            SFE_HIP(hipStreamSynchronize(f->stream));
+            memcpy(op + off * out_e, f->h_stage_out, m * out_e);
+            continue;
+        }
         SFE_HIP(hipMemcpyAsync(f->d_st_in, f->h_stage, m * in_e, hipMemcpyHostToDevice, f->stream));
         int rc = fir_run(f, f->d_st_in, f->d_st_out, m, m, m, f->stream);
         if (rc != SFE_OK) return rc;
@@ -1213,6 +1241,43 @@ int sfe_dsp_rs_process(sfe_rs_t h, const float *in, int n_in, float *out, int ou
     }
     if (n_in < 0 || out_len < 0 || (n_in && !in) || (out_len && !out)) return SFE_EINVAL;
     SFE_ON_DEVICE(r->device);
+
+    // The common call -- out_len roomy enough that the law, not the buffer, ends the outputs -- is the
+    // bulk path on one block with the reference's arithmetic order (exact): the tiled / run-length kernels
+    // stage the block in LDS instead of two global dot products per output, the outputs are written
+    // straight into pinned host memory, and the stream sees copy-in, kernel, history instead of seven
+    // operations.  Same bits (tests/test_gpu_parity.py: class calls against the compiled reference).
+    if (n_in > 0 && !r->in_u8) {
+        const float stepf = rate * (float)r->U;
+        const bool int_step = stepf >= 1.0f && stepf == floorf(stepf) && stepf < 1.0e6f && r->ts.mu == 0.0f &&
+                              ((double)r->blksize * r->U + stepf) < 16777216.0;
+        bool roomy;
+        if (int_step) {
+            const long long S = (long long)stepf, pos0 = r->ts.leftover ? -1 : (long long)r->ts.pos;
+            const long long lim = (long long)n_in * r->U - 2;
+            roomy = (pos0 <= lim ? (lim - pos0) / S + 1 : 0) <= (long long)out_len;
+        } else
+            roomy = (long long)out_len >= (long long)ceilf((float)n_in / rate) + 2;
+        if (roomy) {
+            const size_t in_b = (size_t)n_in * r->esz(), out_off = (in_b + 255) & ~(size_t)255;
+            int rc = rs_ensure_stage(r, out_off + ((size_t)out_len + 1) * r->esz());
+            if (rc != SFE_OK) return rc;
+            char *h_out = static_cast<char *>(r->h_stage) + out_off;
+            memcpy(r->h_stage, in, in_b);
+            SFE_HIP(hipMemcpyAsync(r->d_in, r->h_stage, in_b, hipMemcpyHostToDevice, r->stream));
+            const int keep = r->exact_stream;
+            r->exact_stream = 1;
+            size_t n = 0;
+            rc = sfe_dsp_rs_process_stream(h, r->d_in, (size_t)n_in, (size_t)n_in, h_out, (size_t)out_len, (size_t)out_len,
+                                           rate, &n, r->stream);
+            r->exact_stream = keep;
+            if (rc != SFE_OK) return rc;
+            SFE_HIP(hipStreamSynchronize(r->stream));
+            if (n) memcpy(out, h_out, n * r->esz());
+            *n_out = (int)n;
+            return SFE_OK;
+        }
+    }
 
     int rc = rs_ensure_sched(r, (size_t)out_len + 1);
     if (rc != SFE_OK) return rc;
