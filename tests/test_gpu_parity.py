@@ -221,6 +221,58 @@ def test_rs_class_reference_vector_bit_exact(api, g4, cls, tag):
     assert np.array_equal(y, g4[f"y_{tag}"])
 
 
+def _tight_out_lens(orc, cls, g4, U, B, rate, x, slack):
+    """Drive the oracle with per-call out_len = the call's natural output count + slack; returns
+    (out_len, n_out, outputs) per call.  The natural count comes from a second oracle object kept in
+    step (slack >= 1 never ends a call on the buffer test, so both objects stay in the same state)."""
+    obj = getattr(orc, cls.capitalize())(g4["taps"], U, B)
+    twin = getattr(orc, cls.capitalize())(g4["taps"], U, B)
+    calls = []
+    for off in range(0, len(x), B):
+        seg = x[off:off + B]
+        natural, _ = twin.process(seg, 4 * B, rate)
+        out_len = natural + slack
+        n, y = obj.process(seg, out_len, rate)
+        assert n == natural
+        calls.append((out_len, n, y[:n].copy()))
+    return calls
+
+
+@pytest.mark.parametrize("cls", ["resample", "decimate"])
+@pytest.mark.parametrize("tag", ["1p77", "5o3", "2p5"])
+@pytest.mark.parametrize("slack", [1, 2, 3])
+def test_rs_class_tight_out_len(api, orc, g4, cls, tag, slack):
+    """process() with an output buffer only one to three longer than the call's natural output count:
+    at a general rate that can be too tight for the bulk path's planning margin, so the per-output
+    schedule runs; at an integer-valued step the bulk path does -- either way the reference's n_out
+    and bits, call after call (the oracle is bit-pinned to the compiled reference).  A buffer of
+    EXACTLY the natural count ends the reference's loop on the buffer test before it can note a
+    left-over output, and its next call indexes the delay line out of range: not a defined case."""
+    U, B, rate = int(g4["U"]), int(g4["B"]), float(g4[f"rate_{tag}"])
+    x = g4["x"]
+    want = _tight_out_lens(orc, cls, g4, U, B, rate, x, slack)
+    obj = getattr(api, cls)(g4["taps"], U, B)
+    for k, (out_len, nw, yw) in enumerate(want):
+        ng, yg = obj.process(x[k * B:(k + 1) * B], out_len, rate)
+        assert ng == nw, (k, out_len)
+        assert np.array_equal(yg[:ng], yw), (k, out_len)
+
+
+@pytest.mark.parametrize("cls", ["resample", "decimate"])
+@pytest.mark.parametrize("tag", ["1p77", "5o3"])
+def test_rs_class_truncating_out_len_first_call(api, orc, g4, cls, tag):
+    """A buffer shorter than the natural count ends the call at out_len (resample.cxx:126-128).  One
+    call only: after a truncated call the reference's next call indexes its delay line out of range."""
+    U, B, rate = int(g4["U"]), int(g4["B"]), float(g4[f"rate_{tag}"])
+    seg = g4["x"][:B]
+    natural, _ = getattr(orc, cls.capitalize())(g4["taps"], U, B).process(seg, 4 * B, rate)
+    out_len = max(int(np.floor(B / rate)), natural - 3)
+    nw, yw = getattr(orc, cls.capitalize())(g4["taps"], U, B).process(seg, out_len, rate)
+    ng, yg = getattr(api, cls)(g4["taps"], U, B).process(seg, out_len, rate)
+    assert ng == nw == out_len
+    assert np.array_equal(yg[:ng], yw[:nw])
+
+
 @pytest.mark.parametrize("name", ["cfg3", "cfg4", "gen", "gen2"])
 @pytest.mark.parametrize("B", [4096, 1001])
 def test_rs_class_baseline_shapes_bit_exact(api, g5, name, B):
