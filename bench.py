@@ -25,10 +25,11 @@ BEFORE anything touches the GPU and relays rank 0's line.  It never prints an n_
                 timed leg of its own with parity: resample 5/3 (configs[2], in both readings of
                 "127-tap polyphase arm": the 381-tap prototype and the 127-tap prototype), decimate by 8
                 (configs[3]), the 64-channel FIR on one GPU (configs[4] at G = 1) and the
-                complex-tap FIR.  They run BEFORE the headline's warm-up so the
-                headline's timed steps sit on the chip's sustained clock, not on the power
-                controller's start-up transient; their parity checks run
-                after all timing.
+                complex-tap FIR.  They run BEFORE the headline's warm-up; their
+                parity checks run after all timing.
+`precondition_s` seconds of untimed launches of whichever leg runs first, before any warm-up or timed
+                step: the chip's first ~100 ms of work after idling run 5-6 % slow (DESIGN.md
+                section 6), and W = 5 steps of a 0.8 ms kernel end well inside that.
 `cpu_baseline`  the CPU oracle (oracle/, a port of the reference algorithm; oracle/_ref for
                 resample/decimate = the reference's own code) timed on this host on a bounded
                 sample of the same workload, rank 0, N = 1 only: `value` on one thread (the
@@ -69,6 +70,7 @@ def parse():
     ap.add_argument("--no-others", action="store_true", help="skip the other_configs legs")
     ap.add_argument("--other-steps", type=int, default=20)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--precondition", type=float, default=0.15, help="seconds of untimed launches before any warm-up")
     return ap.parse_args()
 
 
@@ -411,6 +413,20 @@ def time_leg(ctx, leg, steps, warmup):
     return elapsed, float(np.mean([t.elapsed_ms() for t in timers]))
 
 
+def precondition(ctx, leg, seconds=0.15):
+    """Untimed: run the leg until `seconds` of wall time have passed.  The chip's first ~100 ms of work
+    after idling run 5-6 % slower (power controller / clock start-up transient: a 381-tap resample launch
+    measures 0.739 ms after 15 warm-up launches and 0.694 ms after 100); five warm-up steps of a 0.8 ms
+    kernel end well inside it.  Outside every timed region, before the W warm-up steps; reported in the
+    line as `precondition_s`."""
+    torch = ctx["torch"]
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(8):
+            leg.step()
+        torch.cuda.synchronize()
+
+
 def checksum(ctx, leg):
     """{samples, sum re, sum im, sum |y|^2} of this rank's last output, float64 on the device."""
     torch = ctx["torch"]
@@ -544,8 +560,9 @@ def main():
             except Exception as e:
                 other_errors.append({"error": "%s: %s" % (type(e).__name__, e)})
     other_rows = []
+    precondition(ctx, others[0] if others else head, args.precondition)      # whichever leg runs first takes the chip through its start-up transient
     for leg in others:
-        el, kms = time_leg(ctx, leg, args.other_steps, 15 if leg is others[0] else 3)   # the first leg also takes the chip through its start-up clock transient
+        el, kms = time_leg(ctx, leg, args.other_steps, 3)
         other_rows.append({"workload": leg.workload, "steps": args.other_steps, "ms": kms,
                            "value": leg.n_gpu / (el / args.other_steps) / 1e6, "unit": "MS/s (input)",
                            "kernel": leg.kernel, "algorithmic_bytes_per_launch": leg.bytes_per_launch,
@@ -575,7 +592,7 @@ def main():
         else "complex-float32 input MS/s through libdsp %s; %% of HBM roofline" % wl,
         "value": value, "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic", "precondition_s": args.precondition,
         "config": {"workload": head.workload, "channels_per_gpu": head.nch, "samples_per_gpu": head.n_gpu,
                    "sharding": "independent channels per rank, no data-path collective" if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": head.bytes_per_launch / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
