@@ -27,7 +27,11 @@ t = api.Timer()
 res = {v: [] for v in variants}
 for r in range(rounds + 1):
     for v in variants:
-        vs = v.split("~")                            # Q:4~8 = eight idle steps (~0.5 us each) between pick-up and stores
+        vk = v.split("!")                            # X!1 = the shared rows loaded without the nontemporal hint
+        os.environ["SFE_FIR_HALO_KEEP"] = vk[1] if len(vk) > 1 else "1"
+        vr = vk[0].split("^")                            # X^2 = each counter deals runs of 2^2 consecutive transforms
+        os.environ["SFE_FIR_TQS"] = vr[1] if len(vr) > 1 else "3"
+        vs = vr[0].split("~")                            # Q:4~8 = eight idle steps (~0.5 us each) between pick-up and stores
         os.environ["SFE_FIR_DELAY"] = vs[1] if len(vs) > 1 else "0"
         v_ = vs[0]
         vq = v_.split("%")                            # e:8%7 = loads/stores gated on bit 7 of the device clock

@@ -198,7 +198,11 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
     // transforms g, g + tgroups, ... from its own counter, 128 bytes apart)
     const unsigned tg = a.tgroups, grp = blockIdx.x % tg;
     unsigned *const my_ticket = a.ticket + 32u * grp;
-    const unsigned last_draw = (a.total > grp ? (a.total - grp + tg - 1u) / tg : 0u) + (gridDim.x - grp + tg - 1u) / tg - 1u;
+    // group g owns the runs g, g + tg, ... of Q = 2^tqs consecutive transforms; ticket c of the group is
+    // transform ((c / Q) tg + g) Q + c % Q.  The group's share: Q per complete row of tg runs + its part of the last row.
+    const unsigned Q = 1u << a.tqs, row = tg << a.tqs, rem = a.total % row;
+    const unsigned mine = (a.total / row << a.tqs) + (rem > grp * Q ? (rem - grp * Q < Q ? rem - grp * Q : Q) : 0u);
+    const unsigned last_draw = mine + (gridDim.x - grp + tg - 1u) / tg - 1u;
     // a launch with no more transforms than workgroups (the per-block host calls) deals them by
     // blockIdx and leaves the counters alone: two atomic round trips less on a 10 us kernel
     const bool few = a.total <= gridDim.x;
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         if (few) return 0xFFFFFFFFu;
         const unsigned c = __hip_atomic_fetch_add(my_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (c == last_draw) __hip_atomic_store(my_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long k = (unsigned long long)c * tg + grp;
+        const unsigned long long k = (((unsigned long long)(c >> a.tqs) * tg + grp) << a.tqs) + (c & (Q - 1u));
         return k < a.total ? (unsigned)k : 0xFFFFFFFFu;
     };
     const unsigned nblk32 = (unsigned)a.nblk;
@@ -335,8 +339,15 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
                 off = (row * 256u + half * 128u) * 8u + lane16;
             }
             unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(off), "s"(g), "s"(dst) : "memory");
+            // rows 0 and 15 (with hl = 256: the halo this transform re-reads and the one its successor will)
+            // may stay in the L2: no nontemporal hint on their pieces when the launcher says so
+            const bool shared_row = !WP && a.halo_keep && (a.halo_keep > 1 || (wv == 0 && p < 2) || (wv == 3 && p >= 6));
+            if (shared_row)
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(off), "s"(g), "s"(dst) : "memory");
+            else
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(off), "s"(g), "s"(dst) : "memory");
         }
     };
 
@@ -927,6 +938,14 @@ int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in
     if (const char *e = getenv("SFE_FIR_TGROUPS")) a.tgroups = atoi(e) >= 1 && atoi(e) <= FIR_TICKET_GROUPS_MAX ? atoi(e) : a.tgroups;
 #endif
     if ((long long)a.tgroups > gt) a.tgroups = (unsigned)gt;      // every group needs a workgroup to draw for it
+    // runs of 8: seven of eight 2 KiB halos are re-read on the XCD whose L2 has just seen them
+    // (FETCH_SIZE per launch 4.446 -> see profiles/r02; -1.5 % kernel time, `X` against `X^3`)
+    a.tqs = 3;
+    a.halo_keep = 1;      // `X^3` against `X^3!1`: -0.5 ... -1.3 %
+#ifdef SFE_DIAG
+    if (const char *e = getenv("SFE_FIR_HALO_KEEP")) a.halo_keep = (unsigned)atoi(e);      // 2 (diagnostic): every row
+    if (const char *e = getenv("SFE_FIR_TQS")) a.tqs = atoi(e) >= 0 && atoi(e) <= 8 ? (unsigned)atoi(e) : 0u;
+#endif
     const dim3 grid((unsigned)gt), block(256);
 #define SFE_K(...) hipLaunchKernelGGL((fir_fft4096_kernel<__VA_ARGS__>), grid, block, 0, s, a)
 #ifdef SFE_DIAG
