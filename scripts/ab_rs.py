@@ -25,7 +25,11 @@ t = api.Timer()
 res = {v: [] for v in variants}
 for k in range(rounds + 1):
     for v in variants:
-        vv = v.split(":")                                  # t:8 = grid of 8 x the resident workgroups
+        vk = v.split("!")                                  # t^3!1 = first / last staged rows without the nontemporal hint
+        os.environ["SFE_RS_HALO_KEEP"] = vk[1] if len(vk) > 1 else "1"
+        vr = vk[0].split("^")                              # t^3 = a counter deals runs of 2^3 consecutive passes
+        os.environ["SFE_RS_TQS"] = vr[1] if len(vr) > 1 else "3"
+        vv = vr[0].split(":")                              # t:8 = grid of 8 x the resident workgroups
         os.environ["SFE_RS_VARIANT"] = vv[0]
         os.environ["SFE_RS_WG_FACTOR"] = vv[1] if len(vv) > 1 else ("1" if vv[0] in ("t", "x", "l", "h", "w") else "2")
         t.start()

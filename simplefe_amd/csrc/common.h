@@ -160,6 +160,8 @@ struct PolyFftArgs {
     int         hl, e_max, ovl, V;
     unsigned   *ticket;          // [POLY_TICKET_GROUPS][32] work counters, zero between launches (null: fixed-stride walk)
     unsigned    tgroups;         // set by the launcher
+    unsigned    tqs;             // set by the launcher: a counter deals runs of 2^tqs consecutive passes
+    unsigned    halo_keep;       // set by the launcher: 1 = a pass's first and last staged rows are loaded without the nontemporal hint
 };
 constexpr unsigned POLY_TICKET_GROUPS = 8;
 // returns SFE_ESTATE when (SP, UP) has no instantiation

@@ -185,7 +185,11 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
             const char *p = in_c + start * ISZ;
 #pragma unroll
             for (int i = 0; i < SP; i++) {
-                s[sg * SP + i] = load_in(p, t + 256u * i);
+                // the pass's first and last rows are what its neighbours read too: they may stay in the L2
+                if (!PAIR && !IN_U8 && ((sg == 0 && i == 0) || (sg == R - 1 && i == SP - 1)) && a.halo_keep)
+                    s[sg * SP + i] = reinterpret_cast<const v2f *>(p)[t + 256u * i];
+                else
+                    s[sg * SP + i] = load_in(p, t + 256u * i);
                 if constexpr (PAIR) s[sg * SP + i].y = load_in(p + (long long)a.V * SP * ISZ, t + 256u * i).x;
             }
         }
@@ -243,12 +247,15 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
     // counter (128 bytes apart); the launch's last draw of a group zeroes it for the next launch
     const unsigned tg = a.tgroups, grp = TICKET ? blockIdx.x % tg : 0u;
     const unsigned np32 = (unsigned)a.n_pass;
-    const unsigned last_draw = TICKET ? (np32 > grp ? (np32 - grp + tg - 1u) / tg : 0u) + (gridDim.x - grp + tg - 1u) / tg - 1u : 0u;
+    // (runs of Q = 2^tqs consecutive passes per counter, as fir_fft.hip: neighbours' overlaps meet in one XCD's L2)
+    const unsigned Q = 1u << a.tqs, row = tg << a.tqs, rem = TICKET ? np32 % row : 0u;
+    const unsigned mine = TICKET ? (np32 / row << a.tqs) + (rem > grp * Q ? (rem - grp * Q < Q ? rem - grp * Q : Q) : 0u) : 0u;
+    const unsigned last_draw = TICKET ? mine + (gridDim.x - grp + tg - 1u) / tg - 1u : 0u;
     auto draw = [&]() -> unsigned {
         unsigned *const ctr = a.ticket + 32u * grp;
         const unsigned c = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (c == last_draw) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long k = (unsigned long long)c * tg + grp;
+        const unsigned long long k = (((unsigned long long)(c >> a.tqs) * tg + grp) << a.tqs) + (c & (Q - 1u));
         return k < np32 ? (unsigned)k : 0xFFFFFFFFu;
     };
     long long first = blockIdx.x;
@@ -262,10 +269,11 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
     long long prev = -1;       // pass whose inverse transforms run in this iteration
     v2f s[R * SP];
     v4u raw[R];
-    // passes are dealt round-robin (blockIdx.x, + gridDim.x, ...): at any moment the resident
-    // workgroups read one compact window of the stream.  Giving each workgroup a contiguous run of
-    // passes instead (so the overlap re-read hits L2) measured 8 % SLOWER: a thousand separate
-    // read/write streams cost HBM more than the 5 % of re-read bytes they save.
+    // passes are dealt so that at any moment the resident workgroups read one compact window of the
+    // stream.  Giving each WORKGROUP a contiguous run of passes (so the overlap re-read hits L2)
+    // measured 8 % SLOWER: a thousand separate read/write streams cost HBM more than the 5 % of
+    // re-read bytes they save.  Runs of eight per COUNTER (round 2) keep the window compact and
+    // still put neighbours on one XCD.
     bool cur_wide = false;      // this pass's samples were requested ahead: as wide raw lanes (WIDE) ...
     bool cur_fast = false;      // ... or as per-sample registers s[] (interior pass of a non-WIDE kernel)
     if (first < a.n_pass) {
@@ -474,6 +482,12 @@ int launch_one(const PolyFftArgs &a0, int n_channels, hipStream_t s)
     if (TICKET) {
         if (n_channels != 1 || !a.ticket || a.n_pass + grid.x >= 0xFFFFFFFFLL) return SFE_ESTATE;
         a.tgroups = POLY_TICKET_GROUPS < grid.x ? POLY_TICKET_GROUPS : grid.x;
+        a.tqs = 3;            // `t` against `t^3!1` (scripts/ab_rs.py): -0.6 % time, the overlap re-read leaves HBM
+        a.halo_keep = 1;
+#ifdef SFE_DIAG
+        if (const char *e = getenv("SFE_RS_TQS")) a.tqs = atoi(e) >= 0 && atoi(e) <= 8 ? (unsigned)atoi(e) : 0u;
+        if (const char *e = getenv("SFE_RS_HALO_KEEP")) a.halo_keep = atoi(e) ? 1u : 0u;
+#endif
     }
     hipLaunchKernelGGL((poly_fft256_kernel<SP, UP, R, IN_U8, PAIR, DIAG, TICKET, LATE, WPS>), grid, dim3(256), 0, s, a);
     hipError_t err = hipGetLastError();
