@@ -28,7 +28,7 @@ res = {v: [] for v in variants}
 for r in range(rounds + 1):
     for v in variants:
         vk = v.split("!")                            # X!1 = the shared rows loaded without the nontemporal hint
-        os.environ["SFE_FIR_HALO_KEEP"] = vk[1] if len(vk) > 1 else "1"
+        os.environ["SFE_FIR_HALO_KEEP"] = vk[1] if len(vk) > 1 else "0x8001"
         vr = vk[0].split("^")                            # X^2 = each counter deals runs of 2^2 consecutive transforms
         os.environ["SFE_FIR_TQS"] = vr[1] if len(vr) > 1 else "3"
         vs = vr[0].split("~")                            # Q:4~8 = eight idle steps (~0.5 us each) between pick-up and stores

@@ -62,7 +62,7 @@ struct FirFftArgs {
     unsigned    total;    // set by the launcher: transforms over all channels (channel-major tickets)
     unsigned    tgroups;  // set by the launcher: counters in use (workgroup b draws from counter b % tgroups)
     unsigned    tqs;      // set by the launcher: a group draws runs of 2^tqs CONSECUTIVE transforms (their halos meet in its L2)
-    unsigned    halo_keep; // set by the launcher: 1 = the rows another transform re-reads (first and last) are loaded without the nontemporal hint
+    unsigned    halo_keep; // set by the launcher: mask of input rows loaded WITHOUT the nontemporal hint (0x8001: the two rows a neighbour re-reads)
 };
 constexpr int FIR_TICKET_GROUPS = 8;        // one per XCD under round-robin workgroup placement
 constexpr int FIR_TICKET_GROUPS_MAX = 64;

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             unsigned keep;
             // rows 0 and 15 (with hl = 256: the halo this transform re-reads and the one its successor will)
             // may stay in the L2: no nontemporal hint on their pieces when the launcher says so
-            const bool shared_row = !WP && a.halo_keep && (a.halo_keep > 1 || (wv == 0 && p < 2) || (wv == 3 && p >= 6));
+            const bool shared_row = !WP && ((a.halo_keep >> (4u * wv + (unsigned)(p >> 1))) & 1u);      // halo_keep: a mask over the 16 rows
             if (shared_row)
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(off), "s"(g), "s"(dst) : "memory");
@@ -941,9 +941,9 @@ int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in
     // runs of 8: seven of eight 2 KiB halos are re-read on the XCD whose L2 has just seen them
     // (FETCH_SIZE per launch 4.446 -> see profiles/r02; -1.5 % kernel time, `X` against `X^3`)
     a.tqs = 3;
-    a.halo_keep = 1;      // `X^3` against `X^3!1`: -0.5 ... -1.3 %
+    a.halo_keep = 0x8001u;      // rows 0 and 15; `X^3` against `X^3!1`: -0.5 ... -1.3 %
 #ifdef SFE_DIAG
-    if (const char *e = getenv("SFE_FIR_HALO_KEEP")) a.halo_keep = (unsigned)atoi(e);      // 2 (diagnostic): every row
+    if (const char *e = getenv("SFE_FIR_HALO_KEEP")) a.halo_keep = (unsigned)strtoul(e, nullptr, 0);      // any mask of rows
     if (const char *e = getenv("SFE_FIR_TQS")) a.tqs = atoi(e) >= 0 && atoi(e) <= 8 ? (unsigned)atoi(e) : 0u;
 #endif
     const dim3 grid((unsigned)gt), block(256);
