@@ -296,3 +296,41 @@ def test_fir_partition_plan():
             prev = cost
     assert plan(3841)[1] == 2 and plan(3841)[0] == 2048
     assert L.sfe_dsp_fir_plan(5_000_000, None, None, None) == lib.SFE_ERANGE
+
+
+def test_work_counter_arithmetic_covers_every_transform_once_and_returns_to_zero():
+    """The model of the kernels' draw (csrc/fir_fft.hip, csrc/poly_fft.hip: group g's counter deals runs of
+    2^tqs consecutive transforms, ticket c -> ((c >> tqs) * groups + g << tqs) + (c & (2^tqs - 1)); the
+    group's last draw -- its share plus one failed draw per workgroup -- puts the counter back to zero):
+    every transform is drawn exactly once and every counter ends at zero, whatever the shape."""
+    import random
+
+    def run(total, tg, tqs, grid):
+        Q, row = 1 << tqs, tg << tqs
+        rem = total % row
+        last = []
+        for g in range(tg):
+            mine = (total // row << tqs) + (min(rem - g * Q, Q) if rem > g * Q else 0)
+            last.append(mine + (grid - g + tg - 1) // tg - 1)
+        ctr, done, alive = [0] * tg, [0] * total, list(range(grid))
+        while alive:
+            nxt = []
+            for b in alive:
+                g = b % tg
+                c = ctr[g]
+                ctr[g] = 0 if c == last[g] else c + 1
+                k = (((c >> tqs) * tg + g) << tqs) + (c & (Q - 1))
+                if k < total:
+                    done[k] += 1
+                    nxt.append(b)
+            alive = nxt
+        assert all(d == 1 for d in done), (total, tg, tqs, grid)
+        assert all(c == 0 for c in ctr), (total, tg, tqs, grid)
+
+    rng = random.Random(7)
+    for _ in range(1500):
+        tg = rng.choice([1, 2, 3, 8])
+        grid = rng.randint(tg, 64)
+        run(rng.randint(grid + 1, 2000), tg, rng.choice([0, 1, 3, 5]), grid)
+    for total in range(9, 200):
+        run(total, 8, 3, 8)
