@@ -143,7 +143,9 @@ __device__ __forceinline__ float pair_hi(v2f p) { return p.y; }
 
 // IN_U8: the input is the device wire format (u8 offset binary, gr-simplefe source blocks) and
 // is converted while it is staged -- 2 bytes instead of 8 per complex sample from HBM.
-template <int SP, int UP, bool CPLX, bool EXACT, bool IN_U8 = false>
+// DIAG (instantiated under -DSFE_DIAG only, SFE_TILED_DIAG): bit 0 = no dot products (the staged tile is
+// still written and read once), bit 1 = no staging through LDS either (loads feed the result directly).
+template <int SP, int UP, bool CPLX, bool EXACT, bool IN_U8 = false, int DIAG = 0>
 __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
 {
     typedef typename Elem<CPLX>::T T;
@@ -202,12 +204,19 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
         // division by SP per element.
         const unsigned q0 = tid / SP, r0 = tid % SP;
         const unsigned cell0 = r0 * ROWLEN + q0;
+        if constexpr (DIAG & 2) {
+            T sum = v[0];
+#pragma unroll
+            for (int i = 1; i < MAIN; i++) sum += v[i];
+            X[tid] = sum;
+        } else {
 #pragma unroll
         for (int i = 0; i < MAIN; i++) {
             constexpr unsigned W = SP * ROWLEN - 1;         // row wrap: -SP rows, +1 column
             const unsigned ci = (256u * i) / SP, di = (256u * i) % SP;
             const unsigned cell = cell0 + di * ROWLEN + ci;
             X[(r0 + di >= (unsigned)SP) ? cell - W : cell] = v[i];
+        }
         }
         for (unsigned s = SP * TM + tid; s < (unsigned)n_tile; s += 256)
             X[(s % SP) * ROWLEN + s / SP] = __builtin_nontemporal_load(src + s);
@@ -256,7 +265,11 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
     P2 pa[SP], pb[SP];
 #pragma unroll
     for (int p = 0; p < SP; p++) pa[p] = xp[p * (ROWLEN / 2)];      // pairs at column 2*tid + nchunk
-    int steps = nchunk / 2;
+    int steps = (DIAG & 1) ? 0 : nchunk / 2;
+    if constexpr (DIAG & 1) {
+#pragma unroll
+        for (int r = 0; r < UP; r++) { acc[0][r] = pair_lo(pa[0]); acc[1][r] = pair_hi(pa[SP - 1]); }
+    }
     if (steps & 1) {                                                 // odd count: peel one, landing in pa
         step(pb, pa);
 #pragma unroll
@@ -642,6 +655,19 @@ int launch_poly_tiled(const PolyTiledPlan &plan, const PolyTiledArgs &a, int dat
     }
     dim3 grid((unsigned)tiles, (unsigned)n_channels), block(256);
     const size_t esz = data_complex ? 8 : 4;
+#ifdef SFE_DIAG
+    if (const char *e = getenv("SFE_TILED_DIAG")) {          // decimate by 8, cf32, fused numerics only
+        const int dg = atoi(e);
+        if (dg && plan.SP == 8 && plan.UP == 1 && data_complex && !exact && !in_u8) {
+            const size_t sh = (size_t)8 * tiled_rowlen(8) * esz;
+            if (dg == 1) hipLaunchKernelGGL((poly_tiled_kernel<8, 1, true, false, false, 1>), grid, block, sh, s, a);
+            else if (dg == 2) hipLaunchKernelGGL((poly_tiled_kernel<8, 1, true, false, false, 2>), grid, block, sh, s, a);
+            else hipLaunchKernelGGL((poly_tiled_kernel<8, 1, true, false, false, 3>), grid, block, sh, s, a);
+            SFE_HIP(hipGetLastError());
+            return SFE_OK;
+        }
+    }
+#endif
     if (in_u8) {   // wire-format input: the decimator / resampler shapes a receive chain uses
         if (exact) {
             set_error("polyphase: u8 input runs the fused kernels only");
