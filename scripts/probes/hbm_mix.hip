@@ -53,6 +53,29 @@ __global__ __launch_bounds__(256) void k_copy(const T *in, T *out, size_t n)
     }
 }
 
+// 8 parts read, 1 part written (the decimator's mix): a workgroup reads CH*256 8-byte lanes and writes CH*32
+template <int CH>
+__global__ __launch_bounds__(256) void k_mix81(const v2f *in, v2f *out, size_t n_tiles)
+{
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const v2f *p = in + tile * (size_t)(CH * 256) + threadIdx.x;
+        v2f v[CH];
+#pragma unroll
+        for (int u = 0; u < CH; u++) v[u] = __builtin_nontemporal_load(p + 256 * u);
+        v2f acc = v[0];
+#pragma unroll
+        for (int u = 1; u < CH; u++) acc += v[u];
+        // lanes 0..CH*32-1 of the tile's output: fold eight lanes into one through a shuffle-free trick:
+        // every lane writes its sum for lane % 8 == 0 (an 8-byte store per eight lanes would scatter: use
+        // one 16-byte store per sixteen lanes instead, as the decimator's store is)
+        if ((threadIdx.x & 1) == 0) {
+            v4f w = {acc.x, acc.y, acc.x, acc.y};
+            if ((threadIdx.x & 15) == 0 || CH >= 16)
+                __builtin_nontemporal_store(w, reinterpret_cast<v4f *>(out + tile * (size_t)(CH * 32)) + (threadIdx.x >> 1) % (CH * 16));
+        }
+    }
+}
+
 template <typename F>
 static void timeit(const char *name, double bytes, F launch)
 {
@@ -84,7 +107,7 @@ int main(int argc, char **argv)
     CK(hipMalloc(&out, bytes));
     CK(hipMemset(in, 1, bytes));
     CK(hipMemset(out, 0, bytes));
-    const int grids[] = {2048, 8192, 65536};
+    const int grids[] = {2048, 8192, 65536, 262144};
     for (int g : grids) {
         printf("-- grid %d x 256 threads\n", g);
         const size_t n16 = bytes / 16, n8 = bytes / 8;
@@ -97,6 +120,10 @@ int main(int argc, char **argv)
         timeit("copy  16 B lanes, plain", 2.0 * bytes, [&] { hipLaunchKernelGGL((k_copy<v4f, false, false, 4>), dim3(g), dim3(256), 0, 0, (const v4f *)in, (v4f *)out, n16); });
         timeit("copy  16 B lanes, nt load + plain store", 2.0 * bytes, [&] { hipLaunchKernelGGL((k_copy<v4f, true, false, 4>), dim3(g), dim3(256), 0, 0, (const v4f *)in, (v4f *)out, n16); });
         timeit("copy   8 B lanes, nt load + nt store, 16 deep", 2.0 * bytes, [&] { hipLaunchKernelGGL((k_copy<v2f, true, true, 16>), dim3(g), dim3(256), 0, 0, (const v2f *)in, (v2f *)out, n8); });
+        {
+            const size_t tiles = n8 / (16 * 256);           // 16 loads per lane: the decimator's 4096-sample tile
+            timeit("mix 8:1, 16 x 8 B loads, one 16 B store per 2 lanes", 1.125 * bytes, [&] { hipLaunchKernelGGL((k_mix81<16>), dim3(g), dim3(256), 0, 0, (const v2f *)in, (v2f *)out, tiles); });
+        }
     }
     return 0;
 }
