@@ -43,7 +43,10 @@ for r in range(rounds + 1):
         vg = vd[0].split("/")                        # X/16 = 16 ticket groups
         os.environ["SFE_FIR_TGROUPS"] = vg[1] if len(vg) > 1 else "8"
         vv = vg[0].split(":")
-        os.environ["SFE_FIR_VARIANT"] = vv[0]
+        if vv[0] == "P":                              # P = the product's own dispatch (no variant switch)
+            os.environ.pop("SFE_FIR_VARIANT", None)
+        else:
+            os.environ["SFE_FIR_VARIANT"] = vv[0]
         if len(vv) > 1:
             os.environ["SFE_FIR_WG_PER_CU"] = vv[1]
         else:
