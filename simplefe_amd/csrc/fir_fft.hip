@@ -927,7 +927,14 @@ int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in
     a.nblk = nb;
     // ticketed kernels: ONE grid dimension, transforms of all channels drawn channel-major from a.ticket
     const long long total = nb * n_channels;
-    long long gt = total < 256LL * wg_per_cu ? total : 256LL * wg_per_cu;
+    // compute units of the device (256 on an unpartitioned MI355X; a partitioned one reports its share)
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, c = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0) cus = c;
+        else cus = 256;
+    }
+    long long gt = total < (long long)cus * wg_per_cu ? total : (long long)cus * wg_per_cu;
     if (total + gt >= 0xFFFFFFFFLL || !a.ticket) {
         set_error("fir_fft: %lld transforms in one launch exceed the ticket counter", total);
         return SFE_ERANGE;
@@ -951,7 +958,7 @@ int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in
 #ifdef SFE_DIAG
     // fixed-stride walk (round 1): blockIdx.x, + gridDim.x, ... per channel on a 2-D grid
     long long gx = nb;
-    const long long cap = (256LL * wg_per_cu + n_channels - 1) / n_channels;
+    const long long cap = ((long long)cus * wg_per_cu + n_channels - 1) / n_channels;
     if (gx > cap) gx = cap < 1 ? 1 : cap;
     const dim3 grid2((unsigned)gx, (unsigned)n_channels);
 #define SFE_K2(...) hipLaunchKernelGGL((fir_fft4096_kernel<__VA_ARGS__>), grid2, block, 0, s, a)
