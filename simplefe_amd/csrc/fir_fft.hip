@@ -328,15 +328,21 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         const char *g = chan + (blk * a.advance - a.hl - a.shift) * 8;      // uniform
 #pragma unroll
         for (int p = 0; p < 8; p++) {
+            // the piece's place in the transform goes into the SCALAR base, the lane's into the one vector
+            // offset all eight pieces share (eight per-piece vector offsets cost the wave-private form 4 spilled
+            // VGPRs, each reloaded behind an s_waitcnt vmcnt(0) between two requests)
             unsigned dst, off;
+            const char *gp;
             if constexpr (WP) {
                 // piece p of wave wv: rows p (lanes 0-31) and p + 8 (lanes 32-63) of columns 64 wv .. 64 wv + 63
                 dst = lds_base + (wv * WP_REGION + (unsigned)p * WP_PITCH) * 8u;
-                off = ((unsigned)p * 256u + 64u * wv) * 8u + lane_wp;
+                gp = g + ((unsigned)p * 256u + 64u * wv) * 8u;
+                off = lane_wp;
             } else {
                 const unsigned row = 4u * wv + (p >> 1), half = p & 1;
                 dst = lds_base + (row * LDS_K2_STRIDE + half * 128u) * 8u;
-                off = (row * 256u + half * 128u) * 8u + lane16;
+                gp = g + (row * 256u + half * 128u) * 8u;
+                off = lane16;
             }
             unsigned keep;
             // rows 0 and 15 (with hl = 256: the halo this transform re-reads and the one its successor will)
@@ -344,10 +350,10 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             const bool shared_row = !WP && ((a.halo_keep >> (4u * wv + (unsigned)(p >> 1))) & 1u);      // halo_keep: a mask over the 16 rows
             if (shared_row)
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(off), "s"(g), "s"(dst) : "memory");
+                             : "=&s"(keep) : "v"(off), "s"(gp), "s"(dst) : "memory");
             else
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(off), "s"(g), "s"(dst) : "memory");
+                             : "=&s"(keep) : "v"(off), "s"(gp), "s"(dst) : "memory");
         }
     };
 
