@@ -12,7 +12,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from simplefe_amd import build, lib  # noqa: E402
-lib.LIB_PATH = build.build_lib(diag=True)          # before anything loads the product library
+lib.LIB_PATH = os.environ.get("SFE_DIAG_LIB") or build.build_lib(diag=True)      # SFE_DIAG_LIB: a saved build to compare against          # before anything loads the product library
 from simplefe_amd import api, synth  # noqa: E402
 
 variants = sys.argv[1:] or ["3n", "3p", "2n", "2p"]

@@ -206,13 +206,22 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
     // a launch with no more transforms than workgroups (the per-block host calls) deals them by
     // blockIdx and leaves the counters alone: two atomic round trips less on a 10 us kernel
     const bool few = a.total <= gridDim.x;
-    auto draw = [&]() -> unsigned {
+    // A draw is ISSUED (the atomic goes out, nothing looks at what it returns) and FINISHED two stages later
+    // (reset on the last value, ticket -> transform): looked at where it is issued, the returning atomic is
+    // waited for with s_waitcnt vmcnt(0) -- behind the previous transform's 15 stores, which nothing else ever
+    // waits for -- by the wave every barrier of the transform then waits for.  (The file is compiled with the
+    // atomic optimizer off: its wave-aggregated form reads the result back at once.)
+    auto draw_issue = [&]() -> unsigned {
+        if (few) return 0u;
+        return __hip_atomic_fetch_add(my_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto draw_finish = [&](unsigned c) -> unsigned {
         if (few) return 0xFFFFFFFFu;
-        const unsigned c = __hip_atomic_fetch_add(my_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (c == last_draw) __hip_atomic_store(my_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long k = (((unsigned long long)(c >> a.tqs) * tg + grp) << a.tqs) + (c & (Q - 1u));
         return k < a.total ? (unsigned)k : 0xFFFFFFFFu;
     };
+    auto draw = [&]() -> unsigned { return draw_finish(draw_issue()); };
     const unsigned nblk32 = (unsigned)a.nblk;
     v2f hreg[16];
     if (HREG) {
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         }
         lds_barrier();
         unsigned drawn = 0;
-        if (TICKET && t == 0) drawn = draw();      // consumed two stages further down
+        if (TICKET && t == 0) drawn = draw_issue();      // finished two stages further down
         // ---- F2: gather n1 for (k2=hi, n0=lo)
         fresh_b();
 #pragma unroll
@@ -438,7 +447,11 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 #pragma unroll
             for (int k = 0; k < 16; k++) lds[cell_c(k)] = v[k];
         }
-        if (TICKET && t == 0) s_next = drawn;
+        // every wave "looks at" the draw here, so that the compiler's wait for the atomic sits HERE on every
+        // path: left to the one-lane branch below, the other waves' path keeps it pending and a vmcnt(0)
+        // appears in front of the stores -- behind the next transform's rows
+        if (TICKET) asm volatile("" : "+v"(drawn));
+        if (TICKET && t == 0) s_next = draw_finish(drawn);
         lds_barrier();
         if (TICKET) kt_next = __builtin_amdgcn_readfirstlane(s_next);
         // the transform after this one: (nch, nb), uniform

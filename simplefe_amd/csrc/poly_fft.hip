@@ -251,13 +251,17 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
     const unsigned Q = 1u << a.tqs, row = tg << a.tqs, rem = TICKET ? np32 % row : 0u;
     const unsigned mine = TICKET ? (np32 / row << a.tqs) + (rem > grp * Q ? (rem - grp * Q < Q ? rem - grp * Q : Q) : 0u) : 0u;
     const unsigned last_draw = TICKET ? mine + (gridDim.x - grp + tg - 1u) / tg - 1u : 0u;
-    auto draw = [&]() -> unsigned {
+    // issued early, looked at late (fir_fft.hip: draw_issue / draw_finish has the reasoning)
+    auto draw_issue = [&]() -> unsigned {
+        return __hip_atomic_fetch_add(a.ticket + 32u * grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto draw_finish = [&](unsigned c) -> unsigned {
         unsigned *const ctr = a.ticket + 32u * grp;
-        const unsigned c = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (c == last_draw) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long k = (((unsigned long long)(c >> a.tqs) * tg + grp) << a.tqs) + (c & (Q - 1u));
         return k < np32 ? (unsigned)k : 0xFFFFFFFFu;
     };
+    auto draw = [&]() -> unsigned { return draw_finish(draw_issue()); };
     long long first = blockIdx.x;
     if constexpr (TICKET) {
         if (t == 0) s_next = draw();
@@ -328,8 +332,9 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
                 }
         }
         lds_barrier();
-        unsigned drawn = 0xFFFFFFFFu;
-        if (TICKET && cur && t == 0) drawn = draw();       // published before the barrier that ends S2
+        unsigned drawn = 0u;
+        const bool drawing = TICKET && cur;
+        if (drawing && t == 0) drawn = draw_issue();       // finished and published before the barrier that ends S2
         // ---- S1: the transform (forward groups: staged samples; inverse groups: Y of the last pass)
         v2f v[16];
         asm volatile("" : "+v"(cell_in), "+v"(cell0));
@@ -359,6 +364,11 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
 #pragma unroll
         for (int r = 0; r < 16; r++) v[r] = lds[cell0 + 16u * l + r];
         dft16<-1>(v);                       // bin l + 16 k0 is in v[P16(k0)]
+        // the draw is finished and published HERE: nothing of this pass is in flight yet (its samples were
+        // consumed in S0), so the wait for the atomic waits for nothing else -- after S2 it would wait for
+        // S2's output stores.  s_next is read after the barrier that ends S2.
+        if (TICKET) asm volatile("" : "+v"(drawn));      // the wait sits here on every wave's path
+        if (TICKET && t == 0) s_next = drawing ? draw_finish(drawn) : 0xFFFFFFFFu;
         // ---- S2
         if (is_fwd) {
 #pragma unroll
@@ -409,7 +419,6 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
                 if (l == 0 && a.ovl == 0 && lim > 0) __builtin_nontemporal_store(v[P16(0)], reinterpret_cast<v2f *>(out_c + ko0 * 8));
             }
         }
-        if (TICKET && t == 0) s_next = drawn;
         lds_barrier();
         long long next = pass + gridDim.x;
         if constexpr (TICKET) {
