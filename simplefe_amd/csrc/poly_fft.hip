@@ -357,12 +357,15 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
             if ((k >> 2) && (k & 3)) x = cmul2(x, q2[k >> 2], p2[k & 3]);
             else if (k >> 2) x = cmul(x, q2[k >> 2]);
             else if (k & 3) x = cmul(x, p2[k & 3]);
-            lds[cell0 + 17u * k] = x;
+            if constexpr (DIAG & 16) v[P16(k)] = x;        // ablation: no exchange at all (results are not a transform)
+            else lds[cell0 + 17u * k] = x;
         }
         // the exchange stays inside this wave: program order + the compiler's waitcnt suffice
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if constexpr (!(DIAG & 16)) {
 #pragma unroll
         for (int r = 0; r < 16; r++) v[r] = lds[cell0 + 16u * l + r];
+        }
         dft16<-1>(v);                       // bin l + 16 k0 is in v[P16(k0)]
         // the draw is finished and published HERE: nothing of this pass is in flight yet (its samples were
         // consumed in S0), so the wait for the atomic waits for nothing else -- after S2 it would wait for
@@ -555,6 +558,7 @@ int launch_poly_fft(const PolyFftPlan &plan, const PolyFftArgs &a0, int data_com
             if (e[0] == 'L') return launch_one<5, 3, 2, false, false, 0, false, 1>(a, n_channels, s);
             if (e[0] == 'x') return launch_one<5, 3, 2, false, false, 8, true, 0>(a, n_channels, s);         // t with the round-1 XOR scatter layout
             if (e[0] == 'h') return launch_one<5, 3, 2, false, false, 0, true, 2>(a, n_channels, s);         // half before S3, half after
+            if (e[0] == 'e') return launch_one<5, 3, 2, false, false, 16, true, 0>(a, n_channels, s);        // t without the in-wave exchange (upper bound for doing it off the LDS)
             if (e[0] == 'w') return launch_one<5, 3, 2, false, false, 0, true, 0, 3>(a, n_channels, s);     // 3 workgroups per CU, 168 VGPRs: no spill
         }
     }
