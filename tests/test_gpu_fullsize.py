@@ -309,3 +309,52 @@ def test_bulk_kernels_are_deterministic_run_to_run():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("12 runs") == 4, r.stdout
+
+
+def test_fir_single_channel_beyond_4_gib(api, L, orc):
+    """One channel of 2^29 + 12 345 cf32 samples: 4 GiB + of input and of output in ONE stream, so byte
+    offsets inside a channel pass 2^32 (the 64-channel config only has channel BASES that far out).
+    Windows at the start, either side of the 4 GiB byte boundary (sample 2^29), at a transform seam
+    beyond it and at the ragged end."""
+    n = (1 << 29) + 12345
+    taps = synth.taps_cfg2()
+    x = api.DeviceArray(2 * n)
+    x.fill_synth(synth.SEED)
+    y = api.DeviceArray(2 * n)
+    f = api.Fir(taps, data_complex=True)          # the product's default kernel
+    f.process_stream(x, y, n)
+    W, H = 1 << 12, 255
+    seam = 3840 * ((1 << 29) // 3840 + 2)
+    for s0 in (0, (1 << 29) - W // 2, (1 << 29) + 5, seam - 100, n - W):
+        lo = max(0, s0 - H)
+        seg = synth.synth_cf32(s0 + W - lo, first_sample=lo)
+        got = _window(y, s0, W)
+        for part in (0, 1):
+            ref = orc.Blkconv(taps, 4096).stream(np.ascontiguousarray(seg[part::2]))[s0 - lo:]
+            assert synth.rel_rms(got[part::2], ref) <= TOL, (s0, part)
+    x.free()
+    y.free()
+
+
+def test_resample_beyond_4_gib_input(api, L, orc, monkeypatch):
+    """Resample 5/3 (381 taps, the default transform-domain kernel) over 2^29 + 2^22 + 777 cf32 samples:
+    input byte offsets pass 2^32 with 32 MiB to go.  Windows of the output whose inputs sit either side of that boundary, at a
+    pass seam beyond it and at the end, against the oracle."""
+    monkeypatch.delenv("SFE_RS_FFT", raising=False)
+    monkeypatch.delenv("SFE_RS_MFMA", raising=False)
+    n = (1 << 29) + (1 << 22) + 777
+    taps = synth.taps_cfg3()
+    x = api.DeviceArray(2 * n)
+    x.fill_synth(synth.SEED)
+    cap = n * 3 // 5 + 8
+    y = api.DeviceArray(2 * cap)
+    r = api.Rs(taps, 3, 4096, mode=L.RS_RESAMPLE, data_complex=True)
+    k = r.process_stream(x, n, y, cap, 5.0 / 3.0)
+    assert abs(k - (n * 3 + 4) // 5) <= 1
+    W, P = 4200, 1386
+    kb = ((1 << 29) * 3) // 5                  # the output whose input is sample 2^29 (byte offset 2^32)
+    k0s = [0, kb - W // 2, kb + 7, P * (kb // P + 3) - 700, k - W - 2]
+    k0s = [k0 - k0 % 3 for k0 in k0s]
+    _rs_windows_vs_oracle(orc, "Resample", y, taps, 3, 5, k0s, W, n, exact=False, hist_samples=150)
+    x.free()
+    y.free()
