@@ -134,7 +134,8 @@ int sfe_dsp_fir_set_algo(sfe_fir_t h, int algo);
 /* Pipelined host streaming for scheduler-sized calls.  A GNU Radio scheduler
  * hands a block a few thousand items per work() call (gr-simplefe/lib/sink_c_impl.cc:157-174,
  * source_c_impl.cc:134-153); one synchronous round trip per call is launch/sync bound.  A pipe
- * over a single-channel float32 FIR handle collects pushed items in pinned batches of
+ * over a single-channel FIR handle (float32 items, or u8 wire-format items in when the handle's
+ * input format is SFE_FMT_U8; float32 items out) collects pushed items in pinned batches of
  * `batch_items` (0 = 262144) and keeps up to four batches in flight on three streams (copy in,
  * filter, copy out); pull hands out finished items in order.  Item k out is the filter's output
  * for item k in: no delay is inserted, only latency.  While a pipe exists, drive its handle only

@@ -1879,8 +1879,8 @@ int sfe_dsp_fir_pipe_create(sfe_fir_t fir, size_t batch_items, sfe_pipe_t *out)
     if (!out) return SFE_EINVAL;
     *out = nullptr;
     Fir *f = as_fir(fir);
-    if (!f || f->n_channels != 1 || f->in_u8 || f->out_tx10) {
-        set_error("fir_pipe_create: needs a single-channel float32 FIR handle");
+    if (!f || f->n_channels != 1 || f->out_tx10) {
+        set_error("fir_pipe_create: needs a single-channel FIR handle with float32 output");
         return SFE_EINVAL;
     }
     if (batch_items == 0) batch_items = (size_t)1 << 18;
@@ -1894,7 +1894,9 @@ int sfe_dsp_fir_pipe_create(sfe_fir_t fir, size_t batch_items, sfe_pipe_t *out)
     p->f = f;
     p->device = f->device;
     p->batch = p->out_cap = batch_items;
-    p->in_e = f->data_complex ? 8 : 4;
+    // items in: float32 samples, or the u8 wire format when the handle converts on load (SFE_FMT_U8:
+    // 2 bytes per complex item, 1 per real one -- a receive chain hands the device's bytes straight in)
+    p->in_e = f->in_u8 ? (f->data_complex ? 2 : 1) : (f->data_complex ? 8 : 4);
     p->out_e = f->out_complex ? 8 : 4;
     return pipe_alloc(p, out);
 }

@@ -902,6 +902,54 @@ def test_rs_pipe_equals_the_reference_stream(api, L, orc, U, rate, blk, n_taps, 
     assert 0 <= len(ref) - k <= 1 and np.array_equal(out[:k], ref[:k])
 
 
+@pytest.mark.parametrize("cplx", [True, False])
+def test_fir_pipe_takes_the_u8_wire_format(api, L, orc, cplx):
+    """sfe_dsp_fir_pipe_* over a handle whose input format is the receive wire format: u8 items in (2 bytes per
+    complex item, gr-simplefe/lib/source_c_impl.cc:121-132), float32 items out, scheduler-sized pushes.
+    Bit for bit the bulk device call on the same bytes, and within the bar of the oracle's conversion + filter."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    n = 300001
+    per = 2 if cplx else 1
+    raw = rng.integers(0, 256, size=per * n, dtype=np.uint8)
+    taps = synth.taps_cfg2()
+    f = api.Fir(taps, data_complex=cplx)
+    f.set_input_format(L.FMT_U8)
+    lib = L.load()
+    p = C.c_void_p()
+    api.check(lib.sfe_dsp_fir_pipe_create(f._h, 1 << 16, C.byref(p)))
+    out = np.zeros(per * n, np.float32)
+    taken, got = C.c_size_t(0), C.c_size_t(0)
+    off = k = 0
+    sizes = [4096, 1001, 8191, 37, 16384]
+    i = 0
+    while off < n:
+        m = min(sizes[i % 5], n - off)
+        i += 1
+        api.check(lib.sfe_dsp_pipe_push(p, raw.ctypes.data + per * off, m, C.byref(taken)))
+        off += taken.value
+        api.check(lib.sfe_dsp_pipe_pull(p, out.ctypes.data + 4 * per * k, 6000, 0 if taken.value else 1, C.byref(got)))
+        k += got.value
+    while True:
+        api.check(lib.sfe_dsp_pipe_pull(p, out.ctypes.data + 4 * per * k, 6000, 2, C.byref(got)))
+        if got.value == 0:
+            break
+        k += got.value
+    lib.sfe_dsp_pipe_destroy(p)
+    assert k == n
+    # the bulk call on the same bytes, cut where the pipe cut its batches (the FFT kernel's results do not depend on the cut)
+    g = api.Fir(taps, data_complex=cplx)
+    g.set_input_format(L.FMT_U8)
+    d_in, d_out = api.DeviceArray.from_bytes(raw), api.DeviceArray(per * n)
+    g.process_stream(d_in, d_out, n)
+    bulk = d_out.to_numpy(per * n)
+    assert synth.rel_rms(out, bulk) <= 2e-6
+    xf = orc.rx_u8_to_cf32(raw) if cplx else orc.rx_u8_to_f32(raw)
+    for part in range(per):
+        ref = orc.Blkconv(taps, 4096).stream(np.ascontiguousarray(xf[part::per]))
+        assert synth.rel_rms(out[part::per], ref) <= TOL
+
+
 def test_stream_entry_points_reject_bad_buffers(api, L):
     """sfe_dsp_rs_process_stream has the checks the FIR entry has -- channel strides that
     would let channels overwrite each other, pointers not aligned to their element, input and
