@@ -229,6 +229,9 @@ int sfe_dsp_rs_set_input_format(sfe_rs_t h, int fmt);
 int sfe_dsp_rs_load_history(sfe_rs_t h, const void *d_prev, size_t n_prev, size_t stride,
                             sfe_stream_t stream);
 int sfe_dsp_rs_seek(sfe_rs_t h, uint64_t first_sample, float rate);
+/* the host pipe (sfe_dsp_pipe_*) over a single-channel resample / decimate handle at `rate`: batches of whole
+ * blksize-sample reference calls; items in are float32 samples, or u8 wire-format items when the handle's input
+ * format is SFE_FMT_U8 (integer-valued steps); items out float32 */
 int sfe_dsp_rs_pipe_create(sfe_rs_t rs, size_t batch_items, float rate, sfe_pipe_t *out);
 int sfe_dsp_rs_reset(sfe_rs_t h);
 int sfe_dsp_rs_destroy(sfe_rs_t h);

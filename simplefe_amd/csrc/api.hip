@@ -1906,8 +1906,8 @@ int sfe_dsp_rs_pipe_create(sfe_rs_t rs, size_t batch_items, float rate, sfe_pipe
     if (!out) return SFE_EINVAL;
     *out = nullptr;
     Rs *r = as_rs(rs);
-    if (!r || r->n_channels != 1 || r->in_u8) {
-        set_error("rs_pipe_create: needs a single-channel float32 resample/decimate handle");
+    if (!r || r->n_channels != 1) {
+        set_error("rs_pipe_create: needs a single-channel resample/decimate handle");
         return SFE_EINVAL;
     }
     if (r->mode == SFE_RS_RESAMPLE ? (rate < 1.0 / r->U) : (rate < 1.0)) {
@@ -1930,7 +1930,8 @@ int sfe_dsp_rs_pipe_create(sfe_rs_t rs, size_t batch_items, float rate, sfe_pipe
     p->device = r->device;
     p->batch = batch_items;
     p->out_cap = (size_t)ceil((double)batch_items / (double)rate) + 8;
-    p->in_e = p->out_e = (size_t)r->esz();
+    p->out_e = (size_t)r->esz();
+    p->in_e = r->in_u8 ? (r->data_complex ? 2 : 1) : p->out_e;      // u8 wire-format items in (integer-valued steps)
     return pipe_alloc(p, out);
 }
 

@@ -950,6 +950,43 @@ def test_fir_pipe_takes_the_u8_wire_format(api, L, orc, cplx):
         assert synth.rel_rms(out[part::per], ref) <= TOL
 
 
+def test_rs_pipe_takes_the_u8_wire_format(api, L, orc, g5):
+    """sfe_dsp_rs_pipe_* over a decimate-by-8 handle reading the receive wire format (`source_c -> decimate`):
+    u8 items in (2 bytes per complex item), cf32 items out, scheduler-sized pushes; within the bar of
+    converter -> oracle, nothing lost at the end."""
+    import ctypes as C
+    taps, U, rate = g5["cfg4_taps"], int(g5["cfg4_U"]), float(g5["cfg4_rate"])
+    n = 200000
+    raw = _u8_stream(2 * n, 3)
+    r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=True)
+    r.set_input_format(L.FMT_U8)
+    lib = L.load()
+    p = C.c_void_p()
+    api.check(lib.sfe_dsp_rs_pipe_create(r._h, 1 << 15, rate, C.byref(p)))
+    out = np.zeros(2 * (int(n / rate) + 4096), np.float32)
+    taken, got = C.c_size_t(0), C.c_size_t(0)
+    off = k = i = 0
+    sizes = [4096, 1001, 8191, 37, 16384]
+    while off < n:
+        m = min(sizes[i % 5], n - off)
+        i += 1
+        api.check(lib.sfe_dsp_pipe_push(p, raw.ctypes.data + 2 * off, m, C.byref(taken)))
+        off += taken.value
+        api.check(lib.sfe_dsp_pipe_pull(p, out.ctypes.data + 8 * k, 3000, 0 if taken.value else 1, C.byref(got)))
+        k += got.value
+    while True:
+        api.check(lib.sfe_dsp_pipe_pull(p, out.ctypes.data + 8 * k, 3000, 2, C.byref(got)))
+        if got.value == 0:
+            break
+        k += got.value
+    lib.sfe_dsp_pipe_destroy(p)
+    xf = orc.rx_u8_to_f32(raw)
+    for part in (0, 1):
+        ref, _ = orc.Resample(taps, U, 4096).stream(np.ascontiguousarray(xf[part::2]), rate)
+        assert 0 <= len(ref) - k <= 1
+        assert synth.rel_rms(out[part:2 * k:2], ref[:k]) <= TOL
+
+
 def test_stream_entry_points_reject_bad_buffers(api, L):
     """sfe_dsp_rs_process_stream has the checks the FIR entry has -- channel strides that
     would let channels overwrite each other, pointers not aligned to their element, input and
