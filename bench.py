@@ -204,7 +204,8 @@ class Leg:
     """One workload on this rank's GPU: buffers, the handle, step(), and the parity check."""
 
 
-def make_fir_leg(ctx, name, taps, log2n, nch, algo="auto", in_fmt="f32", out_fmt="f32", x_share=None):
+def make_fir_leg(ctx, name, taps, log2n, nch, algo="auto", in_fmt="f32", out_fmt="f32", x_share=None, per_channel=False,
+                 y_share=None):
     torch, api, lib, synth, shard = ctx["torch"], ctx["api"], ctx["lib"], ctx["synth"], ctx["shard"]
     dev, stream, L = ctx["dev"], ctx["stream"], ctx["L"]
     leg = Leg()
@@ -223,8 +224,11 @@ def make_fir_leg(ctx, name, taps, log2n, nch, algo="auto", in_fmt="f32", out_fmt
     in_bytes, out_bytes = 8.0, 8.0
     src = x
     ctaps = bool(np.iscomplexobj(taps))
+    n_taps = taps.shape[-1]
     leg.workload = "%d-tap %sFIR (blkconv law), 2^%d cf32 samples per GPU, %d channel(s) x 2^%d, device-resident in/out" % (
-        len(taps), "complex-tap " if ctaps else "", log2n, nch, log2n - (nch.bit_length() - 1))
+        n_taps, "complex-tap " if ctaps else "", log2n, nch, log2n - (nch.bit_length() - 1))
+    if per_channel:
+        leg.workload += ", a different filter per channel"
     leg.key = "fir256_cf32_2p%d%s%s" % (log2n, "_ctaps" if ctaps else "", "_direct" if algo == "direct" else "")
     if nch > 1:
         leg.key += "_%dch" % nch
@@ -237,8 +241,12 @@ def make_fir_leg(ctx, name, taps, log2n, nch, algo="auto", in_fmt="f32", out_fmt
         leg.key += "_u8"
         leg.workload += ", u8 (I,Q) wire-format input converted on load"
     leg.x = x
-    leg.obj = api.Fir(taps, data_complex=True, n_channels=nch, device=ctx["local_rank"],
-                      algo={"auto": lib.FIR_ALGO_AUTO, "fft": lib.FIR_ALGO_FFT, "direct": lib.FIR_ALGO_DIRECT}[algo])
+    if per_channel:
+        leg.obj = api.Fir(taps, per_channel=True, device=ctx["local_rank"])
+        leg.key += "_pctaps"
+    else:
+        leg.obj = api.Fir(taps, data_complex=True, n_channels=nch, device=ctx["local_rank"],
+                          algo={"auto": lib.FIR_ALGO_AUTO, "fft": lib.FIR_ALGO_FFT, "direct": lib.FIR_ALGO_DIRECT}[algo])
     if in_fmt == "u8":
         leg.obj.set_input_format(lib.FMT_U8)
     if out_fmt == "tx10":
@@ -248,7 +256,7 @@ def make_fir_leg(ctx, name, taps, log2n, nch, algo="auto", in_fmt="f32", out_fmt
         leg.workload += ", 10-bit packed transmit wire format out"
         leg.y = torch.empty(nch * (n * 2 // 4) * 5 + 64, dtype=torch.uint8, device=dev)
     else:
-        leg.y = torch.empty(nch * n * 2, dtype=torch.float32, device=dev)
+        leg.y = y_share if y_share is not None else torch.empty(nch * n * 2, dtype=torch.float32, device=dev)
     leg.out_fmt = out_fmt
     leg.bytes_per_launch = (in_bytes + out_bytes) * n_gpu       # 8 B read + 8 B written per sample
     leg.kernel = "fir_fft4096_kernel" if algo != "direct" else "poly_tiled_kernel"
@@ -265,9 +273,7 @@ def make_fir_leg(ctx, name, taps, log2n, nch, algo="auto", in_fmt="f32", out_fmt
         """Windows of the LAST step's output against the oracle (history = the tail of the same
         buffer fed in the previous step).  Returns the worst rel-RMS (tx10: fraction of bytes off)."""
         from oracle import binding as orc
-        W, hlen = 1 << 13, len(taps) - 1
-        tr = np.ascontiguousarray(np.real(taps), dtype=np.float32)
-        ti = np.ascontiguousarray(np.imag(taps), dtype=np.float32) if ctaps else None
+        W, hlen = 1 << 13, n_taps - 1
         chans = sorted(set([0, nch - 1] if not full else range(nch)))
         starts = [0, 3840 - 100, n // 2 - 77, n - W]
         if nch > 2:
@@ -275,6 +281,9 @@ def make_fir_leg(ctx, name, taps, log2n, nch, algo="auto", in_fmt="f32", out_fmt
         worst, count = 0.0, 0
         blk = lambda t, v: orc.Blkconv(t, 4096).stream(np.ascontiguousarray(v))
         for c in chans:
+            tc = taps[c] if per_channel else taps
+            tr = np.ascontiguousarray(np.real(tc), dtype=np.float32)
+            ti = np.ascontiguousarray(np.imag(tc), dtype=np.float32) if ctaps else None
             xc = leg.x[2 * n * c: 2 * n * (c + 1)]
             for s0 in starts:
                 s0 = max(0, min(s0, n - W))
@@ -553,6 +562,8 @@ def main():
         makers = [lambda: make_rs_leg(ctx, "resample", 28), lambda: make_rs_leg(ctx, "resample", 28, short_proto=True),
                   lambda: make_rs_leg(ctx, "decimate", 30),
                   lambda: make_fir_leg(ctx, "fir_64ch", synth.taps_cfg2(), 30, 64),
+                  lambda: make_fir_leg(ctx, "fir_64ch_pctaps", synth.taps_per_channel(64), 30, 64, per_channel=True,
+                                       x_share=next(l.x for l in others if l.name == "fir_64ch")),
                   lambda: make_fir_leg(ctx, "fir_ctaps", (tr + 1j * ti).astype(np.complex64), 28, 1, x_share=head.x)]
         for mk in makers:      # an extra leg that cannot be set up is reported, never allowed to take the headline with it
             try:

@@ -93,6 +93,13 @@ int sfe_dsp_synth_fill(void *dptr, uint64_t n_floats, uint32_t seed, uint32_t ch
  *   device        HIP device ordinal. */
 int sfe_dsp_fir_create(const float *taps, int n_taps, int taps_complex, int data_complex,
                        int n_channels, int block_hint, int device, sfe_fir_t *out);
+
+/* The same with a tap vector PER CHANNEL (what 64 reference objects with 64 different filters are):
+ *   taps  [n_channels][n_taps] floats ([n_channels][n_taps] (re,im) pairs when taps_complex); copied.
+ * Complex float32 streams, the FFT path (any n_taps it takes); one launch covers all channels, a
+ * channel's spectrum is read per transform instead of being held in registers.  No host block. */
+int sfe_dsp_fir_create_per_channel(const float *taps, int n_taps, int taps_complex, int n_channels,
+                                   int device, sfe_fir_t *out);
 /* Host-only (no GPU): how a tap count is served by the 4096-point kernel -- the overlap of one
  * transform (a multiple of 256), the number of tap partitions (one launch each; 1 for any filter
  * a single transform overlaps economically, i.e. up to ~2800 taps) and the samples a transform

@@ -110,10 +110,23 @@ class Timer:
 class Fir:
     """One FIR stream set (sfe_dsp_fir_*): taps real (n,) or complex (n,) complex64."""
 
-    def __init__(self, taps, data_complex=True, n_channels=1, block_hint=0, device=0, algo=_l.FIR_ALGO_AUTO):
+    def __init__(self, taps, data_complex=True, n_channels=1, block_hint=0, device=0, algo=_l.FIR_ALGO_AUTO,
+                 per_channel=False):
         self._L = _l.load()
         taps = np.asarray(taps)
         self.taps_complex = bool(np.iscomplexobj(taps))
+        if per_channel:
+            # taps: (n_channels, n_taps), one filter per channel (sfe_dsp_fir_create_per_channel); cf32 streams
+            assert taps.ndim == 2
+            n_channels, n_taps = taps.shape
+            t = (np.ascontiguousarray(taps.astype(np.complex64)).view(np.float32) if self.taps_complex
+                 else _f32(taps)).reshape(-1)
+            self.n_taps, self.data_complex, self.out_complex, self.n_channels = n_taps, True, True, n_channels
+            h = C.c_void_p()
+            check(self._L.sfe_dsp_fir_create_per_channel(t.ctypes.data, n_taps, int(self.taps_complex), n_channels,
+                                                         device, C.byref(h)))
+            self._h = h.value
+            return
         if self.taps_complex:
             t = np.ascontiguousarray(taps.astype(np.complex64)).view(np.float32)
             n_taps = t.size // 2

@@ -342,6 +342,7 @@ struct Fir {
     int blk = 0, block_hint = 0;
     int hl = 0;                 // carried history per channel, samples (multiple of 256)
     int ovl = 0;                // overlap of one transform (multiple of 256): each launch applies `ovl` (+1) taps
+    int per_channel = 0;        // taps given per channel ([n_channels][n_taps]): one spectrum set per channel
     int parts = 1;              // partitions of the tap vector, one launch each (filters longer than one overlap)
     bool fft_ok = false;
     v2f *d_hs = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr;
@@ -440,21 +441,26 @@ static int fir_build_tables(Fir *f, const float *taps)
                 }
         }
     };
-    std::vector<v2f> hs((size_t)f->parts * 16 * 256), tw1(7 * 256), tw2(7 * 16);
+    // one set of spectra per tap vector: one for all channels, or (per_channel) channel by channel, [set][partition][k0][t]
+    const int n_sets = f->per_channel ? f->n_channels : 1;
+    std::vector<v2f> hs((size_t)n_sets * f->parts * 16 * 256), tw1(7 * 256), tw2(7 * 16);
     std::vector<double> hr(N), hi(N);
+    for (int set = 0; set < n_sets; set++) {
+    const float *tp = taps + (size_t)set * f->n_taps * (f->taps_complex ? 2 : 1);
     for (int p = 0; p < f->parts; p++) {
         const int first = f->parts == 1 ? 0 : p * f->ovl;
         const int count = f->parts == 1 ? f->n_taps : (f->n_taps - first < f->ovl ? f->n_taps - first : f->ovl);
         for (int n = 0; n < N; n++) {
-            hr[n] = n < count ? (f->taps_complex ? taps[2 * (first + n)] : taps[first + n]) / (double)N : 0.0;
-            hi[n] = n < count && f->taps_complex ? taps[2 * (first + n) + 1] / (double)N : 0.0;
+            hr[n] = n < count ? (f->taps_complex ? tp[2 * (first + n)] : tp[first + n]) / (double)N : 0.0;
+            hi[n] = n < count && f->taps_complex ? tp[2 * (first + n) + 1] / (double)N : 0.0;
         }
         fft(hr, hi);
         for (int t = 0; t < 256; t++)
             for (int k0 = 0; k0 < 16; k0++) {
                 const int bin = (t >> 4) + 16 * (t & 15) + 256 * k0;
-                hs[((size_t)p * 16 + k0) * 256 + t] = (v2f){(float)hr[bin], (float)hi[bin]};
+                hs[(((size_t)set * f->parts + p) * 16 + k0) * 256 + t] = (v2f){(float)hr[bin], (float)hi[bin]};
             }
+    }
     }
     // twiddle bases: row k (1..3) = W^(e k), row k+3 = W^(4 e k); the kernel forms
     // W^(e (4a+b)) as row[a+3] * row[b]
@@ -541,6 +547,7 @@ static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_st
         a.ticket = f->d_ticket;
         a.total = 0;
         a.tgroups = 0;
+        a.hs_stride = f->per_channel ? (long long)f->parts * 16 * 256 : 0;
         rc = SFE_OK;
         // one launch per tap partition: partition p filters the stream delayed by p*ovl samples and
         // (p > 0) adds to what the earlier ones wrote
@@ -551,8 +558,8 @@ static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_st
             rc = launch_fir_fft(a, f->data_complex, f->out_complex, f->in_u8, f->out_tx10, f->n_channels, s, p > 0);
         }
     } else {
-        if (f->taps_complex || f->in_u8 || f->out_tx10) {
-            set_error("fir: the direct kernel takes real taps and float input/output; use SFE_FIR_ALGO_FFT");
+        if (f->taps_complex || f->in_u8 || f->out_tx10 || f->per_channel) {
+            set_error("fir: the direct kernel takes one set of real taps and float input/output; use SFE_FIR_ALGO_FFT");
             return SFE_EINVAL;
         }
         const PolyTiledPlan *pl = get_tiled_plan(f->plans, f->h_taps, 1, f->n_taps, 1, 0, &rc);
@@ -835,8 +842,8 @@ int sfe_dsp_synth_fill(void *dptr, uint64_t n_floats, uint32_t seed, uint32_t ch
 }
 
 // ---------------------------------------------------------------------------- FIR
-int sfe_dsp_fir_create(const float *taps, int n_taps, int taps_complex, int data_complex,
-                       int n_channels, int block_hint, int device, sfe_fir_t *out)
+static int fir_create_impl(const float *taps, int n_taps, int taps_complex, int data_complex,
+                           int n_channels, int block_hint, int device, int per_channel, sfe_fir_t *out)
 {
     if (!out) return SFE_EINVAL;
     *out = nullptr;
@@ -860,10 +867,16 @@ int sfe_dsp_fir_create(const float *taps, int n_taps, int taps_complex, int data
     f->data_complex = data_complex ? 1 : 0;
     f->out_complex = (f->taps_complex || f->data_complex) ? 1 : 0;
     f->n_channels = n_channels;
+    f->per_channel = per_channel ? 1 : 0;
     f->device = device;
     f->block_hint = block_hint;
     f->blk = block_hint ? block_hint + 1 - n_taps : 0;
     f->fft_ok = fir_choose_partition(n_taps, &f->ovl, &f->parts);
+    if (f->per_channel && !f->fft_ok) {
+        delete f;
+        set_error("fir_create_per_channel: %d taps exceed %d partitions of the 4096-point kernel", n_taps, FIR_MAX_PARTS);
+        return SFE_ERANGE;
+    }
     if (f->fft_ok) f->hl = f->parts * f->ovl;                       // history the slowest partition reaches back to
     else f->hl = ((n_taps - 1 + 255) / 256) * 256;                  // beyond FIR_MAX_PARTS partitions: direct kernel only
     auto fail = [&](int code) { fir_free(f); return code; };
@@ -873,7 +886,7 @@ int sfe_dsp_fir_create(const float *taps, int n_taps, int taps_complex, int data
         rc = fir_build_tables(f, taps);
         if (rc != SFE_OK) return fail(rc);
     }
-    if (!f->taps_complex) {
+    if (!f->taps_complex && !f->per_channel) {
         f->h_taps.assign(taps, taps + n_taps);
         TRY(hipMalloc(&f->d_taps, (size_t)n_taps * sizeof(float)));
         TRY(hipMemcpy(f->d_taps, taps, (size_t)n_taps * sizeof(float), hipMemcpyHostToDevice));
@@ -900,6 +913,18 @@ int sfe_dsp_fir_create(const float *taps, int n_taps, int taps_complex, int data
 #undef TRY
     *out = f;
     return SFE_OK;
+}
+
+int sfe_dsp_fir_create(const float *taps, int n_taps, int taps_complex, int data_complex,
+                       int n_channels, int block_hint, int device, sfe_fir_t *out)
+{
+    return fir_create_impl(taps, n_taps, taps_complex, data_complex, n_channels, block_hint, device, 0, out);
+}
+
+int sfe_dsp_fir_create_per_channel(const float *taps, int n_taps, int taps_complex, int n_channels, int device,
+                                   sfe_fir_t *out)
+{
+    return fir_create_impl(taps, n_taps, taps_complex, 1, n_channels, 0, device, 1, out);
 }
 
 int sfe_dsp_fir_plan(int n_taps, int *overlap, int *partitions, int *advance)

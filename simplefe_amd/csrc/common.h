@@ -61,6 +61,7 @@ struct FirFftArgs {
                           // draw transforms from; zero between launches
     unsigned    total;    // set by the launcher: transforms over all channels (channel-major tickets)
     unsigned    tgroups;  // set by the launcher: counters in use (workgroup b draws from counter b % tgroups)
+    long long   hs_stride; // 0: one spectrum for every channel; else channel c's spectra start c*hs_stride elements after hs (per-channel taps: read per transform, not held in registers)
     unsigned    tqs;      // set by the launcher: a group draws runs of 2^tqs CONSECUTIVE transforms (their halos meet in its L2)
     unsigned    halo_keep; // set by the launcher: mask of input rows loaded WITHOUT the nontemporal hint (0x8001: the two rows a neighbour re-reads)
 };

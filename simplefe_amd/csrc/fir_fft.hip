@@ -94,9 +94,13 @@ __device__ __forceinline__ void store_group(unsigned char *d, unsigned u0, unsig
 // variant lost a resident workgroup to its 32 extra VGPRs).  F1 then reads its column from LDS.
 // Edge transforms (history in front, ragged end) keep the guarded register loads.
 template <bool IN_C, bool OUT_C, int WAVES, bool PREFETCH, bool SWZ, bool HREG = false, bool IN_U8 = false, bool PAIR = false,
-          bool OUT_TX10 = false, bool DMA = false, int DIAG = 0, bool TICKET = true, bool ACC = false, bool WP = false>
+          bool OUT_TX10 = false, bool DMA = false, int DIAG = 0, bool TICKET = true, bool ACC = false, bool WP = false,
+          bool HCH = false>
 __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 {
+    // HCH (with HREG): per-channel taps -- the spectrum registers are reloaded when the workgroup's next transform
+    // belongs to another channel (channel-major tickets: every few transforms at 64 x 2^24, not every one)
+    static_assert(!HCH || (HREG && TICKET), "per-channel spectra ride the register-resident, ticketed kernels");
     // WP (with DMA): wave-private [n2|k2][column] layout.  Thread t touches column t of the first /
     // last exchange layout in F1 (read + write), I3 (read) and nothing else does between the I2->I3
     // barrier and the F1->F2 barrier; if every wave's 64 columns sit in a region of their own AND the
@@ -160,7 +164,15 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
     const char *in_c, *hist_c;
     char *out_c;
     auto in_of = [&](int c) -> const char * { return static_cast<const char *>(a.in) + (size_t)c * a.in_stride * ISZ; };
+    v2f hreg[16];
     auto set_channel = [&](int c) {
+        if constexpr (HCH) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                hreg[k] = (a.hs + (size_t)c * a.hs_stride + k * 256)[threadIdx.x];
+                asm volatile("" : "+v"(hreg[k]));
+            }
+        }
         in_c = in_of(c);
         // 10-bit output: the channel's floats (2 per complex sample) in whole groups of 4 -> 5 bytes
         out_c = static_cast<char *>(a.out) + (OUT_TX10 ? (size_t)c * (a.out_stride * (OUT_C ? 2 : 1) / 4) * 5 : (size_t)c * a.out_stride * (OUT_C ? 8 : 4));
@@ -223,8 +235,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
     };
     auto draw = [&]() -> unsigned { return draw_finish(draw_issue()); };
     const unsigned nblk32 = (unsigned)a.nblk;
-    v2f hreg[16];
-    if (HREG) {
+    if (HREG && !HCH) {
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             hreg[k] = (a.hs + k * 256)[t];
@@ -440,7 +451,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             // with the transposed schedule, which consumes exactly that order: no shuffling.
             // H/N for this thread's 16 bins is streamed from L2 each transform.
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[P16(k)] = cmul(v[P16(k)], HREG ? hreg[k] : (a.hs + k * 256)[t]);
+            for (int k = 0; k < 16; k++) v[P16(k)] = cmul(v[P16(k)], HREG ? hreg[k] : (a.hs + (size_t)ch * a.hs_stride + k * 256)[t]);
             dft16_rev<+1>(v);
             // I1: element n0 goes back to the cell this thread read n0 from (no barrier needed)
             fresh_c();
@@ -1070,7 +1081,16 @@ int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in
     }
 #endif
     //       IN_C   OUT_C  WAVES PREFETCH SWZ  HREG  IN_U8  PAIR   OUT_TX10 DMA DIAG TICKET ACC
-    if (accumulate) {           // partitions after the first: out += this partition's result
+    if (a.hs_stride) {          // per-channel taps: the channel's spectrum is read per transform (cf32 streams only)
+        if (!in_complex || !out_complex || in_u8 || out_tx10) {
+            set_error("fir_fft: per-channel taps are built for complex float32 streams");
+            return SFE_EINVAL;
+        }
+        //                         IN_C  OUT_C W  PREF   SWZ    HREG  IN_U8  PAIR   TX10   DMA    DG TICKET ACC   WP     HCH
+        if (accumulate) SFE_K(true, true, 4, false, false, true, false, false, false, false, 0, true, true, false, true);
+        else if (dma_ok) SFE_K(true, true, 4, false, false, true, false, false, false, true, 0, true, false, false, true);
+        else SFE_K(true, true, 4, false, false, true, false, false, false, false, 0, true, false, false, true);
+    } else if (accumulate) {           // partitions after the first: out += this partition's result
         if (in_complex) {
             if (in_u8) SFE_K(true, true, 4, false, false, true, true, false, false, false, 0, true, true);
             else SFE_K(true, true, 4, false, false, true, false, false, false, false, 0, true, true);

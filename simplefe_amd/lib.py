@@ -44,6 +44,7 @@ SIGNATURES = {
     "sfe_dsp_timer_destroy": (i32, [vp]),
     "sfe_dsp_synth_fill": (i32, [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, vp]),
     "sfe_dsp_fir_create": (i32, [vp, i32, i32, i32, i32, i32, i32, C.POINTER(vp)]),
+    "sfe_dsp_fir_create_per_channel": (i32, [vp, i32, i32, i32, i32, C.POINTER(vp)]),
     "sfe_dsp_fir_plan": (i32, [i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "sfe_dsp_fir_host_buffer": (i32, [vp, C.POINTER(fp), C.POINTER(i32)]),
     "sfe_dsp_fir_process_block": (i32, [vp]),

@@ -68,6 +68,19 @@ def taps_cfg2():
     return lowpass_taps(256, 0.2)
 
 
+def taps_per_channel(n_channels, n_taps=256):
+    """cfg5's "per-channel-distinct taps" variant: channel c's 256-tap Hamming
+    windowed-sinc low-pass at cut-off 0.10 + 0.30 c / n_channels (float64 formula, rounded to float32)."""
+    k = np.arange(n_taps, dtype=np.float64) - (n_taps - 1) / 2.0
+    w = 0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(n_taps) / (n_taps - 1))
+    out = np.empty((n_channels, n_taps), dtype=np.float32)
+    for c in range(n_channels):
+        fc = 0.10 + 0.30 * c / n_channels
+        h = fc * np.sinc(fc * k) * w
+        out[c] = (h / h.sum()).astype(np.float32)
+    return out
+
+
 def taps_cfg3():
     """381-tap prototype for U=3 (127 taps per polyphase arm), rate 5/3, DC gain U."""
     return lowpass_taps(381, 0.18, gain=3.0)

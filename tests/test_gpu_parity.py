@@ -142,6 +142,43 @@ def test_fir_multichannel_strided(api, L):
         assert not y[c, 2 * n:].any()       # padding untouched
 
 
+@pytest.mark.parametrize("n_taps,ctaps", [(256, False), (63, True), (1000, False)])
+def test_fir_per_channel_taps(api, L, orc, n_taps, ctaps):
+    """sfe_dsp_fir_create_per_channel: every channel its own filter (what several reference objects with
+    different taps are), one launch for all of them, state carried across two calls.  Each channel against
+    a single-channel handle with that channel's taps (same transform arithmetic) and against the oracle."""
+    rng = np.random.default_rng(n_taps)
+    nch, n, stride = 5, 20000, 20480
+    taps = rng.standard_normal((nch, n_taps)).astype(np.float32) / np.sqrt(n_taps)
+    if ctaps:
+        taps = (taps + 1j * rng.standard_normal((nch, n_taps)).astype(np.float32) / np.sqrt(n_taps)).astype(np.complex64)
+    x = np.zeros((nch, 2 * stride), dtype=np.float32)
+    for c in range(nch):
+        x[c, : 2 * n] = synth.synth_cf32(n, ch=20 + c)
+    d_in = api.DeviceArray.from_numpy(x)
+    d_out = api.DeviceArray(nch * 2 * stride)
+    f = api.Fir(taps, per_channel=True)
+    cut = 7777
+    f.process_stream(d_in, d_out, cut, in_stride=stride, out_stride=stride)
+    y1 = d_out.to_numpy().reshape(nch, 2 * stride)[:, : 2 * cut].copy()
+    f.process_stream(d_in.ptr + 8 * cut, d_out.ptr + 8 * cut, n - cut, in_stride=stride, out_stride=stride)
+    y = d_out.to_numpy().reshape(nch, 2 * stride)
+    assert np.array_equal(y[:, : 2 * cut], y1)
+    for c in range(nch):
+        one = api.Fir(taps[c], data_complex=True, algo=L.FIR_ALGO_FFT).filter(x[c, : 2 * n])[0]
+        assert synth.rel_rms(y[c, : 2 * n], one) <= 1e-6, c
+        xr, xi = x[c, 0:2 * n:2], x[c, 1:2 * n:2]
+        if ctaps:
+            hr, hi = np.real(taps[c]).astype(np.float32), np.imag(taps[c]).astype(np.float32)
+            rr, ii = orc.Blkconv(hr, 4096 if n_taps <= 2048 else 8192).stream(xr), orc.Blkconv(hi, 4096).stream(xi)
+            ri, ir = orc.Blkconv(hr, 4096).stream(xi), orc.Blkconv(hi, 4096).stream(xr)
+            ref_re, ref_im = rr - ii, ri + ir
+        else:
+            ref_re = orc.Blkconv(taps[c], 4096).stream(xr)
+            ref_im = orc.Blkconv(taps[c], 4096).stream(xi)
+        assert synth.rel_rms(y[c, 0:2 * n:2], ref_re) <= TOL and synth.rel_rms(y[c, 1:2 * n:2], ref_im) <= TOL, c
+
+
 def test_blkconv_class_known_answer(api, g1):
     """libdsp/test/test_blkconv.cxx:5-33 through the drop-in class."""
     c = api.blkconv(g1["taps"], int(g1["fft_len"]))
