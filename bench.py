@@ -24,7 +24,8 @@ BEFORE anything touches the GPU and relays rank 0's line.  It never prints an n_
 `other_configs` (N = 1, default workload) the other BASELINE.json configs at G = 1, each a short
                 timed leg of its own with parity: resample 5/3 (configs[2], in both readings of
                 "127-tap polyphase arm": the 381-tap prototype and the 127-tap prototype), decimate by 8
-                (configs[3]), the 64-channel FIR on one GPU (configs[4] at G = 1) and the
+                (configs[3]), the 64-channel FIR on one GPU (configs[4] at G = 1; shared filter, and a
+                different filter per channel) and the
                 complex-tap FIR.  They run BEFORE the headline's warm-up; their
                 parity checks run after all timing.
 `precondition_s` seconds of untimed launches of whichever leg runs first, before any warm-up or timed
