@@ -358,3 +358,66 @@ def test_resample_beyond_4_gib_input(api, L, orc, monkeypatch):
     _rs_windows_vs_oracle(orc, "Resample", y, taps, 3, 5, k0s, W, n, exact=False, hist_samples=150)
     x.free()
     y.free()
+
+
+def _seeded_starts(rng, total, W, fixed, count=32):
+    """`count` window starts in [0, total - W]: the fixed ones (stream start, last window, seams) plus
+    seeded random ones, sorted, each pulled down to a multiple of 6 (whole phase periods of the 5/3 law)."""
+    starts = [min(max(0, int(s)), total - W) for s in fixed]
+    while len(starts) < count:
+        starts.append(int(rng.integers(0, total - W)))
+    return sorted({s - s % 6 for s in starts})
+
+
+def test_parity_at_scale_32_windows_of_2pow16(api, L, orc, monkeypatch):
+    """SURVEY.md 8(d) "parity check at scale", as written: for the 2^28 / 2^30 configs compare 32 seeded
+    windows of 2^16 outputs -- always the stream start, the last window and windows straddling the GPU's
+    block seams -- against the CPU oracle fed the corresponding input span plus the filter's history.
+    The kernels bench.py times (default mode): cfg2 FIR, cfg3 resample 5/3, cfg4 decimate by 8."""
+    monkeypatch.delenv("SFE_RS_FFT", raising=False)
+    monkeypatch.delenv("SFE_RS_MFMA", raising=False)
+    rng = np.random.default_rng(synth.SEED)
+    W = 1 << 16
+    # ---- cfg2: 256-tap FIR, 2^28 cf32 (transform seams every 3840 samples; runs of eight per work counter)
+    n = 1 << 28
+    taps = synth.taps_cfg2()
+    x = api.DeviceArray(2 * n)
+    x.fill_synth(synth.SEED)
+    y = api.DeviceArray(2 * n)
+    api.Fir(taps, data_complex=True).process_stream(x, y, n)
+    worst, H = 0.0, 255
+    for s0 in _seeded_starts(rng, n, W, [0, n - W, 3840 * 8 * 1000 - W // 2, 3840 * 34953 - 100, n // 2]):
+        lo = max(0, s0 - H)
+        seg = synth.synth_cf32(s0 + W - lo, first_sample=lo)
+        got = _window(y, s0, W)
+        for part in (0, 1):
+            ref = orc.Blkconv(taps, 4096).stream(np.ascontiguousarray(seg[part::2]))[s0 - lo:]
+            e = synth.rel_rms(got[part::2], ref)
+            worst = max(worst, e)
+            assert e <= TOL, ("fir", s0, part, e)
+    print(f"cfg2: 32 x 2^16 windows, worst rel-RMS {worst:.2e}")
+    y.free()
+    # ---- cfg3: resample 5/3, 381 taps, the same 2^28 stream (a pass = 1386 outputs)
+    taps3 = synth.taps_cfg3()
+    cap = n * 3 // 5 + 8
+    y3 = api.DeviceArray(2 * cap)
+    k = api.Rs(taps3, 3, 4096, mode=L.RS_RESAMPLE, data_complex=True).process_stream(x, n, y3, cap, 5.0 / 3.0)
+    k0s = _seeded_starts(rng, k - 2, W, [0, k - 2 - W, 1386 * 40000 - W // 2, 1386 * 8 * 5000 + 3])
+    worst = _rs_windows_vs_oracle(orc, "Resample", y3, taps3, 3, 5, k0s, W, n, exact=False, hist_samples=150)
+    print(f"cfg3: {len(k0s)} x 2^16 windows, worst rel-RMS {worst:.2e}")
+    y3.free()
+    x.free()
+    # ---- cfg4: decimate by 8, 64 taps, 2^30 cf32 (workgroup tiles of 512 outputs)
+    n4 = 1 << 30
+    taps4 = synth.taps_cfg4()
+    x4 = api.DeviceArray(2 * n4)
+    x4.fill_synth(synth.SEED)
+    cap4 = n4 // 8 + 8
+    y4 = api.DeviceArray(2 * cap4)
+    k4 = api.Rs(taps4, 1, 4096, mode=L.RS_DECIMATE, data_complex=True).process_stream(x4, n4, y4, cap4, 8.0)
+    assert k4 == n4 // 8
+    k0s = _seeded_starts(rng, k4, W, [0, k4 - W, 512 * 100000 - W // 2, (1 << 26) - W // 2])
+    worst = _rs_windows_vs_oracle(orc, "Decimate", y4, taps4, 1, 8, k0s, W, n4, exact=False, hist_samples=80)
+    print(f"cfg4: {len(k0s)} x 2^16 windows, worst rel-RMS {worst:.2e}")
+    x4.free()
+    y4.free()
