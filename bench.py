@@ -8,19 +8,26 @@ Default line (what the driver records): BASELINE.json configs[1] -- a 256-tap FI
 of the hot path over that batch: one sfe_dsp_fir_process_stream call (the FFT overlap-save
 kernel, which also writes the 2 KiB history carry-over).
 
-N > 1: one rank per GPU, every rank filters its own 8 independent channels of 2^25 samples --
-the channel-sharded configs[4] shape, same per-GPU sample count, no data-path collective; the
-only cross-rank traffic is the barrier, the MAX of the elapsed time and of the worst parity
-figure, and the SUM of the per-rank output checksums {samples, sum re, sum im, sum |y|^2}
-(RCCL); after the timed region the ranks also cut ONE stream into spans, exchange
-the 256-sample span tails and check the seams (`split_stream`).  Started under torch.distributed.run the ranks are taken from the
+N > 1: BASELINE.json configs[4] as SURVEY.md 8(d) cfg5 words it -- a FIXED job of 64 independent
+channels x 2^24 samples, block-partitioned 64/N channels per rank (shard.channel_block), one rank
+per GPU, all of a rank's channels in ONE launch, no data-path collective ("scaling": "strong";
+`value` = 2^30 samples / max-over-ranks step time; `roofline.frac` against N x 8 TB/s).  The only
+cross-rank traffic is the barrier, the MAX of the elapsed time and of the worst parity figure, and
+the SUM of the per-rank output checksums {samples, sum re, sum im, sum |y|^2} (RCCL; SURVEY.md
+8(e)); every local channel of every rank is checked.  The round-2 weak-scaling shape (8 channels x
+2^25 per rank) is timed as an `other_configs` row.  After the timed region the ranks also cut ONE
+stream into spans, send the 256-sample span tails to their right neighbours point to point and
+check the seams (`split_stream`).  --channels / --log2n describe the whole
+job (per-channel length = 2^log2n / channels).  Started under torch.distributed.run the ranks are taken from the
 environment; started bare (`python bench.py --gpus 4`) this script launches the N ranks itself
 BEFORE anything touches the GPU and relays rank 0's line.  It never prints an n_gpus=1 line for
 --gpus N > 1: a world size that does not match --gpus is an error.
 
 `roofline`      algorithmic bytes of the dominant kernel per launch / its mean duration, timed
-                with HIP events on the launch stream inside the timed region; `traffic` is the
-                PMC-measured HBM bytes per launch from profiles/ (null if no pass was recorded).
+                with HIP events on the launch stream inside the timed region (min / max / std /
+                median of the K steps beside the mean); `traffic` is the PMC-measured HBM bytes
+                per launch from profiles/ -- null if no pass was recorded, and null with
+                `traffic_stale: true` if simplefe_amd/csrc/ has changed since that pass.
 `other_configs` (N = 1, default workload) the other BASELINE.json configs at G = 1, each a short
                 timed leg of its own with parity: resample 5/3 (configs[2], in both readings of
                 "127-tap polyphase arm": the 381-tap prototype and the 127-tap prototype), decimate by 8
@@ -59,10 +66,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)   # ~0.2 s of GPU time
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="fir", choices=["fir", "fir_ctaps", "resample", "decimate"])
-    ap.add_argument("--log2n", type=int, default=None, help="samples per GPU = 2^log2n (default per workload)")
+    ap.add_argument("--log2n", type=int, default=None,
+                    help="samples in the whole job = 2^log2n (default per workload: 28 at N=1, 30 for the 64-channel job at N>1; "
+                         "resample/decimate: per GPU)")
     ap.add_argument("--algo", default="auto", choices=["auto", "fft", "direct"])
     ap.add_argument("--channels", type=int, default=None,
-                    help="channels per GPU (default 1 at N=1, 8 at N>1: the 64-channel config over 8 GPUs)")
+                    help="channels in the whole job, block-partitioned over the ranks (default 1 at N=1, 64 at N>1: configs[4])")
     ap.add_argument("--input", default="f32", choices=["f32", "u8"],
                     help="u8: the stream is the device wire format, converted on load (fused RX converter, N2)")
     ap.add_argument("--output", default="f32", choices=["f32", "tx10"],
@@ -103,11 +112,15 @@ def spawn_ranks(args):
 
 # ------------------------------------------------------------------------------ helpers
 def pmc_traffic(workload_key):
-    """HBM bytes per launch from the committed PMC summary, if one exists for this workload."""
+    """(HBM bytes per launch, stale) from the committed PMC summary for this workload, latest round.
+    The summary carries a hash of simplefe_amd/csrc/ as it was when the counters were collected
+    (scripts/summarise_profiles.py); if the kernel sources have changed since, the bytes are not
+    reported: (None, True).  No summary at all: (None, False)."""
+    from simplefe_amd import build as _b
     best = None
     pdir = os.path.join(ROOT, "profiles")
     if not os.path.isdir(pdir):
-        return None
+        return None, False
     for f in sorted(os.listdir(pdir)):
         if f.startswith("pmc_") and f.endswith(".json"):
             try:
@@ -115,8 +128,12 @@ def pmc_traffic(workload_key):
             except Exception:
                 continue
             if d.get("workload") == workload_key and d.get("hbm_bytes_per_launch"):
-                best = d["hbm_bytes_per_launch"]
-    return best
+                best = d
+    if best is None:
+        return None, False
+    if best.get("csrc_sha256") != _b.csrc_hash():
+        return None, True
+    return best["hbm_bytes_per_launch"], False
 
 
 def host_cores():
@@ -205,16 +222,22 @@ class Leg:
     """One workload on this rank's GPU: buffers, the handle, step(), and the parity check."""
 
 
-def make_fir_leg(ctx, name, taps, log2n, nch, algo="auto", in_fmt="f32", out_fmt="f32", x_share=None, per_channel=False,
+def _p2(v):
+    """'2^k' for a power of two, the plain number otherwise."""
+    v = int(v)
+    return "2^%d" % (v.bit_length() - 1) if v > 0 and v & (v - 1) == 0 else str(v)
+
+
+def make_fir_leg(ctx, name, taps, n, nch, ch0=0, algo="auto", in_fmt="f32", out_fmt="f32", x_share=None, per_channel=False,
                  y_share=None):
+    """n samples per channel, nch channels on THIS rank, the first of them global channel ch0 (its
+    seed): what one rank of a channel-sharded job holds (shard.channel_block)."""
     torch, api, lib, synth, shard = ctx["torch"], ctx["api"], ctx["lib"], ctx["synth"], ctx["shard"]
     dev, stream, L = ctx["dev"], ctx["stream"], ctx["L"]
     leg = Leg()
     leg.name, leg.kind = name, "fir"
-    n_gpu = 1 << log2n
-    n = n_gpu // nch
+    n_gpu = n * nch
     leg.n, leg.nch, leg.n_gpu = n, nch, n_gpu
-    ch0 = shard.channel_block(nch * ctx["world"], ctx["world"], ctx["rank"])[0]
     leg.seeds = [ch0 + c for c in range(nch)]                  # global channel id = its seed
     if x_share is not None:
         x = x_share
@@ -226,11 +249,11 @@ def make_fir_leg(ctx, name, taps, log2n, nch, algo="auto", in_fmt="f32", out_fmt
     src = x
     ctaps = bool(np.iscomplexobj(taps))
     n_taps = taps.shape[-1]
-    leg.workload = "%d-tap %sFIR (blkconv law), 2^%d cf32 samples per GPU, %d channel(s) x 2^%d, device-resident in/out" % (
-        n_taps, "complex-tap " if ctaps else "", log2n, nch, log2n - (nch.bit_length() - 1))
+    leg.workload = "%d-tap %sFIR (blkconv law), %s cf32 samples per GPU, %d channel(s) x %s, device-resident in/out" % (
+        n_taps, "complex-tap " if ctaps else "", _p2(n_gpu), nch, _p2(n))
     if per_channel:
         leg.workload += ", a different filter per channel"
-    leg.key = "fir256_cf32_2p%d%s%s" % (log2n, "_ctaps" if ctaps else "", "_direct" if algo == "direct" else "")
+    leg.key = "fir256_cf32_2p%d%s%s" % (max(n_gpu, 1).bit_length() - 1, "_ctaps" if ctaps else "", "_direct" if algo == "direct" else "")
     if nch > 1:
         leg.key += "_%dch" % nch
     if in_fmt == "u8":
@@ -356,7 +379,7 @@ def make_rs_leg(ctx, which, log2n, in_fmt="f32", short_proto=False):
     if in_fmt == "u8":
         leg.obj.set_input_format(lib.FMT_U8)
     # the library picks the transform-domain kernel for long filters on cf32 streams (api.hip: get_fft_plan)
-    leg.kernel = "poly_fft256_kernel" if which == "resample" and not short_proto and os.environ.get("SFE_RS_FFT", "") != "0" else "poly_tiled_kernel"
+    leg.kernel = "poly_fft256_kernel" if which == "resample" and not short_proto else "poly_tiled_kernel"
     leg.k_before = 0          # outputs produced by all calls before the most recent one
     leg.n_out = 0
     leg.calls = 0
@@ -407,7 +430,7 @@ def make_rs_leg(ctx, which, log2n, in_fmt="f32", short_proto=False):
 
 def time_leg(ctx, leg, steps, warmup):
     """W untimed steps, then exactly `steps` timed ones between barriers; returns
-    (wall seconds max over ranks, mean HIP-event ms per step on the launch stream)."""
+    (wall seconds max over ranks, the HIP-event ms of every timed step on the launch stream)."""
     api, shard, stream = ctx["api"], ctx["shard"], ctx["stream"]
     for _ in range(warmup):
         leg.step()
@@ -420,7 +443,7 @@ def time_leg(ctx, leg, steps, warmup):
         timers[k].stop(stream)
     ctx["barrier"]()
     elapsed = shard.max_over_ranks(time.perf_counter() - t0, ctx["red_dev"])
-    return elapsed, float(np.mean([t.elapsed_ms() for t in timers]))
+    return elapsed, [t.elapsed_ms() for t in timers]
 
 
 def precondition(ctx, leg, seconds=0.15):
@@ -457,12 +480,14 @@ def checksum(ctx, leg):
 
 def split_stream_check(ctx, taps):
     """N > 1 only, outside every timed region: ONE stream cut into one span per rank (SURVEY.md 8(e)
-    row 3).  The ranks exchange the last 256 samples of their spans (an all-gather of 2 KiB per rank:
-    the path's one real exchange step; shard.halo_from_left is the point-to-point form), each loads
-    its left neighbour's as its handle's history and filters its span; the first window of every
-    span -- the samples that depend on the halo -- is checked against the oracle on the uncut
-    stream.  Never fatal and never one-sided: both collectives are reached by every rank whatever
-    happened locally, and a failure is reported in the line."""
+    row 3).  Every rank sends the last 256 samples of its span to its right neighbour POINT TO POINT
+    (shard.halo_from_left: RCCL send/recv, 2 KiB over one xGMI link -- the path's one real exchange
+    step), loads what it received as its handle's history and filters its span; the first window of
+    every span -- the samples that depend on the halo -- is checked against the oracle on the uncut
+    stream.  If the point-to-point exchange raises on any rank, all ranks agree on that (an
+    all-reduce) and repeat the exchange as an all-gather of the span tails; which one carried the
+    halo is reported.  Never fatal and never one-sided: every collective is reached by every rank
+    whatever happened locally, and a failure is reported in the line."""
     import torch.distributed as dist
     torch, api, synth, shard = ctx["torch"], ctx["api"], ctx["synth"], ctx["shard"]
     L, dev, stream, rank, world = ctx["L"], ctx["dev"], ctx["stream"], ctx["rank"], ctx["world"]
@@ -479,8 +504,18 @@ def split_stream_check(ctx, taps):
         tail = x[-2 * HL:].to(cdev).contiguous()
     except Exception as e:
         err = "%s: %s" % (type(e).__name__, e)
-    tails = torch.zeros(world * 2 * HL, dtype=torch.float32, device=cdev)
-    dist.all_gather_into_tensor(tails, tail)                   # collective 1: every rank, always
+    halo, p2p_err = None, None
+    try:
+        halo = shard.halo_from_left(tail, 2 * HL)               # exchange: send right / receive from the left
+    except Exception as e:
+        p2p_err = "%s: %s" % (type(e).__name__, e)
+    any_failed = shard.max_over_ranks(1.0 if p2p_err else 0.0, ctx["red_dev"]) > 0      # every rank, always
+    exchange = "point-to-point send/recv of the span tail to the right neighbour (%s)" % dist.get_backend()
+    if any_failed:
+        tails = torch.zeros(world * 2 * HL, dtype=torch.float32, device=cdev)
+        dist.all_gather_into_tensor(tails, tail)               # the fallback: every rank, always
+        halo = tails[(rank - 1) * 2 * HL: rank * 2 * HL] if rank > 0 else torch.zeros_like(tail)
+        exchange = "FALLBACK all-gather of the span tails (%s); point-to-point failed" % dist.get_backend()
     if on_gpu:
         torch.cuda.synchronize()        # RCCL orders torch's stream only; the handle below runs on the library's
     try:
@@ -488,8 +523,8 @@ def split_stream_check(ctx, taps):
             from oracle import binding as orc
             f = api.Fir(taps, data_complex=True, device=ctx["local_rank"])
             if rank > 0:
-                halo = tails[(rank - 1) * 2 * HL: rank * 2 * HL].to(dev).contiguous()
-                f.load_history(halo.data_ptr(), HL, stream=stream)
+                h = halo.to(dev).contiguous()
+                f.load_history(h.data_ptr(), HL, stream=stream)
             y = torch.empty(2 * count, dtype=torch.float32, device=dev)
             f.process_stream(x.data_ptr(), y.data_ptr(), count, stream=stream)
             torch.cuda.synchronize()
@@ -502,9 +537,11 @@ def split_stream_check(ctx, taps):
                 worst = max(worst, synth.rel_rms(got[part::2], ref))
     except Exception as e:
         err, worst = "%s: %s" % (type(e).__name__, e), float("inf")
-    worst = shard.max_over_ranks(worst, ctx["red_dev"])       # collective 2: every rank, always
+    worst = shard.max_over_ranks(worst, ctx["red_dev"])       # every rank, always
     out = {"ok": bool(worst <= TOL), "rel_rms_max": worst if worst != float("inf") else None, "samples": n_total,
-           "spans": world, "halo_samples": HL, "exchange": "all-gather of the span tails (%s)" % dist.get_backend()}
+           "spans": world, "halo_samples": HL, "exchange": exchange}
+    if p2p_err:
+        out["p2p_error"] = p2p_err
     if err:
         out["error"] = err
     return out
@@ -545,76 +582,129 @@ def main():
     ctx_red = red_dev       # where the control-plane reductions live: the GPU under RCCL, the host under gloo
 
     wl = args.workload
+    total_channels = 1
     if wl in ("fir", "fir_ctaps"):
-        nch = args.channels or (1 if world == 1 else 8)   # N > 1: 8*N channels, block-partitioned over ranks
+        # --channels / --log2n describe the WHOLE JOB.  N = 1: configs[1], one channel of 2^28.  N > 1:
+        # configs[4] as SURVEY 8(d) cfg5 words it -- 64 channels x 2^24, block-partitioned 64/N per rank
+        # (a fixed job: strong scaling); rank r holds channels channel_block(64, N, r), seed = global id.
+        total_channels = args.channels or (1 if world == 1 else 64)
+        log2n = args.log2n or (28 if world == 1 else 30)
+        if (1 << log2n) % total_channels:
+            raise SystemExit("--channels must divide 2^log2n")
+        n_ch = (1 << log2n) // total_channels
+        ch0, nch = shard.channel_block(total_channels, world, rank)
+        if nch < 1:
+            raise SystemExit(f"--gpus {world} but only {total_channels} channel(s): a rank would hold none")
         taps = synth.taps_cfg2()
         if wl == "fir_ctaps":
             tr, ti = synth.complex_taps(256, 0.2)
             taps = (tr + 1j * ti).astype(np.complex64)
-        head = make_fir_leg(ctx, wl, taps, args.log2n or 28, nch, algo=args.algo, in_fmt=args.input, out_fmt=args.output)
+        head = make_fir_leg(ctx, wl, taps, n_ch, nch, ch0=ch0, algo=args.algo, in_fmt=args.input, out_fmt=args.output)
     else:
         head = make_rs_leg(ctx, wl, args.log2n or (28 if wl == "resample" else 30), in_fmt=args.input)
 
     # ---- the other BASELINE configs at G = 1 (short legs; built and timed before the headline)
     others, other_errors = [], []
-    if world == 1 and wl == "fir" and not args.no_others and args.input == "f32" and args.output == "f32" \
-            and args.algo == "auto" and not args.log2n and not args.channels:
+    plain = wl == "fir" and not args.no_others and args.input == "f32" and args.output == "f32" \
+        and args.algo == "auto" and not args.log2n and not args.channels
+    if world == 1 and plain:
         tr, ti = synth.complex_taps(256, 0.2)
         makers = [lambda: make_rs_leg(ctx, "resample", 28), lambda: make_rs_leg(ctx, "resample", 28, short_proto=True),
                   lambda: make_rs_leg(ctx, "decimate", 30),
-                  lambda: make_fir_leg(ctx, "fir_64ch", synth.taps_cfg2(), 30, 64),
-                  lambda: make_fir_leg(ctx, "fir_64ch_pctaps", synth.taps_per_channel(64), 30, 64, per_channel=True,
+                  lambda: make_fir_leg(ctx, "fir_64ch", synth.taps_cfg2(), 1 << 24, 64),
+                  lambda: make_fir_leg(ctx, "fir_64ch_pctaps", synth.taps_per_channel(64), 1 << 24, 64, per_channel=True,
                                        x_share=next(l.x for l in others if l.name == "fir_64ch")),
-                  lambda: make_fir_leg(ctx, "fir_ctaps", (tr + 1j * ti).astype(np.complex64), 28, 1, x_share=head.x)]
-        for mk in makers:      # an extra leg that cannot be set up is reported, never allowed to take the headline with it
-            try:
-                others.append(mk())
-            except Exception as e:
-                other_errors.append({"error": "%s: %s" % (type(e).__name__, e)})
+                  lambda: make_fir_leg(ctx, "fir_ctaps", (tr + 1j * ti).astype(np.complex64), 1 << 28, 1, x_share=head.x)]
+    elif plain:
+        # N > 1: the round-2 weak-scaling shape beside the fixed 64-channel job -- 8 channels x 2^25 per
+        # rank whatever N is (the same per-GPU launch at every N; at N = 8 it is 64 channels of 2^25)
+        makers = [lambda: make_fir_leg(ctx, "fir_weak", synth.taps_cfg2(), 1 << 25, 8, ch0=8 * rank)]
+    else:
+        makers = []
+    for mk in makers:      # an extra leg that cannot be set up is reported, never allowed to take the headline with it
+        try:
+            others.append(mk())
+        except Exception as e:
+            other_errors.append({"error": "%s: %s" % (type(e).__name__, e)})
     other_rows = []
     precondition(ctx, others[0] if others else head, args.precondition)      # whichever leg runs first takes the chip through its start-up transient
     for leg in others:
         el, kms = time_leg(ctx, leg, args.other_steps, 3)
-        other_rows.append({"workload": leg.workload, "steps": args.other_steps, "ms": kms,
-                           "value": leg.n_gpu / (el / args.other_steps) / 1e6, "unit": "MS/s (input)",
-                           "kernel": leg.kernel, "algorithmic_bytes_per_launch": leg.bytes_per_launch,
-                           "frac": leg.bytes_per_launch / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        kmean = shard.max_over_ranks(float(np.mean(kms)), ctx_red)
+        row = {"workload": leg.workload, "steps": args.other_steps, "ms": kmean,
+               "value": world * leg.n_gpu / (el / args.other_steps) / 1e6, "unit": "MS/s (input)",
+               "kernel": leg.kernel, "algorithmic_bytes_per_launch": leg.bytes_per_launch,
+               "frac": leg.bytes_per_launch / (kmean * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if world > 1:
+            row["scaling"] = "weak"
+            row["workload"] += " -- per rank, %d ranks (weak scaling: the per-GPU launch is the same at every N)" % world
+            row["frac_note"] = "per-GPU algorithmic bytes / slowest rank's mean launch time / 8 TB/s"
+        other_rows.append(row)
 
     # ---- headline: W untimed + exactly K timed steps
-    elapsed, kern_ms = time_leg(ctx, head, args.steps, args.warmup)
+    elapsed, kern_list = time_leg(ctx, head, args.steps, args.warmup)
     ms_per_step = elapsed * 1e3 / args.steps
-    value = world * head.n_gpu / (ms_per_step * 1e-3) / 1e6      # whole-job complex MS/s
+    job_samples = shard.sum_over_ranks([head.n_gpu], ctx_red)[0]      # all ranks' samples per step
+    value = job_samples / (ms_per_step * 1e-3) / 1e6                  # whole-job complex MS/s
+    job_bytes = shard.sum_over_ranks([head.bytes_per_launch], ctx_red)[0]
+    kern_ms = float(np.mean(kern_list))                               # this rank's launches (rank 0's in the line)
+    kern_ms_slowest = shard.max_over_ranks(kern_ms, ctx_red)          # the rank that bounds the job
 
     # ---- parity (every rank, its own channels) and the cross-rank checksum; the oracle is the checker only
-    worst, nwin, W = head.check(full=False)
+    worst, nwin, W = head.check(full=world > 1)          # N > 1: EVERY local channel, first and last window
     worst_all = shard.max_over_ranks(worst, ctx_red)
+    nwin_all = int(shard.sum_over_ranks([nwin], ctx_red)[0])
     csum = shard.sum_over_ranks(checksum(ctx, head), ctx_red)
     is_tx10 = getattr(head, "out_fmt", "f32") == "tx10"
-    parity = {"rel_rms_max": worst_all, "windows": nwin * world, "window_len": W, "tol": TOL,
+    parity = {"rel_rms_max": worst_all, "windows": nwin_all, "window_len": W, "tol": TOL,
               "ok": bool(worst_all <= (2e-3 if is_tx10 else TOL)), "ranks_checked": world,
-              "checked": "last timed step, every rank: first and last local channel"}
+              "checked": "last timed step, every rank: " + ("every local channel, first and last window" if world > 1 and head.kind == "fir"
+                                                            else "first and last local channel")}
     if is_tx10:
         parity["note"] = "10-bit output: figure = fraction of packed bytes differing from the oracle's packing (1-LSB code-boundary flips)"
     for leg, row in zip(others, other_rows):
         w, c, wl_ = leg.check(full=False)
+        if world > 1:
+            w, c = shard.max_over_ranks(w, ctx_red), int(shard.sum_over_ranks([c], ctx_red)[0])
         row["parity"] = {"rel_rms_max": w, "windows": c, "window_len": wl_, "tol": TOL, "ok": bool(w <= TOL)}
 
+    sharded = world > 1 and head.kind == "fir"
+    traffic, traffic_stale = pmc_traffic(head.key)
     out = {
         "metric": "complex-float32 MS/s through 256-tap blkconv FIR; % of HBM roofline" if wl == "fir"
         else "complex-float32 input MS/s through libdsp %s; %% of HBM roofline" % wl,
         "value": value, "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True,
+        # a channel-sharded FIR job is FIXED (64 channels x 2^24 whatever N is): strong scaling;
+        # resample/decimate at N > 1 are N replicas of the one-GPU job: weak
+        "scaling": "strong" if sharded else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic", "precondition_s": args.precondition,
         "config": {"workload": head.workload, "channels_per_gpu": head.nch, "samples_per_gpu": head.n_gpu,
                    "sharding": "independent channels per rank, no data-path collective" if world > 1 else "single GPU"},
-        "roofline": {"bound": "hbm", "achieved": head.bytes_per_launch / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": head.bytes_per_launch / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic(head.key), "kernel": head.kernel, "kernel_ms": kern_ms,
+        # per launch of the dominant kernel.  N > 1: the whole job's algorithmic bytes per step over the
+        # slowest rank's mean launch time, against N x 8 TB/s
+        "roofline": {"bound": "hbm", "achieved": job_bytes / (kern_ms_slowest * 1e-3) / 1e9, "peak": HBM_PEAK_GBS * world,
+                     "unit": "GB/s", "frac": job_bytes / (kern_ms_slowest * 1e-3) / 1e9 / (HBM_PEAK_GBS * world),
+                     "traffic": traffic, "kernel": head.kernel, "kernel_ms": kern_ms_slowest,
+                     "kernel_ms_min": float(np.min(kern_list)), "kernel_ms_max": float(np.max(kern_list)),
+                     "kernel_ms_std": float(np.std(kern_list)), "kernel_ms_median": float(np.median(kern_list)),
                      "algorithmic_bytes_per_launch": head.bytes_per_launch},
         "parity": parity,
         "checksum": {"samples": csum[0], "sum_re": csum[1], "sum_im": csum[2], "sum_abs2": csum[3],
                      "over": "all ranks' last output (float64 sums, all-reduced)"},
     }
+    if traffic_stale:
+        out["roofline"]["traffic_stale"] = True      # simplefe_amd/csrc changed since the PMC pass in profiles/
+    if world > 1:
+        out["roofline"]["note"] = ("achieved = all ranks' algorithmic bytes per step / the slowest rank's mean launch time; "
+                                   "peak = %d x 8 TB/s; kernel_ms_min/max/std are rank 0's launches" % world)
+    if sharded:
+        out["config"]["workload"] = ("%d independent cf32 channels x %s samples, 256-tap FIR (blkconv law), channel-sharded %s per GPU over %d GPUs, "
+                                     "device-resident in/out" % (total_channels, _p2(head.n),
+                                                                 "%d/%d" % (total_channels, world), world))
+        out["config"]["channels_total"] = total_channels
+        out["config"]["samples_per_channel"] = head.n
+        out["config"]["samples_total"] = int(job_samples)
     if other_rows or other_errors:
         out["other_configs"] = other_rows + other_errors
     if world > 1 and head.kind == "fir" and not np.iscomplexobj(head.taps):

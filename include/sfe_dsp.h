@@ -138,6 +138,12 @@ int sfe_dsp_fir_process_host(sfe_fir_t h, const void *in, void *out, size_t n);
 int sfe_dsp_fir_load_history(sfe_fir_t h, const void *d_prev, size_t n_prev, size_t stride,
                              sfe_stream_t stream);
 int sfe_dsp_fir_set_algo(sfe_fir_t h, int algo);
+/* Host calls (blkconv::process() on the object's buffer, sfe_dsp_fir_process_host) of at most
+ * max_samples samples let the kernel read and write pinned host memory itself -- one stream
+ * operation instead of copy-in, launch, copy-out (default 2^20 samples; 0 = always the DMA copies).
+ * Has no reference counterpart (the reference's buffer, libdsp/blkconv.h:44-47, is plain host
+ * memory); a tuning knob of the compatibility path.  Set before the first process_host call. */
+int sfe_dsp_fir_set_zero_copy_max(sfe_fir_t h, size_t max_samples);
 /* Pipelined host streaming for scheduler-sized calls.  A GNU Radio scheduler
  * hands a block a few thousand items per work() call (gr-simplefe/lib/sink_c_impl.cc:157-174,
  * source_c_impl.cc:134-153); one synchronous round trip per call is launch/sync bound.  A pipe
@@ -221,6 +227,16 @@ int sfe_dsp_rs_process(sfe_rs_t h, const float *in, int n_in, float *out, int ou
 int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t in_stride,
                               void *d_out, size_t out_cap, size_t out_stride, float rate,
                               size_t *n_out, sfe_stream_t stream);
+/* Which kernel the integer-step bulk path (fused numerics) takes.  AUTO: the calibrated rule of
+ * DESIGN.md 4.2c (transform-domain kernel for long filters on long calls, else the tiled direct
+ * kernel).  DIRECT: never the transform-domain kernel.  FFT: the transform-domain kernel wherever
+ * the shape is instantiated.  MFMA: the f32 matrix-pipe form of the direct kernel (measured slower,
+ * kept as evidence: DESIGN.md 4.2b).  The library reads no environment variable. */
+#define SFE_RS_ALGO_AUTO    0
+#define SFE_RS_ALGO_DIRECT  1
+#define SFE_RS_ALGO_FFT     2
+#define SFE_RS_ALGO_MFMA    3
+int sfe_dsp_rs_set_algo(sfe_rs_t h, int algo);
 /* exact = 1: separate multiply and add in the reference's order (bit-exact with the CPU
  * classes); exact = 0 (default for *_stream): fused multiply-add, same order. */
 int sfe_dsp_rs_set_exact(sfe_rs_t h, int exact);

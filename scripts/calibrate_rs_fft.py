@@ -24,9 +24,8 @@ for U, S, taps_list in ((1, 2, (64, 128, 256, 512)), (1, 3, (100, 200, 400)), (1
     for nt in taps_list:
         taps = (rng.standard_normal(nt) / np.sqrt(nt)).astype(np.float32)
         res = []
-        for fft in ("0", "1"):
-            os.environ["SFE_RS_FFT"] = fft
-            r = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=True)
+        for algo in (lib.RS_ALGO_DIRECT, lib.RS_ALGO_FFT):
+            r = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=True, algo=algo)
             cap = int(n * U / S) + 16
             ts = []
             for it in range(12):

@@ -11,11 +11,11 @@ from simplefe_amd import api, lib, synth  # noqa: E402
 
 
 def run(U, S, n_taps, n, nch=1, chunk=None, fft=True, exact=False, seed=0):
-    os.environ["SFE_RS_FFT"] = "1" if fft else "0"
     rng = np.random.default_rng(seed)
     taps = (rng.standard_normal(n_taps) / np.sqrt(n_taps)).astype(np.float32)
     x = np.stack([synth.synth_f32(2 * n, ch=seed * 4 + c) for c in range(nch)])
-    r = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=True, n_channels=nch)
+    r = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=True, n_channels=nch,
+               algo=lib.RS_ALGO_FFT if fft else lib.RS_ALGO_DIRECT)
     r.set_exact(exact)
     y = r.resample_array(x, float(np.float32(S) / np.float32(U)), chunk=chunk)
     r.close()
@@ -51,8 +51,7 @@ def main():
     cap = n * 3 // 5 + 16
     d_out = api.DeviceArray(2 * cap)
     for fft in (False, True, False, True):
-        os.environ["SFE_RS_FFT"] = "1" if fft else "0"
-        r = api.Rs(taps, 3, 4096, mode=lib.RS_RESAMPLE, data_complex=True)
+        r = api.Rs(taps, 3, 4096, mode=lib.RS_RESAMPLE, data_complex=True, algo=lib.RS_ALGO_FFT if fft else lib.RS_ALGO_DIRECT)
         ts = []
         for it in range(60):
             r.reset()
@@ -67,8 +66,7 @@ def main():
     nr = 1 << 29
     capr = nr * 3 // 5 + 16
     for fft in (False, True, False, True):
-        os.environ["SFE_RS_FFT"] = "1" if fft else "0"
-        r = api.Rs(taps, 3, 4096, mode=lib.RS_RESAMPLE, data_complex=False)
+        r = api.Rs(taps, 3, 4096, mode=lib.RS_RESAMPLE, data_complex=False, algo=lib.RS_ALGO_FFT if fft else lib.RS_ALGO_DIRECT)
         ts = []
         for it in range(60):
             r.reset()

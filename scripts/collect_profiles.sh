@@ -4,12 +4,14 @@
 # the two transform kernels, and the variant / ablation tables from the diagnostic library.
 # Output under gpurun_out/prof_<tag>_*/; summarised into profiles/ by scripts/summarise_profiles.py
 # (run in the authoring container).   usage: scripts/collect_profiles.sh [tag]
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp; export TMPDIR=/tmp
 for WL in fir decimate resample; do
   O=$R/gpurun_out/prof_${TAG}_${WL}
   mkdir -p $O
+  # the kernel sources these counters belong to (bench.py reports roofline.traffic only while this matches the tree)
+  (cd $R && python3 -m simplefe_amd.build --hash) > $O/csrc_hash.txt
   # --no-others: the headline kernel alone (the default line's other_configs legs launch the same
   # kernel name on other shapes, which would mix into the per-name average)
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --workload $WL --no-cpu --no-others > $O/kt.log 2>&1 || exit 1

@@ -147,6 +147,9 @@ class Fir:
     def set_algo(self, algo):
         check(self._L.sfe_dsp_fir_set_algo(self._h, algo))
 
+    def set_zero_copy_max(self, max_samples):
+        check(self._L.sfe_dsp_fir_set_zero_copy_max(self._h, int(max_samples)))
+
     def set_input_format(self, fmt):
         """lib.FMT_U8: process_stream reads u8 offset-binary samples (fused RX converter)."""
         check(self._L.sfe_dsp_fir_set_input_format(self._h, fmt))
@@ -204,7 +207,8 @@ class Fir:
 class Rs:
     """One resample/decimate stream set (sfe_dsp_rs_*)."""
 
-    def __init__(self, taps, upsample, blksize, mode=_l.RS_RESAMPLE, data_complex=False, n_channels=1, device=0):
+    def __init__(self, taps, upsample, blksize, mode=_l.RS_RESAMPLE, data_complex=False, n_channels=1, device=0,
+                 algo=_l.RS_ALGO_AUTO):
         self._L = _l.load()
         t = _f32(taps)
         self.data_complex = bool(data_complex)
@@ -215,9 +219,15 @@ class Rs:
         check(self._L.sfe_dsp_rs_create(t.ctypes.data, t.size, upsample, blksize, int(self.data_complex),
                                         n_channels, device, mode, C.byref(h)))
         self._h = h.value
+        if algo != _l.RS_ALGO_AUTO:
+            self.set_algo(algo)
 
     def set_exact(self, exact=True):
         check(self._L.sfe_dsp_rs_set_exact(self._h, int(bool(exact))))
+
+    def set_algo(self, algo):
+        """lib.RS_ALGO_AUTO / DIRECT / FFT / MFMA: the kernel of the integer-step bulk path."""
+        check(self._L.sfe_dsp_rs_set_algo(self._h, algo))
 
     def set_input_format(self, fmt):
         check(self._L.sfe_dsp_rs_set_input_format(self._h, fmt))

@@ -32,6 +32,19 @@ def _deps():
         os.path.join(os.path.dirname(HERE), "include", "*.h"))
 
 
+def csrc_hash():
+    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h: names and contents).  Stamped into
+    profiles/pmc_*.json when counters are collected; bench.py reports roofline.traffic only while
+    the stamp matches the tree (otherwise traffic: null, traffic_stale: true)."""
+    import hashlib
+    h = hashlib.sha256()
+    for p in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))):
+        h.update(os.path.basename(p).encode() + b"\0")
+        h.update(open(p, "rb").read())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
 def needs_build(lib=LIB):
     if not os.path.exists(lib):
         return True
@@ -79,4 +92,7 @@ def build_lib(force=False, verbose=False, extra=(), diag=False):
 
 
 if __name__ == "__main__":
+    if "--hash" in sys.argv:
+        print(csrc_hash())
+        raise SystemExit(0)
     print(build_lib(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv))

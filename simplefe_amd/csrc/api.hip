@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <new>
 #include <numeric>
@@ -31,6 +32,19 @@ int hip_fail(hipError_t e, const char *what)
 {
     set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
     return e == hipErrorOutOfMemory ? SFE_ENOMEM : (e == hipErrorNoDevice ? SFE_ENODEV : SFE_EHIP);
+}
+
+int device_cu_count()
+{
+    constexpr int MAXDEV = 64;
+    static std::atomic<int> cache[MAXDEV];          // zero-initialised; 0 = not asked yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return 256;
+    int c = cache[dev].load(std::memory_order_relaxed);
+    if (c > 0) return c;
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+    cache[dev].store(c, std::memory_order_relaxed);   // racing threads store the same value
+    return c;
 }
 
 // Every entry point that touches a handle runs on the handle's device and puts the caller's
@@ -362,7 +376,7 @@ struct Fir {
     size_t stage_samples = 0;
     // Calls of at most zc_max samples skip the two DMA copies: the kernel reads the pinned host buffer
     // and writes a pinned host buffer itself (one launch + one wait instead of copy, launch, copy, wait).
-    // Only where the kernel reads its input once (parts == 1).  SFE_ZEROCOPY_MAX at create; 0 disables.
+    // Only where the kernel reads its input once (parts == 1).  sfe_dsp_fir_set_zero_copy_max; 0 disables.
     size_t zc_max = (size_t)1 << 20;
     hipStream_t stream = nullptr;
     size_t hist_bytes() const { return (size_t)n_channels * hl * (data_complex ? 8 : 4); }
@@ -612,8 +626,8 @@ struct Rs {
     uint32_t magic = 0x52533031u;   // 'RS01'
     int U = 1, n_taps = 0, plen = 0, blksize = 0, data_complex = 0, n_channels = 1;
     int device = 0, mode = SFE_RS_RESAMPLE, exact_stream = 0, in_u8 = 0;
-    int fft_mode = 0;                      // SFE_RS_FFT at create: 1 force the transform-domain kernel, -1 never
-    int use_mfma = 0;                      // SFE_RS_MFMA=1 at create: the matrix-pipe form (measured slower; opt-in)
+    int fft_mode = 0;                      // sfe_dsp_rs_set_algo: 1 force the transform-domain kernel, -1 never, 0 the calibrated rule
+    int use_mfma = 0;                      // sfe_dsp_rs_set_algo(SFE_RS_ALGO_MFMA): the matrix-pipe form (measured slower; opt-in)
     int hl = 0;
     float *d_taps = nullptr;               // [U][plen] phase-major
     std::vector<float> h_taps_pm;          // host copy of the same (tiled plans)
@@ -908,7 +922,6 @@ static int fir_create_impl(const float *taps, int n_taps, int taps_complex, int 
         TRY(hipMalloc(&f->d_blk_out, (size_t)f->blk * out_e * sizeof(float)));
         TRY(hipHostMalloc(&f->h_blk_out, hb));
     }
-    if (const char *e = getenv("SFE_ZEROCOPY_MAX")) f->zc_max = (size_t)atoll(e) > 0 ? (size_t)atoll(e) : 0;
     TRY(hipDeviceSynchronize());
 #undef TRY
     *out = f;
@@ -1138,6 +1151,19 @@ int sfe_dsp_fir_set_algo(sfe_fir_t h, int algo)
     return SFE_OK;
 }
 
+int sfe_dsp_fir_set_zero_copy_max(sfe_fir_t h, size_t max_samples)
+{
+    Fir *f = as_fir(h);
+    if (!f) return SFE_EINVAL;
+    if (f->h_stage) {
+        // the pinned output staging of sfe_dsp_fir_process_host was sized from the old limit
+        set_error("fir_set_zero_copy_max: set it before the first sfe_dsp_fir_process_host call");
+        return SFE_ESTATE;
+    }
+    f->zc_max = max_samples;
+    return SFE_OK;
+}
+
 int sfe_dsp_fir_reset(sfe_fir_t h)
 {
     Fir *f = as_fir(h);
@@ -1200,9 +1226,6 @@ int sfe_dsp_rs_create(const float *taps, int n_taps, int upsample, int blksize, 
     r->n_channels = n_channels;
     r->device = device;
     r->mode = mode;
-    // environment switches are read ONCE, here: never on the per-call path
-    if (const char *e = getenv("SFE_RS_FFT")) r->fft_mode = e[0] == '1' ? 1 : (e[0] == '0' ? -1 : 0);
-    if (const char *e = getenv("SFE_RS_MFMA")) r->use_mfma = e[0] == '1';
     // decimate appends a zero tap when n_taps is even (decimate.cxx:42-51); resample pads the
     // last phase with zeros (resample.cxx:43,55-64).  Both are "ceil to a whole phase row".
     const int eff = (mode == SFE_RS_DECIMATE && (n_taps % 2 == 0)) ? n_taps + 1 : n_taps;
@@ -1422,7 +1445,7 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         a.pos0 = pos0;
         a.step = (int)S;
         a.n_out = K;
-        // matrix-pipe form (fused numerics, cf32): opt-in with SFE_RS_MFMA=1.  Measured slower
+        // matrix-pipe form (fused numerics, cf32): opt-in with sfe_dsp_rs_set_algo(SFE_RS_ALGO_MFMA).  Measured slower
         // than the VALU kernel on the one shape where its tap matrix is dense (polyphase.hip).
         const PolyMfmaPlan *mp = nullptr;
         if (r->use_mfma && !r->exact_stream && r->data_complex && !r->in_u8) {
@@ -1701,6 +1724,17 @@ int sfe_dsp_rs_set_input_format(sfe_rs_t h, int fmt)
     Rs *r = as_rs(h);
     if (!r || (fmt != SFE_FMT_F32 && fmt != SFE_FMT_U8)) return SFE_EINVAL;
     r->in_u8 = fmt == SFE_FMT_U8;
+    return SFE_OK;
+}
+
+int sfe_dsp_rs_set_algo(sfe_rs_t h, int algo)
+{
+    Rs *r = as_rs(h);
+    if (!r || algo < SFE_RS_ALGO_AUTO || algo > SFE_RS_ALGO_MFMA) return SFE_EINVAL;
+    r->fft_mode = algo == SFE_RS_ALGO_FFT ? 1 : (algo == SFE_RS_ALGO_AUTO ? 0 : -1);
+    r->use_mfma = algo == SFE_RS_ALGO_MFMA;
+    // plans are cached per (step, pos0) together with the choice that made them
+    r->fft_plans.clear();
     return SFE_OK;
 }
 

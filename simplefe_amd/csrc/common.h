@@ -26,6 +26,10 @@ __device__ __forceinline__ void lds_barrier()
 
 void set_error(const char *fmt, ...);
 int hip_fail(hipError_t e, const char *what);
+// Compute units of the CURRENT device (256 on an unpartitioned MI355X; a partitioned one reports
+// its share), cached per device ordinal, thread-safe (api.hip).  The persistent grids are sized
+// from it; 256 if the attribute cannot be read.
+int device_cu_count();
 
 #define SFE_HIP(call)                                         \
     do {                                                      \
@@ -61,7 +65,7 @@ struct FirFftArgs {
                           // draw transforms from; zero between launches
     unsigned    total;    // set by the launcher: transforms over all channels (channel-major tickets)
     unsigned    tgroups;  // set by the launcher: counters in use (workgroup b draws from counter b % tgroups)
-    long long   hs_stride; // 0: one spectrum for every channel; else channel c's spectra start c*hs_stride elements after hs (per-channel taps: read per transform, not held in registers)
+    long long   hs_stride; // 0: one spectrum for every channel; else channel c's spectra start c*hs_stride elements after hs (per-channel taps: held in registers like the shared one and reloaded, 16 loads per thread, when the workgroup's next transform belongs to another channel)
     unsigned    tqs;      // set by the launcher: a group draws runs of 2^tqs CONSECUTIVE transforms (their halos meet in its L2)
     unsigned    halo_keep; // set by the launcher: mask of input rows loaded WITHOUT the nontemporal hint (0x8001: the two rows a neighbour re-reads)
 };

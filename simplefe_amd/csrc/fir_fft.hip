@@ -957,13 +957,8 @@ int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in
     a.nblk = nb;
     // ticketed kernels: ONE grid dimension, transforms of all channels drawn channel-major from a.ticket
     const long long total = nb * n_channels;
-    // compute units of the device (256 on an unpartitioned MI355X; a partitioned one reports its share)
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0, c = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0) cus = c;
-        else cus = 256;
-    }
+    // compute units of the launch's device (cached per device ordinal, common.h)
+    const int cus = device_cu_count();
     long long gt = total < (long long)cus * wg_per_cu ? total : (long long)cus * wg_per_cu;
     if (total + gt >= 0xFFFFFFFFLL || !a.ticket) {
         set_error("fir_fft: %lld transforms in one launch exceed the ticket counter", total);

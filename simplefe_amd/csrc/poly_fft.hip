@@ -30,6 +30,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "common.h"
 #include "fft16.h"
 
@@ -472,14 +474,16 @@ template <int SP, int UP, int R, bool IN_U8, bool PAIR, int DIAG = 0, bool TICKE
 int launch_one(const PolyFftArgs &a0, int n_channels, hipStream_t s)
 {
     PolyFftArgs a = a0;
-    static int resident = 0;
-    if (!resident) {
-        int dev = 0, cus = 0, per_cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, poly_fft256_kernel<SP, UP, R, IN_U8, PAIR, DIAG, TICKET, LATE, WPS>, 256, 0) != hipSuccess || per_cu < 1)
+    // workgroups of this instantiation a CU holds (a property of the code object, the same on every
+    // gfx950 device) x the compute units of the launch's device (cached per device ordinal, common.h)
+    static std::atomic<int> per_cu_cache{0};
+    int per_cu = per_cu_cache.load(std::memory_order_relaxed);
+    if (!per_cu) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, poly_fft256_kernel<SP, UP, R, IN_U8, PAIR, DIAG, TICKET, LATE, WPS>, 256, 0) != hipSuccess || per_cu < 1)
             return hip_fail(hipGetLastError(), "poly_fft occupancy");
-        resident = cus * per_cu;
+        per_cu_cache.store(per_cu, std::memory_order_relaxed);
     }
+    const long long resident = (long long)device_cu_count() * per_cu;
     // persistent workgroups, shared over the channels
     // fixed-stride walk: two workgroups per resident slot (1, 2, 3, 4, 8 measured within noise of each
     // other); work counters: exactly the resident count -- any further workgroup would start when

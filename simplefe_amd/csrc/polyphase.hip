@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
 }
 
 // ------------------------------------------- integer-step law on the matrix pipe (f32 MFMA)
-// OPT-IN (SFE_RS_MFMA=1), kept as measured evidence.  The 127-tap-per-arm resampler is VALU-bound
+// OPT-IN (sfe_dsp_rs_set_algo(h, SFE_RS_ALGO_MFMA)), kept as measured evidence.  The 127-tap-per-arm resampler is VALU-bound
 // in the tiled kernel (130 v_pk_fma_f32 per output is its arithmetic floor; 39 % of the HBM
 // roofline).  Grouping RG = UP*DM consecutive outputs makes the tap matrix A[RG x Kp] 78 % dense
 // for that shape, and v_mfma_f32_16x16x4_f32 is an exact k-ordered fmaf chain
@@ -765,7 +765,7 @@ int launch_poly_mfma(const PolyMfmaArgs &a, int n_channels, hipStream_t s)
     if (const char *e = getenv("SFE_MFMA_WG_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
 #endif
     long long gx = (tiles + 3) / 4;
-    const long long cap = (256LL * per_cu + n_channels - 1) / n_channels;
+    const long long cap = ((long long)device_cu_count() * per_cu + n_channels - 1) / n_channels;
     if (gx > cap) gx = cap;
     dim3 grid((unsigned)gx, (unsigned)n_channels), block(256);
 #ifdef SFE_DIAG

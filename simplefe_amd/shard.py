@@ -26,25 +26,21 @@ def span_block(n_samples, world, rank, quantum=1):
     return first, max(0, min(per, n - first))
 
 
-def halo_from_left(tail, halo_len, device=None):
-    """The one data exchange a cut stream needs: every rank sends the last `halo_len` samples of its
-    span to its right neighbour (n_taps-1 samples, 2 KiB for 256 taps cf32) and receives its own
-    halo from the left; rank 0 gets zeros (stream start).  `tail`: 1-D float32 tensor holding AT
-    LEAST the span's last halo_len elements (on the GPU under RCCL, on the host under gloo).
-    Point-to-point over xGMI (RCCL send/recv), not a collective."""
+def halo_exchange(tail, halo_len, left, right):
+    """Send the last `halo_len` elements of `tail` to rank `right` and receive as many from rank
+    `left` (either may be None: nothing sent / zeros returned).  One batched RCCL send/recv pair --
+    point to point over one xGMI link, not a collective; under gloo the same calls on host tensors.
+    A rank may name itself on both sides (a world of one: the loop-back the one-GPU box can run)."""
     import torch
     import torch.distributed as dist
     halo = torch.zeros(halo_len, dtype=tail.dtype, device=tail.device)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return halo
-    rank, world = dist.get_rank(), dist.get_world_size()
     send = tail[-halo_len:].contiguous() if tail.numel() >= halo_len else torch.cat(
         [torch.zeros(halo_len - tail.numel(), dtype=tail.dtype, device=tail.device), tail])
     ops = []
-    if rank + 1 < world:
-        ops.append(dist.P2POp(dist.isend, send, rank + 1))
-    if rank > 0:
-        ops.append(dist.P2POp(dist.irecv, halo, rank - 1))
+    if right is not None:
+        ops.append(dist.P2POp(dist.isend, send, right))
+    if left is not None:
+        ops.append(dist.P2POp(dist.irecv, halo, left))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
@@ -55,16 +51,30 @@ def halo_from_left(tail, halo_len, device=None):
     return halo
 
 
+def halo_from_left(tail, halo_len, device=None):
+    """The one data exchange a cut stream needs: every rank sends the last `halo_len` samples of its
+    span to its right neighbour (n_taps-1 samples, 2 KiB for 256 taps cf32) and receives its own
+    halo from the left; rank 0 gets zeros (stream start).  `tail`: 1-D float32 tensor holding AT
+    LEAST the span's last halo_len elements (on the GPU under RCCL, on the host under gloo)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return torch.zeros(halo_len, dtype=tail.dtype, device=tail.device)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    return halo_exchange(tail, halo_len, rank - 1 if rank > 0 else None, rank + 1 if rank + 1 < world else None)
+
+
 def env_ranks():
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init_process_group(device=None):
-    """One process per GPU, rendezvous on 127.0.0.1; returns (rank, local_rank, world)."""
+def init_process_group(device=None, force=False):
+    """One process per GPU, rendezvous on 127.0.0.1; returns (rank, local_rank, world).  A single
+    rank makes no group unless `force` (the world-size-1 RCCL group of tests/test_gpu_rccl.py)."""
     import torch.distributed as dist
     rank, local_rank, world = env_ranks()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         # RCCL ("nccl") on GPUs, gloo on CPU-only hosts; SFE_DIST_BACKEND=gloo lets the N > 1 code
@@ -78,9 +88,12 @@ def init_process_group(device=None):
 
 
 def max_over_ranks(value, device=None):
+    """MAX of one float over the ranks.  Runs the collective whenever a process group exists (a
+    world-size-1 RCCL group included: tests/test_gpu_rccl.py drives exactly this code on the one-GPU
+    box); without a group it is the identity."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -91,12 +104,12 @@ def sum_over_ranks(values, device=None):
     import torch
     import torch.distributed as dist
     t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [float(v) for v in t.tolist()]
 
 
 def barrier():
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()

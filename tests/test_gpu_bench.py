@@ -25,23 +25,46 @@ def _bench(*args, env_extra=None, timeout=600):
 
 def test_bench_gpus2_from_a_bare_shell_starts_two_ranks_and_checks_both():
     """`python bench.py --gpus 2` with WORLD_SIZE unset must start 2 ranks itself (here both on the
-    one device, over gloo: SFE_BENCH_ONE_DEVICE=1) and report n_gpus == 2 with every rank's
-    windows checked; the all-reduced checksum equals the one-process run over the same 16
-    channels (seeds 0..15) -- the channel partition changes nothing."""
-    r2, j2 = _bench("--gpus", "2", "--log2n", "22", "--steps", "3", "--warmup", "1", "--no-cpu",
+    one device, over gloo: SFE_BENCH_ONE_DEVICE=1) and run BASELINE configs[4] as written: the
+    FIXED 64-channel job block-partitioned 32 + 32 (strong scaling), every local channel of every
+    rank checked; the all-reduced checksum equals the one-process run over the same 64 channels
+    (seeds 0..63) -- the channel partition changes nothing."""
+    r2, j2 = _bench("--gpus", "2", "--log2n", "24", "--steps", "3", "--warmup", "1", "--no-cpu",
                     env_extra={"SFE_BENCH_ONE_DEVICE": "1"})
     assert r2.returncode == 0, r2.stdout + r2.stderr
-    assert j2["n_gpus"] == 2 and j2["config"]["channels_per_gpu"] == 8
-    assert j2["parity"]["ok"] and j2["parity"]["ranks_checked"] == 2 and j2["parity"]["windows"] == 8
-    assert j2["checksum"]["samples"] == 2 * (1 << 22)
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "strong"
+    cfg = j2["config"]
+    assert cfg["channels_per_gpu"] == 32 and cfg["channels_total"] == 64 and cfg["samples_per_channel"] == 1 << 18
+    assert "64 independent cf32 channels" in cfg["workload"] and "64/2 per GPU" in cfg["workload"]
+    assert j2["parity"]["ok"] and j2["parity"]["ranks_checked"] == 2
+    assert j2["parity"]["windows"] == 64 * 2                   # every channel: first and last window
+    assert j2["checksum"]["samples"] == 1 << 24
+    assert j2["roofline"]["peak"] == 16000.0 and 0 < j2["roofline"]["frac"] < 1
+    for k in ("kernel_ms_min", "kernel_ms_max", "kernel_ms_std"):
+        assert k in j2["roofline"]
     # one stream cut across the two ranks, halo exchanged point to point: the seam matches the uncut stream
-    assert j2["split_stream"]["ok"] and j2["split_stream"]["spans"] == 2, j2["split_stream"]
-    r1, j1 = _bench("--gpus", "1", "--log2n", "23", "--channels", "16", "--steps", "3", "--warmup", "1", "--no-cpu")
+    ss = j2["split_stream"]
+    assert ss["ok"] and ss["spans"] == 2 and ss["exchange"].startswith("point-to-point"), ss
+    r1, j1 = _bench("--gpus", "1", "--log2n", "24", "--channels", "64", "--steps", "3", "--warmup", "1", "--no-cpu")
     assert r1.returncode == 0, r1.stdout + r1.stderr
     assert j1["n_gpus"] == 1 and j1["checksum"]["samples"] == j2["checksum"]["samples"]
+    assert j1["config"]["channels_per_gpu"] == 64
     for k in ("sum_re", "sum_im", "sum_abs2"):
         a, b = j1["checksum"][k], j2["checksum"][k]
         assert abs(a - b) <= 1e-9 * max(1.0, abs(a)), (k, a, b)
+
+
+def test_bench_gpus2_default_shape_carries_the_weak_row():
+    """No --log2n/--channels at N > 1: the 64 x 2^24 job as the headline (32 channels per rank here)
+    and the round-2 weak shape (8 channels x 2^25 per rank) as an other_configs row, both checked."""
+    r, j = _bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--other-steps", "3", "--no-cpu",
+                  env_extra={"SFE_BENCH_ONE_DEVICE": "1"}, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert j["config"]["samples_per_channel"] == 1 << 24 and j["config"]["channels_per_gpu"] == 32
+    assert j["config"]["samples_total"] == 1 << 30 and j["parity"]["ok"]
+    rows = j["other_configs"]
+    assert len(rows) == 1 and rows[0]["scaling"] == "weak" and rows[0]["parity"]["ok"], rows
+    assert "8 channel(s) x 2^25" in rows[0]["workload"]
 
 
 def test_bench_refuses_a_world_size_that_is_not_gpus():
@@ -58,5 +81,8 @@ def test_bench_default_line_small():
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "checksum"):
         assert k in j, k
     assert j["parity"]["ok"] and j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1
+    rf = j["roofline"]
+    assert rf["kernel_ms_min"] <= rf["kernel_ms_median"] <= rf["kernel_ms_max"] and rf["kernel_ms_std"] >= 0
+    assert rf["traffic"] is None or not rf.get("traffic_stale")      # never stale bytes
     cb = j["cpu_baseline"]
     assert cb["cores"] == 1 and cb["all_cores"]["cores"] == cb["host_cores"] >= 1

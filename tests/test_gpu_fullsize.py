@@ -211,8 +211,6 @@ def test_resample_cfg3_full_size_default_kernel(api, L, orc, monkeypatch):
     (resample.cxx:100-148) at the stream start, at pass seams (a pass = 2 segments x 231 low-rate
     points = 2310 inputs = 1386 outputs), in the middle, where a persistent workgroup takes
     its second pass, and at the end (input byte offsets just below 2^31)."""
-    monkeypatch.delenv("SFE_RS_FFT", raising=False)
-    monkeypatch.delenv("SFE_RS_MFMA", raising=False)
     n = 1 << 28
     taps = synth.taps_cfg3()
     x = api.DeviceArray(2 * n)
@@ -340,8 +338,6 @@ def test_resample_beyond_4_gib_input(api, L, orc, monkeypatch):
     """Resample 5/3 (381 taps, the default transform-domain kernel) over 2^29 + 2^22 + 777 cf32 samples:
     input byte offsets pass 2^32 with 32 MiB to go.  Windows of the output whose inputs sit either side of that boundary, at a
     pass seam beyond it and at the end, against the oracle."""
-    monkeypatch.delenv("SFE_RS_FFT", raising=False)
-    monkeypatch.delenv("SFE_RS_MFMA", raising=False)
     n = (1 << 29) + (1 << 22) + 777
     taps = synth.taps_cfg3()
     x = api.DeviceArray(2 * n)
@@ -374,8 +370,6 @@ def test_parity_at_scale_32_windows_of_2pow16(api, L, orc, monkeypatch):
     windows of 2^16 outputs -- always the stream start, the last window and windows straddling the GPU's
     block seams -- against the CPU oracle fed the corresponding input span plus the filter's history.
     The kernels bench.py times (default mode): cfg2 FIR, cfg3 resample 5/3, cfg4 decimate by 8."""
-    monkeypatch.delenv("SFE_RS_FFT", raising=False)
-    monkeypatch.delenv("SFE_RS_MFMA", raising=False)
     rng = np.random.default_rng(synth.SEED)
     W = 1 << 16
     # ---- cfg2: 256-tap FIR, 2^28 cf32 (transform seams every 3840 samples; runs of eight per work counter)

@@ -97,7 +97,6 @@ def test_rs_fft_path_random_shapes(api, L, monkeypatch, seed):
     the longest overlap it accepts (beyond that the call silently takes the direct kernel), stream
     lengths around segment/pass boundaries, random chunkings and channel counts -- against the
     exact-mode kernels (bit-exact with the compiled reference, tested elsewhere)."""
-    monkeypatch.setenv("SFE_RS_FFT", "1")
     rng = np.random.default_rng(3000 + seed)
     U, S = [(3, 5), (2, 3), (2, 5), (3, 4), (1, 2), (1, 3), (1, 4), (1, 5), (1, 6), (1, 7), (1, 8), (2, 7), (4, 5),
             (6, 10), (2, 4), (3, 9)][seed]
@@ -112,7 +111,7 @@ def test_rs_fft_path_random_shapes(api, L, monkeypatch, seed):
     cuts = sorted(set([0, n] + [int(v) for v in rng.integers(1, n, size=int(rng.integers(0, 3)))]))
     outs = {}
     for exact in (False, True):
-        r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=True, n_channels=nch)
+        r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=True, n_channels=nch, algo=L.RS_ALGO_FFT)
         r.set_exact(exact)
         parts = []
         for a, b in zip(cuts[:-1], cuts[1:]):

@@ -424,19 +424,18 @@ def test_converters_bit_exact(api, L, orc):
 @pytest.mark.parametrize("name,force", [("cfg3", True), ("cfg4", True), ("gen2_int", True)])
 @pytest.mark.parametrize("chunk", [None, 5000, 1001])
 def test_rs_bulk_mfma_path_cf32(api, L, orc, g5, monkeypatch, name, force, chunk):
-    """The opt-in f32-MFMA form of the bulk path (SFE_RS_MFMA=1) on cf32 data: 5/3 resampler
+    """The opt-in f32-MFMA form of the bulk path (sfe_dsp_rs_set_algo MFMA) on cf32 data: 5/3 resampler
     (78 % dense tap matrix), 7/3 (odd step), and decimate/8, whose plan does not fit and must fall
     back to the VALU kernel silently.  Versus the oracle, I and Q as
     two real passes; chunked calls exercise every carried pos0."""
-    if force:
-        monkeypatch.setenv("SFE_RS_MFMA", "1")
     if name == "gen2_int":
         taps, U, rate = g5["cfg3_taps"], 3, 7.0 / 3.0
     else:
         taps, U, rate = g5[f"{name}_taps"], int(g5[f"{name}_U"]), float(g5[f"{name}_rate"])
     n, nch = 40000, 2
     x = np.stack([synth.synth_cf32(n, ch=c) for c in range(nch)])
-    r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=True, n_channels=nch)
+    r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=True, n_channels=nch,
+               algo=L.RS_ALGO_MFMA if force else L.RS_ALGO_AUTO)
     y = r.resample_array(x, rate, chunk=chunk)
     for c in range(nch):
         for part in (0, 1):
@@ -457,14 +456,13 @@ def test_rs_bulk_mfma_path_cf32(api, L, orc, g5, monkeypatch, name, force, chunk
     (2, 7, 450, 100000, 1, 33000), (4, 5, 700, 90000, 1, None), (3, 5, 381, 30000, 19, None)])
 def test_rs_bulk_fft_path_cf32(api, L, orc, monkeypatch, U, S, n_taps, n, nch, chunk):
     """Every instantiated (SP, UP) of the 256-point transform-domain kernel, forced on
-    (SFE_RS_FFT=1), against the oracle with I and Q as two real passes: ragged ends, chunked calls
+    (sfe_dsp_rs_set_algo FFT), against the oracle with I and Q as two real passes: ragged ends, chunked calls
     (carried history and pos0), channel strides, a filter too short to need it, one whose overlap
     (Li = 192 low-rate taps of every 256 points) is the longest it accepts, and a stream of few segments."""
-    monkeypatch.setenv("SFE_RS_FFT", "1")
     rng = np.random.default_rng(U * 100 + S)
     taps = (rng.standard_normal(n_taps) / np.sqrt(n_taps)).astype(np.float32)
     x = np.stack([synth.synth_cf32(n, ch=10 + c) for c in range(nch)])
-    r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=True, n_channels=nch)
+    r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=True, n_channels=nch, algo=L.RS_ALGO_FFT)
     y = r.resample_array(x, float(np.float32(S) / np.float32(U)), chunk=chunk)
     for c in range(nch):
         for part in (0, 1):
@@ -482,12 +480,11 @@ def test_rs_bulk_fft_path_real_data(api, L, orc, monkeypatch, U, S, n_taps, n, n
     """Real float32 streams through the transform-domain kernel: two consecutive real segments
     ride as the real and imaginary parts of one transform (the sub-filters are real).  Odd and
     even segment counts, streams ending inside the first / second half of a pair, chunked calls."""
-    monkeypatch.setenv("SFE_RS_FFT", "1")
     rng = np.random.default_rng(U * 1000 + S)
     taps = (rng.standard_normal(n_taps) / np.sqrt(n_taps)).astype(np.float32)
     x = np.stack([synth.synth_f32(n, ch=20 + c) for c in range(nch)])
     rate = float(np.float32(S) / np.float32(U))
-    r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=False, n_channels=nch)
+    r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=False, n_channels=nch, algo=L.RS_ALGO_FFT)
     y = r.resample_array(x, rate, chunk=chunk)
     for c in range(nch):
         ref, _ = orc.Resample(taps, U, 4096).stream(x[c], rate)
@@ -499,7 +496,6 @@ def test_rs_bulk_fft_path_real_data(api, L, orc, monkeypatch, U, S, n_taps, n, n
 def test_rs_bulk_fft_path_decimate_mode(api, L, orc, monkeypatch, U, S, n_taps):
     """The decimate class's bulk path (mode DECIMATE: its own tap folding, decimate.cxx:37-66)
     takes the transform-domain kernel for long filters by default; against the oracle's Decimate."""
-    monkeypatch.delenv("SFE_RS_FFT", raising=False)
     rng = np.random.default_rng(S * 10 + U)
     taps = (rng.standard_normal(n_taps) / np.sqrt(n_taps)).astype(np.float32)
     n = 150001
@@ -521,17 +517,13 @@ def test_rs_bulk_fft_path_decimate_mode(api, L, orc, monkeypatch, U, S, n_taps):
 
 def test_rs_fft_path_is_the_default_for_long_filters(api, L, g5, monkeypatch):
     """cfg3 (5/3, 381 taps) takes the transform-domain kernel by default and the direct kernel
-    with SFE_RS_FFT=0 or in exact mode; the two agree to float32 rounding and the exact one is
+    with sfe_dsp_rs_set_algo(DIRECT) or in exact mode; the two agree to float32 rounding and the exact one is
     bit-identical with the oracle's law (checked elsewhere), so the default is within tolerance."""
     taps, U, rate = g5["cfg3_taps"], 3, float(g5["cfg3_rate"])
     x = synth.synth_cf32(300000, ch=3)[None, :]
     ys = []
-    for env, exact in (("", False), ("0", False), ("", True)):
-        if env:
-            monkeypatch.setenv("SFE_RS_FFT", env)
-        else:
-            monkeypatch.delenv("SFE_RS_FFT", raising=False)
-        r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=True)
+    for algo, exact in ((L.RS_ALGO_AUTO, False), (L.RS_ALGO_DIRECT, False), (L.RS_ALGO_AUTO, True)):
+        r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=True, algo=algo)
         r.set_exact(exact)
         ys.append(r.resample_array(x, rate)[0])
         r.close()
