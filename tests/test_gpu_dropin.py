@@ -36,6 +36,27 @@ def test_reference_test_blkconv_program_unmodified(g1):
     assert [v.lstrip("-") for v in vals] == want       # "-0.00" and "0.00" print alike in effect
 
 
+def test_reference_test_program_built_by_the_committed_cmake_target(g1):
+    """The same program built through CMakeLists.txt's `Libdsp` target by a scratch project whose only
+    source is the reference's test_blkconv.cxx (tests/test_cmake_dropin.py builds it under
+    oracle/_ref/cmake_dropin/), linked to the libsfe_dsp.so CMake built with hipcc: same known answer."""
+    build = os.path.join(ROOT, "oracle/_ref/cmake_dropin/build")
+    exe = os.path.join(build, "test_blkconv")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/cmake_dropin not prebuilt (tests/test_cmake_dropin.py)")
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(build, "sfe_dsp") + ":" + env.get("LD_LIBRARY_PATH", "")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.split("\n")
+    assert lines[0].strip() == "blksize = 28"
+    vals = [l.strip() for l in lines[1:] if l.strip()]
+    want = ["%.2f" % v for v in list(g1["out1"]) + list(g1["out2"])]
+    assert [v.lstrip("-") for v in vals] == want
+    maps = subprocess.run(["ldd", exe], capture_output=True, text=True, env=env).stdout
+    assert "cmake_dropin/build/sfe_dsp/libsfe_dsp.so" in maps, maps      # the CMake-built library, not the in-tree one
+
+
 def test_reference_test_program_prints_the_same_either_way():
     """test_blkconv.cxx linked the reference's way (its own blkconv.cxx + ROCm's libhipfftw for
     the FFTW calls) and linked to the drop-in: the two programs print the same lines."""
