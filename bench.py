@@ -292,6 +292,14 @@ def make_fir_leg(ctx, name, taps, n, nch, ch0=0, algo="auto", in_fmt="f32", out_
     def step():
         leg.obj.process_stream(sp, yp, n, stream=stream)
     leg.step = step
+    # untimed first call: a large cf32 call measures the kernel's data-movement variants on THIS device
+    # once per shape (api.hip: fir_pick_variant) -- here, so that it can never fall into a timed step
+    step()
+    torch.cuda.synchronize()
+    v, cal, ms = leg.obj.get_variant()
+    leg.variant = {"ran": lib.FIR_VARIANT_NAMES.get(v, str(v)), "measured_by_this_handle": bool(cal)}
+    if cal:
+        leg.variant["median_ms"] = {lib.FIR_VARIANT_NAMES[i]: round(m, 4) for i, m in enumerate(ms) if m > 0}
 
     def check(full):
         """Windows of the LAST step's output against the oracle (history = the tail of the same
@@ -635,6 +643,8 @@ def main():
                "value": world * leg.n_gpu / (el / args.other_steps) / 1e6, "unit": "MS/s (input)",
                "kernel": leg.kernel, "algorithmic_bytes_per_launch": leg.bytes_per_launch,
                "frac": leg.bytes_per_launch / (kmean * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if getattr(leg, "variant", None):
+            row["variant"] = leg.variant["ran"]
         if world > 1:
             row["scaling"] = "weak"
             row["workload"] += " -- per rank, %d ranks (weak scaling: the per-GPU launch is the same at every N)" % world
@@ -693,6 +703,8 @@ def main():
         "checksum": {"samples": csum[0], "sum_re": csum[1], "sum_im": csum[2], "sum_abs2": csum[3],
                      "over": "all ranks' last output (float64 sums, all-reduced)"},
     }
+    if getattr(head, "variant", None):
+        out["roofline"]["variant"] = head.variant     # which data-movement variant this device's measurement picked
     if traffic_stale:
         out["roofline"]["traffic_stale"] = True      # simplefe_amd/csrc changed since the PMC pass in profiles/
     if world > 1:

@@ -138,6 +138,25 @@ int sfe_dsp_fir_process_host(sfe_fir_t h, const void *in, void *out, size_t n);
 int sfe_dsp_fir_load_history(sfe_fir_t h, const void *d_prev, size_t n_prev, size_t stride,
                              sfe_stream_t stream);
 int sfe_dsp_fir_set_algo(sfe_fir_t h, int algo);
+/* How the rows of an aligned complex float32 stream reach the FFT kernel's transform: guarded
+ * register loads, LDS-DMA requested early, or LDS-DMA into a wave-private exchange layout
+ * (DESIGN.md 4.1).  Same arithmetic, bit-identical output; which is fastest differs by a few
+ * percent BETWEEN DEVICES of one pool, so by default (AUTO) a handle's first bulk call of >= 8192
+ * transforms on a device and shape times all of them on that call's own buffers (three interleaved
+ * rounds; the call then takes ~10x its usual time, and is not asynchronous) and the process
+ * remembers the winner for that (device, channels, size class, overlap).  set_variant fixes the
+ * choice and turns the measurement off (latency-critical callers; a call inside a hipGraph capture
+ * never measures).  get_variant: what the handle's last bulk call ran, how many measurements this
+ * handle made, and (ms_by_variant: 3 floats, may be NULL) the medians of its last measurement.
+ * forget_calibrations drops the process-wide memory.  No reference counterpart: blkconv has one
+ * code path (libdsp/blkconv.cxx:77-110). */
+#define SFE_FIR_VARIANT_AUTO          (-1)
+#define SFE_FIR_VARIANT_REGISTER_LOADS  0
+#define SFE_FIR_VARIANT_LDS_DMA         1
+#define SFE_FIR_VARIANT_WAVE_PRIVATE    2
+int sfe_dsp_fir_set_variant(sfe_fir_t h, int variant);
+int sfe_dsp_fir_get_variant(sfe_fir_t h, int *last_variant, int *calibrations, float *ms_by_variant);
+int sfe_dsp_fir_forget_calibrations(void);
 /* Host calls (blkconv::process() on the object's buffer, sfe_dsp_fir_process_host) of at most
  * max_samples samples let the kernel read and write pinned host memory itself -- one stream
  * operation instead of copy-in, launch, copy-out (default 2^20 samples; 0 = always the DMA copies).
@@ -152,7 +171,9 @@ int sfe_dsp_fir_set_zero_copy_max(sfe_fir_t h, size_t max_samples);
  * `batch_items` (0 = 262144) and keeps up to four batches in flight on three streams (copy in,
  * filter, copy out); pull hands out finished items in order.  Item k out is the filter's output
  * for item k in: no delay is inserted, only latency.  While a pipe exists, drive its handle only
- * through the pipe.
+ * through the pipe: the pipe sized its batches from the handle's item formats, so the handle's
+ * format setters that would change them, and its destroy call, return SFE_ESTATE until the pipe
+ * is destroyed.
  *   push  copies up to n_items in; *n_taken < n_items means every batch is in flight: pull first.
  *   pull  copies up to max_items finished items out.  wait = 0: only what has already arrived;
  *         1: block for the oldest batch in flight; 2: also send a partly filled batch on its way

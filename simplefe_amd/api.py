@@ -147,6 +147,17 @@ class Fir:
     def set_algo(self, algo):
         check(self._L.sfe_dsp_fir_set_algo(self._h, algo))
 
+    def set_variant(self, variant):
+        """lib.FIR_VARIANT_*: fix the cf32 kernel's data-movement variant (AUTO: measured per device and shape)."""
+        check(self._L.sfe_dsp_fir_set_variant(self._h, int(variant)))
+
+    def get_variant(self):
+        """(variant of the last bulk call, calibrations made by this handle, [median ms per variant])."""
+        v, k = C.c_int(-1), C.c_int(0)
+        ms = (C.c_float * 3)()
+        check(self._L.sfe_dsp_fir_get_variant(self._h, C.byref(v), C.byref(k), ms))
+        return v.value, k.value, [float(m) for m in ms]
+
     def set_zero_copy_max(self, max_samples):
         check(self._L.sfe_dsp_fir_set_zero_copy_max(self._h, int(max_samples)))
 

@@ -6,6 +6,7 @@ hipcc cross-compiles without a GPU; the built .so sits next to this file so that
 with the repo snapshot to the GPU box and is the library the tests are seen to load.
 """
 import glob
+import json
 import os
 import subprocess
 import sys
@@ -52,6 +53,60 @@ def needs_build(lib=LIB):
     return any(os.path.getmtime(p) > t for p in _deps())
 
 
+def parse_resources(text):
+    """hipcc -Rpass-analysis=kernel-resource-usage remarks -> {demangled kernel name: {field: value}}."""
+    import re
+    out, cur = {}, None
+    for line in text.splitlines():
+        m = re.search(r"remark:\s+Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+(TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|SGPRs Spill|VGPRs Spill|"
+                      r"LDS Size \[bytes/block\]): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).split(" [")[0]] = int(m.group(2))
+    if out:
+        names = list(out)
+        dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
+        if len(dem) == len(names):
+            out = {d: out[n] for d, n in zip(dem, names)}
+    return out
+
+
+FIR_TEMPLATE_ARGS = "IN_C OUT_C WAVES PREFETCH SWZ HREG IN_U8 PAIR OUT_TX10 DMA DIAG TICKET ACC WP HCH".split()
+
+
+def fir_kernel_flags(name):
+    """Template arguments of a demangled fir_fft4096_kernel<...> name -> {flag: value} (None for other kernels)."""
+    import re
+    m = re.search(r"fir_fft4096_kernel<(.*?)>\(", name)
+    if not m:
+        return None
+    vals = [a.strip() for a in m.group(1).split(",")]
+    return {k: (v == "true" if v in ("true", "false") else int(v)) for k, v in zip(FIR_TEMPLATE_ARGS, vals)}
+
+
+def check_resources(res):
+    """the LDS-DMA FIR kernels wait with a COUNTED s_waitcnt vmcnt(15) -- the eight DMA
+    pieces are older than the 15 row stores issued after them.  A scratch spill or reload between
+    the request and the wait is one MORE vector-memory operation there, which only makes that wait
+    retire some stores too (conservative, slower) -- it cannot make F1 read early; what would is
+    FEWER than 15 operations, which the kernel's own `counted` condition rules out.  So scratch in
+    these kernels is a performance bug, not a correctness one: the build refuses it for the default
+    path (DMA, padded layout: the shared-filter and the per-channel kernel) and records every
+    kernel's registers / scratch / occupancy in build/*.resources.json for the tests to read."""
+    bad = []
+    for k, r in res.get("fir_fft.hip", {}).items():
+        fl = fir_kernel_flags(k)
+        if fl and fl["DMA"] and not fl["WP"] and not fl["DIAG"] and (r.get("ScratchSize", 0) or r.get("VGPRs Spill", 0)):
+            bad.append("%s: %s" % (k[:200], r))
+        if fl and not fl["DIAG"] and r.get("Occupancy", 4) < 4:
+            bad.append("%s: fewer than 4 workgroups per CU: %s" % (k[:200], r))
+    if bad:
+        raise RuntimeError("FIR kernels of the default path must not touch scratch and must keep 4 workgroups per CU:\n  " + "\n  ".join(bad))
+
+
 def build_lib(force=False, verbose=False, extra=(), diag=False):
     LIB = LIB_DIAG if diag else globals()["LIB"]
     if diag:
@@ -71,7 +126,7 @@ def build_lib(force=False, verbose=False, extra=(), diag=False):
                                             + glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h")))):
             continue
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
-               "-Wall", "-Wno-unused-function", *extra]
+               "-Wall", "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage", *extra]
         if os.path.basename(src) in EXACT_SOURCES:
             cmd.append("-ffp-contract=off")
         if os.path.basename(src) in TICKET_SOURCES:
@@ -80,10 +135,25 @@ def build_lib(force=False, verbose=False, extra=(), diag=False):
             cmd += ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
         if verbose:
             print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, p in procs:
-        if p.wait() != 0:
+        log = open(obj + ".log", "w")
+        procs.append((cmd, subprocess.Popen(cmd, stderr=log), log, obj))
+    for cmd, p, log, obj in procs:
+        rc = p.wait()
+        log.close()
+        text = open(obj + ".log", errors="replace").read()
+        if rc != 0:
+            sys.stderr.write("\n".join(l for l in text.splitlines() if "-Rpass-analysis" not in l)[-8000:])
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
+        # registers / scratch / occupancy of every kernel in the file, kept beside the object
+        with open(obj[:-2] + ".resources.json", "w") as o:
+            json.dump(parse_resources(text), o, indent=0, sort_keys=True)
+    res = {}
+    for obj in objs:
+        rj = obj[:-2] + ".resources.json"
+        if os.path.exists(rj):
+            res[os.path.basename(obj)[:-2]] = json.load(open(rj))
+    if not diag:          # the diagnostic flavour holds measured-and-rejected variants that do spill
+        check_resources(res)
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
     if verbose:
         print(" ".join(cmd))

@@ -6,9 +6,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <map>
+#include <mutex>
 #include <new>
+#include <tuple>
 #include <numeric>
 #include <utility>
 #include <vector>
@@ -356,6 +359,10 @@ struct Fir {
     int blk = 0, block_hint = 0;
     int hl = 0;                 // carried history per channel, samples (multiple of 256)
     int ovl = 0;                // overlap of one transform (multiple of 256): each launch applies `ovl` (+1) taps
+    int variant = FIR_VAR_AUTO; // data movement of the cf32 kernel: measured per device and shape unless sfe_dsp_fir_set_variant fixed it
+    int last_variant = FIR_VAR_AUTO, cal_runs = 0;      // what the last bulk call ran; calibrations this handle made
+    float cal_ms[FIR_VAR_COUNT] = {0.0f, 0.0f, 0.0f};   // medians of this handle's last calibration, by variant
+    int piped = 0;              // pipes alive over this handle: they froze its item formats, so the format setters refuse
     int per_channel = 0;        // taps given per channel ([n_channels][n_taps]): one spectrum set per channel
     int parts = 1;              // partitions of the tap vector, one launch each (filters longer than one overlap)
     bool fft_ok = false;
@@ -363,6 +370,7 @@ struct Fir {
     unsigned *d_ticket = nullptr;   // work counter of the persistent FFT kernel (zero between launches)
     float *d_taps = nullptr;    // real taps for the direct kernel
     std::vector<float> h_taps;  // host copy (direct-kernel plan)
+    std::vector<float> h_taps_all;   // every tap as given at create (complex pairs / per-channel rows included): re-planning
     PlanCache plans;
     void *d_hist[2] = {nullptr, nullptr};
     int cur = 0;
@@ -531,6 +539,107 @@ static bool fir_choose_partition(int n_taps, int *ovl, int *parts)
     return *parts > 0;
 }
 
+// ---- which data-movement variant of the cf32 kernel (common.h: FIR_VAR_*) ------------------------
+// The three variants compute the same bits and differ by a few percent in time, with a sign that
+// depends on the box (profiles/r02/fir_walk_vs_tickets.txt against DESIGN.md 4.1's earlier tables:
+// LDS-DMA from -5.7 % to +3.7 % against register loads).  So a handle's first LARGE bulk call on a
+// device and shape runs every variant on the call's own buffers -- same output each time, the
+// history carry-over and the work counters are idempotent -- FIR_CAL_ROUNDS interleaved rounds, HIP
+// events on the caller's stream, and the smallest median is cached process-wide under
+// (device, channels, size class, overlap, per-channel taps).  Small calls, calls inside a stream
+// capture and everything that has only one variant take the default (LDS-DMA) and measure nothing.
+constexpr int FIR_CAL_ROUNDS = 5;                         // rounds that count: the LAST five
+constexpr int FIR_CAL_MAX_ROUNDS = 24;                    // ... of at most this many, and of at least FIR_CAL_WARM_MS of launches:
+constexpr float FIR_CAL_WARM_MS = 80.0f;                  // the chip's first ~100 ms of work after idling run 5-6 % slow
+constexpr long long FIR_CAL_MIN_TRANSFORMS = 8192;        // ~2^25 samples: below, the launch is a few tens of microseconds
+struct FirVarKey {
+    int device, n_channels, size_class, ovl, per_channel;
+    bool operator<(const FirVarKey &o) const
+    {
+        return std::tie(device, n_channels, size_class, ovl, per_channel) < std::tie(o.device, o.n_channels, o.size_class, o.ovl, o.per_channel);
+    }
+};
+static std::mutex g_fir_var_mutex;
+static std::map<FirVarKey, int> g_fir_var_cache;
+
+static int fir_pick_variant(Fir *f, FirFftArgs &a, hipStream_t s, int *variant)
+{
+    *variant = f->variant;                      // sfe_dsp_fir_set_variant: a fixed choice, or FIR_VAR_AUTO
+    if (*variant != FIR_VAR_AUTO) return SFE_OK;
+    *variant = FIR_VAR_DMA;
+    if (f->parts != 1 || a.nblk * f->n_channels < FIR_CAL_MIN_TRANSFORMS ||
+        !fir_fft_has_variants(a, f->data_complex, f->out_complex, f->in_u8, f->out_tx10, f->n_channels, 0))
+        return SFE_OK;
+    int sc = 0;
+    for (unsigned long long v = (unsigned long long)a.nblk * f->n_channels; v > 1; v >>= 1) sc++;
+    const FirVarKey key{f->device, f->n_channels, sc, f->ovl, f->per_channel};
+    {
+        std::lock_guard<std::mutex> lk(g_fir_var_mutex);
+        auto it = g_fir_var_cache.find(key);
+        if (it != g_fir_var_cache.end()) {
+            *variant = it->second;
+            return SFE_OK;
+        }
+    }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return SFE_OK;                          // a capture cannot be timed: default, and nothing is cached
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        if (e0) (void)hipEventDestroy(e0);
+        (void)hipGetLastError();
+        return SFE_OK;
+    }
+    const int nvar = f->per_channel ? 2 : FIR_VAR_COUNT;      // per-channel taps: no wave-private instantiation
+    float t[FIR_VAR_COUNT][FIR_CAL_ROUNDS];
+    int rc = SFE_OK;
+    // interleaved rounds; a measurement made on a chip that has just come out of idle ranks the variants by
+    // how they run at a clock the stream will never see again, so rounds go on until FIR_CAL_WARM_MS of
+    // launches have run (and at least FIR_CAL_ROUNDS rounds) and only the last FIR_CAL_ROUNDS count
+    float spent = 0.0f;
+    int rounds = 0;
+    for (int r = 0; r < FIR_CAL_MAX_ROUNDS && rc == SFE_OK && (r < FIR_CAL_ROUNDS || spent < FIR_CAL_WARM_MS); r++, rounds++)
+        for (int v = 0; v < nvar && rc == SFE_OK; v++) {
+            a.variant = v;
+            hipError_t e = hipEventRecord(e0, s);
+            rc = launch_fir_fft(a, f->data_complex, f->out_complex, f->in_u8, f->out_tx10, f->n_channels, s, 0);
+            if (rc != SFE_OK) break;
+            if (e == hipSuccess) e = hipEventRecord(e1, s);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            float ms = 0.0f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (e != hipSuccess) rc = hip_fail(e, "fir variant calibration");
+            else {
+                t[v][r % FIR_CAL_ROUNDS] = ms;         // a ring: the last FIR_CAL_ROUNDS rounds survive
+                spent += ms;
+            }
+        }
+    (void)rounds;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != SFE_OK) return rc;
+    int best = FIR_VAR_DMA;
+    float best_ms = 0.0f;
+    for (int v = 0; v < nvar; v++) {
+        std::sort(t[v], t[v] + FIR_CAL_ROUNDS);
+        const float med = t[v][FIR_CAL_ROUNDS / 2];
+        f->cal_ms[v] = med;
+        if (v == 0 || med < best_ms) {
+            best_ms = med;
+            best = v;
+        }
+    }
+    f->cal_runs++;
+    {
+        std::lock_guard<std::mutex> lk(g_fir_var_mutex);
+        g_fir_var_cache[key] = best;
+    }
+    *variant = best;
+    return SFE_OK;
+}
+
 static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_stride,
                    size_t out_stride, hipStream_t s)
 {
@@ -562,7 +671,16 @@ static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_st
         a.total = 0;
         a.tgroups = 0;
         a.hs_stride = f->per_channel ? (long long)f->parts * 16 * 256 : 0;
-        rc = SFE_OK;
+        a.variant = FIR_VAR_AUTO;
+        a.hs = f->d_hs;
+        a.shift = 0;
+        a.hist_out = hist_fused ? f->d_hist[f->cur ^ 1] : nullptr;
+        // the launches of the measurement ARE this call's (same output every time); the one below repeats it once more
+        int variant = FIR_VAR_AUTO;
+        rc = fir_pick_variant(f, a, s, &variant);
+        if (rc != SFE_OK) return rc;
+        a.variant = variant;
+        f->last_variant = variant;
         // one launch per tap partition: partition p filters the stream delayed by p*ovl samples and
         // (p > 0) adds to what the earlier ones wrote
         for (int p = 0; p < f->parts && rc == SFE_OK; p++) {
@@ -626,6 +744,7 @@ struct Rs {
     uint32_t magic = 0x52533031u;   // 'RS01'
     int U = 1, n_taps = 0, plen = 0, blksize = 0, data_complex = 0, n_channels = 1;
     int device = 0, mode = SFE_RS_RESAMPLE, exact_stream = 0, in_u8 = 0;
+    int piped = 0;                         // pipes alive over this handle (they froze its input format)
     int fft_mode = 0;                      // sfe_dsp_rs_set_algo: 1 force the transform-domain kernel, -1 never, 0 the calibrated rule
     int use_mfma = 0;                      // sfe_dsp_rs_set_algo(SFE_RS_ALGO_MFMA): the matrix-pipe form (measured slower; opt-in)
     int hl = 0;
@@ -896,6 +1015,7 @@ static int fir_create_impl(const float *taps, int n_taps, int taps_complex, int 
     auto fail = [&](int code) { fir_free(f); return code; };
 #define TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(hip_fail(e__, #call)); } while (0)
     TRY(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+    f->h_taps_all.assign(taps, taps + (size_t)n_taps * (taps_complex ? 2 : 1) * (per_channel ? n_channels : 1));
     if (f->fft_ok) {
         rc = fir_build_tables(f, taps);
         if (rc != SFE_OK) return fail(rc);
@@ -1122,6 +1242,11 @@ int sfe_dsp_fir_set_input_format(sfe_fir_t h, int fmt)
 {
     Fir *f = as_fir(h);
     if (!f || (fmt != SFE_FMT_F32 && fmt != SFE_FMT_U8)) return SFE_EINVAL;
+    if (f->piped && (fmt == SFE_FMT_U8) != (f->in_u8 != 0)) {
+        // a pipe sized its pinned and device batches from the item format at create
+        set_error("fir_set_input_format: a pipe over this handle has frozen its item format (destroy the pipe first)");
+        return SFE_ESTATE;
+    }
     if (fmt == SFE_FMT_U8 && (!f->fft_ok || f->taps_complex)) {
         set_error("fir_set_input_format: u8 input needs the FFT kernel with real taps");
         return SFE_ESTATE;
@@ -1130,13 +1255,57 @@ int sfe_dsp_fir_set_input_format(sfe_fir_t h, int fmt)
     return SFE_OK;
 }
 
+// A filter of ~2818..3841 taps is served fastest by TWO partitions (fir_choose_partition), but the
+// 10-bit packed output exists for the single-launch kernel only (partitions after the first
+// read-modify-write float32).  One transform can still overlap such a filter (hl1 < 4096), so the
+// handle is re-planned as ONE partition: new spectrum table, new (zeroed) history.  ADVICE r2.
+static int fir_replan_single(Fir *f)
+{
+    const int need = f->n_taps > 1 ? f->n_taps - 1 : 1;
+    const int hl1 = ((need + 255) / 256) * 256;
+    if (hl1 >= FFT_N) return SFE_ESTATE;
+    SFE_HIP(hipDeviceSynchronize());
+    if (f->d_hs) (void)hipFree(f->d_hs);
+    if (f->d_tw1) (void)hipFree(f->d_tw1);
+    if (f->d_tw2) (void)hipFree(f->d_tw2);
+    if (f->d_ticket) (void)hipFree(f->d_ticket);
+    f->d_hs = f->d_tw1 = f->d_tw2 = nullptr;
+    f->d_ticket = nullptr;
+    for (int i = 0; i < 2; i++) {
+        if (f->d_hist[i]) (void)hipFree(f->d_hist[i]);
+        f->d_hist[i] = nullptr;
+    }
+    f->parts = 1;
+    f->ovl = hl1;
+    f->hl = hl1;
+    f->cur = 0;
+    int rc = fir_build_tables(f, f->h_taps_all.data());
+    if (rc != SFE_OK) return rc;
+    for (int i = 0; i < 2; i++) {
+        SFE_HIP(hipMalloc(&f->d_hist[i], f->hist_bytes()));
+        SFE_HIP(hipMemset(f->d_hist[i], 0, f->hist_bytes()));
+    }
+    return SFE_OK;
+}
+
 int sfe_dsp_fir_set_output_format(sfe_fir_t h, int fmt)
 {
     Fir *f = as_fir(h);
     if (!f || (fmt != SFE_FMT_F32 && fmt != SFE_FMT_TX10)) return SFE_EINVAL;
+    if (f->piped && fmt != SFE_FMT_F32) {
+        set_error("fir_set_output_format: a pipe over this handle hands out float32 items (destroy the pipe first)");
+        return SFE_ESTATE;
+    }
+    if (fmt == SFE_FMT_TX10 && f->fft_ok && f->parts > 1 && f->data_complex == f->out_complex) {
+        // up to 3841 taps one transform still overlaps the filter: re-plan as a single launch (the carried state is zeroed:
+        // formats are set before a stream starts)
+        SFE_ON_DEVICE(f->device);
+        int rc = fir_replan_single(f);
+        if (rc != SFE_OK && rc != SFE_ESTATE) return rc;
+    }
     if (fmt == SFE_FMT_TX10 && (!f->fft_ok || f->parts > 1 || f->data_complex != f->out_complex)) {
         set_error("fir_set_output_format: 10-bit output needs the single-launch FFT kernel (a filter that one 4096-point "
-                  "transform can overlap) and a real->real or complex->complex stream");
+                  "transform can overlap: up to 3841 taps) and a real->real or complex->complex stream");
         return SFE_ESTATE;
     }
     f->out_tx10 = fmt == SFE_FMT_TX10;
@@ -1148,6 +1317,35 @@ int sfe_dsp_fir_set_algo(sfe_fir_t h, int algo)
     Fir *f = as_fir(h);
     if (!f || algo < SFE_FIR_ALGO_AUTO || algo > SFE_FIR_ALGO_FFT) return SFE_EINVAL;
     f->algo = algo;
+    return SFE_OK;
+}
+
+int sfe_dsp_fir_set_variant(sfe_fir_t h, int variant)
+{
+    Fir *f = as_fir(h);
+    if (!f || variant < SFE_FIR_VARIANT_AUTO || variant > SFE_FIR_VARIANT_WAVE_PRIVATE) {
+        set_error("fir_set_variant: -1 (measure) or 0..2");
+        return SFE_EINVAL;
+    }
+    f->variant = variant;
+    return SFE_OK;
+}
+
+int sfe_dsp_fir_get_variant(sfe_fir_t h, int *last_variant, int *calibrations, float *ms_by_variant)
+{
+    Fir *f = as_fir(h);
+    if (!f) return SFE_EINVAL;
+    if (last_variant) *last_variant = f->last_variant;
+    if (calibrations) *calibrations = f->cal_runs;
+    if (ms_by_variant)
+        for (int v = 0; v < FIR_VAR_COUNT; v++) ms_by_variant[v] = f->cal_ms[v];
+    return SFE_OK;
+}
+
+int sfe_dsp_fir_forget_calibrations(void)
+{
+    std::lock_guard<std::mutex> lk(g_fir_var_mutex);
+    g_fir_var_cache.clear();
     return SFE_OK;
 }
 
@@ -1179,6 +1377,10 @@ int sfe_dsp_fir_destroy(sfe_fir_t h)
 {
     Fir *f = as_fir(h);
     if (!f) return SFE_OK;
+    if (f->piped) {
+        set_error("fir_destroy: a pipe still borrows this handle (sfe_dsp_pipe_destroy first)");
+        return SFE_ESTATE;
+    }
     DeviceGuard g(f->device);
     (void)hipDeviceSynchronize();
     fir_free(f);
@@ -1723,6 +1925,10 @@ int sfe_dsp_rs_set_input_format(sfe_rs_t h, int fmt)
 {
     Rs *r = as_rs(h);
     if (!r || (fmt != SFE_FMT_F32 && fmt != SFE_FMT_U8)) return SFE_EINVAL;
+    if (r->piped && (fmt == SFE_FMT_U8) != (r->in_u8 != 0)) {
+        set_error("rs_set_input_format: a pipe over this handle has frozen its item format (destroy the pipe first)");
+        return SFE_ESTATE;
+    }
     r->in_u8 = fmt == SFE_FMT_U8;
     return SFE_OK;
 }
@@ -1765,6 +1971,10 @@ int sfe_dsp_rs_destroy(sfe_rs_t h)
 {
     Rs *r = as_rs(h);
     if (!r) return SFE_OK;
+    if (r->piped) {
+        set_error("rs_destroy: a pipe still borrows this handle (sfe_dsp_pipe_destroy first)");
+        return SFE_ESTATE;
+    }
     DeviceGuard g(r->device);
     (void)hipDeviceSynchronize();
     rs_free(r);
@@ -1957,7 +2167,9 @@ int sfe_dsp_fir_pipe_create(sfe_fir_t fir, size_t batch_items, sfe_pipe_t *out)
     // 2 bytes per complex item, 1 per real one -- a receive chain hands the device's bytes straight in)
     p->in_e = f->in_u8 ? (f->data_complex ? 2 : 1) : (f->data_complex ? 8 : 4);
     p->out_e = f->out_complex ? 8 : 4;
-    return pipe_alloc(p, out);
+    const int rc = pipe_alloc(p, out);
+    if (rc == SFE_OK) f->piped++;          // the handle's formats are frozen while the pipe lives
+    return rc;
 }
 
 int sfe_dsp_rs_pipe_create(sfe_rs_t rs, size_t batch_items, float rate, sfe_pipe_t *out)
@@ -1991,7 +2203,9 @@ int sfe_dsp_rs_pipe_create(sfe_rs_t rs, size_t batch_items, float rate, sfe_pipe
     p->out_cap = (size_t)ceil((double)batch_items / (double)rate) + 8;
     p->out_e = (size_t)r->esz();
     p->in_e = r->in_u8 ? (r->data_complex ? 2 : 1) : p->out_e;      // u8 wire-format items in (integer-valued steps)
-    return pipe_alloc(p, out);
+    const int rc = pipe_alloc(p, out);
+    if (rc == SFE_OK) r->piped++;
+    return rc;
 }
 
 int sfe_dsp_pipe_push(sfe_pipe_t h, const void *in, size_t n_items, size_t *n_taken)
@@ -2087,6 +2301,9 @@ int sfe_dsp_pipe_destroy(sfe_pipe_t h)
         (void)hipStreamSynchronize(p->s_k);
         (void)hipStreamSynchronize(p->s_out);
     }
+    // the handle is alive: its destroy call refuses while a pipe borrows it
+    if (p->f && p->f->piped > 0) p->f->piped--;
+    if (p->rs && static_cast<Rs *>(p->rs)->piped > 0) static_cast<Rs *>(p->rs)->piped--;
     pipe_free(p);
     return SFE_OK;
 }

@@ -68,7 +68,18 @@ struct FirFftArgs {
     long long   hs_stride; // 0: one spectrum for every channel; else channel c's spectra start c*hs_stride elements after hs (per-channel taps: held in registers like the shared one and reloaded, 16 loads per thread, when the workgroup's next transform belongs to another channel)
     unsigned    tqs;      // set by the launcher: a group draws runs of 2^tqs CONSECUTIVE transforms (their halos meet in its L2)
     unsigned    halo_keep; // set by the launcher: mask of input rows loaded WITHOUT the nontemporal hint (0x8001: the two rows a neighbour re-reads)
+    int         variant;  // how an aligned complex float32 stream's rows reach the transform (FIR_VAR_*); others ignore it
 };
+// Data-movement variants of the cf32 kernel (same arithmetic, bit-identical results):
+//   REG  tickets + guarded register loads (16 global_load_dwordx2 per thread)
+//   DMA  tickets + LDS-DMA requested early into the padded exchange layout, rows 0 / 15 kept in L2
+//   WP   DMA into a wave-private exchange layout (two workgroup barriers fewer per transform)
+// Which is fastest differs by a few percent between boxes of one pool (-5.7 % ... +3.7 % for DMA
+// against REG), so the handle measures them on its first large call per device and shape
+// (api.hip: fir_pick_variant) instead of compiling one in.
+enum { FIR_VAR_AUTO = -1, FIR_VAR_REG = 0, FIR_VAR_DMA = 1, FIR_VAR_WP = 2, FIR_VAR_COUNT = 3 };
+// true when the launch described by (a, flags) has more than one data-movement variant
+bool fir_fft_has_variants(const FirFftArgs &a, int in_complex, int out_complex, int in_u8, int out_tx10, int n_channels, int accumulate);
 constexpr int FIR_TICKET_GROUPS = 8;        // one per XCD under round-robin workgroup placement
 constexpr int FIR_TICKET_GROUPS_MAX = 64;
 // in_u8: the input stream is the device wire format, u8 offset binary (one byte per real sample,

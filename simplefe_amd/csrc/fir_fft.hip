@@ -321,7 +321,14 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         }
         if (base >= 0 && base + FFT_N <= a.n) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) x[r] = load_sample<IN_C, IN_U8>(in_c + (base + 256 * r) * ISZ, t);
+            for (int r = 0; r < 16; r++) {
+                // rows 0 and 15 are the ones a neighbouring transform reads too: without the nontemporal hint they
+                // may stay in the XCD's L2 for the neighbour drawn microseconds later (launcher: a.halo_keep)
+                if (IN_C && !IN_U8 && (r == 0 || r == 15) && ((a.halo_keep >> r) & 1u))
+                    x[r] = reinterpret_cast<const v2f *>(in_c + (base + 256 * r) * ISZ)[t];
+                else
+                    x[r] = load_sample<IN_C, IN_U8>(in_c + (base + 256 * r) * ISZ, t);
+            }
         } else {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -919,6 +926,13 @@ __global__ __launch_bounds__(256, WAVES) void fir_copy_pattern_dma2_kernel(FirFf
 
 }  // namespace
 
+bool fir_fft_has_variants(const FirFftArgs &a, int in_complex, int out_complex, int in_u8, int out_tx10, int n_channels, int accumulate)
+{
+    // LDS-DMA moves 16-byte lanes: every channel's first sample must sit on a 16-byte boundary
+    const bool dma_ok = (reinterpret_cast<uintptr_t>(a.in) & 15u) == 0 && (n_channels == 1 || (a.in_stride & 1) == 0);
+    return in_complex && out_complex && !in_u8 && !out_tx10 && !accumulate && dma_ok;
+}
+
 int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in_u8, int out_tx10, int n_channels,
                    hipStream_t s, int accumulate)
 {
@@ -946,6 +960,8 @@ int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in
     const bool pair = !in_complex && !out_complex;     // real stream, real taps: two segments per transform
     // LDS-DMA moves 16-byte lanes: every channel's first sample must sit on a 16-byte boundary
     const bool dma_ok = (reinterpret_cast<uintptr_t>(a.in) & 15u) == 0 && (n_channels == 1 || (a.in_stride & 1) == 0);
+    // data movement of an aligned cf32 stream: what the caller measured (api.hip: fir_pick_variant), else LDS-DMA
+    const int var = !dma_ok ? FIR_VAR_REG : (a.variant == FIR_VAR_REG || a.variant == FIR_VAR_WP ? a.variant : FIR_VAR_DMA);
 #ifdef SFE_DIAG
     // SFE_FIR_VARIANT = "<waves 2-4><p|n>[s][h]" | "c" | "d" | "e",  SFE_FIR_DIAG = bit 0 no loads, bit 1 no stores,
     // SFE_FIR_WG_PER_CU: read per launch so scripts/ab_fir.py can interleave variants in one process
@@ -1083,7 +1099,7 @@ int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in
         }
         //                         IN_C  OUT_C W  PREF   SWZ    HREG  IN_U8  PAIR   TX10   DMA    DG TICKET ACC   WP     HCH
         if (accumulate) SFE_K(true, true, 4, false, false, true, false, false, false, false, 0, true, true, false, true);
-        else if (dma_ok) SFE_K(true, true, 4, false, false, true, false, false, false, true, 0, true, false, false, true);
+        else if (var != FIR_VAR_REG) SFE_K(true, true, 4, false, false, true, false, false, false, true, 0, true, false, false, true);
         else SFE_K(true, true, 4, false, false, true, false, false, false, false, 0, true, false, false, true);
     } else if (accumulate) {           // partitions after the first: out += this partition's result
         if (in_complex) {
@@ -1099,7 +1115,8 @@ int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in
         if (in_u8 && out_tx10) SFE_K(true, true, 4, false, false, true, true, false, true);      // wire to wire
         else if (out_tx10) SFE_K(true, true, 4, false, false, true, false, false, true);
         else if (in_u8) SFE_K(true, true, 4, false, false, true, true);
-        else if (dma_ok) SFE_K(true, true, 4, false, false, true, false, false, false, true);      // LDS-DMA early request
+        else if (var == FIR_VAR_DMA) SFE_K(true, true, 4, false, false, true, false, false, false, true);      // LDS-DMA early request
+        else if (var == FIR_VAR_WP) SFE_K(true, true, 4, false, false, true, false, false, false, true, 0, true, false, true);      // ... into the wave-private layout
         else SFE_K(true, true, 4, false, false, true);
     } else if (out_complex) {
         SFE_K(false, true, 4, false, false, true);                                                // real data, complex taps

@@ -12,6 +12,8 @@ LIB_PATH = os.path.join(HERE, "libsfe_dsp.so")
 
 SFE_OK, SFE_EINVAL, SFE_ENOMEM, SFE_EHIP, SFE_ENODEV, SFE_ESTATE, SFE_ERANGE = 0, -1, -2, -3, -4, -5, -6
 FIR_ALGO_AUTO, FIR_ALGO_DIRECT, FIR_ALGO_FFT = 0, 1, 2
+FIR_VARIANT_AUTO, FIR_VARIANT_REGISTER_LOADS, FIR_VARIANT_LDS_DMA, FIR_VARIANT_WAVE_PRIVATE = -1, 0, 1, 2
+FIR_VARIANT_NAMES = {-1: "auto", 0: "register loads", 1: "LDS-DMA", 2: "LDS-DMA, wave-private layout"}
 RS_RESAMPLE, RS_DECIMATE = 0, 1
 RS_ALGO_AUTO, RS_ALGO_DIRECT, RS_ALGO_FFT, RS_ALGO_MFMA = 0, 1, 2, 3
 FMT_F32, FMT_U8, FMT_TX10 = 0, 1, 2
@@ -53,6 +55,9 @@ SIGNATURES = {
     "sfe_dsp_fir_process_host": (i32, [vp, vp, vp, sz]),
     "sfe_dsp_fir_set_algo": (i32, [vp, i32]),
     "sfe_dsp_fir_set_zero_copy_max": (i32, [vp, sz]),
+    "sfe_dsp_fir_set_variant": (i32, [vp, i32]),
+    "sfe_dsp_fir_get_variant": (i32, [vp, C.POINTER(i32), C.POINTER(i32), fp]),
+    "sfe_dsp_fir_forget_calibrations": (i32, []),
     "sfe_dsp_rs_set_algo": (i32, [vp, i32]),
     "sfe_dsp_fir_pipe_create": (i32, [vp, sz, C.POINTER(vp)]),
     "sfe_dsp_rs_pipe_create": (i32, [vp, sz, f32, C.POINTER(vp)]),

@@ -755,6 +755,41 @@ def test_fir_tx10_output_fused(api, L, orc):
         api.Fir(taps.astype(np.complex64), data_complex=False).set_output_format(L.FMT_TX10)
 
 
+@pytest.mark.parametrize("n_taps", [2818, 3000, 3841])
+def test_fir_tx10_for_a_filter_the_planner_would_partition(api, L, orc, n_taps):
+    """~2818..3841 taps are served fastest by two partitions (sfe_dsp_fir_plan), and the 10-bit
+    output exists for the single-launch kernel only.  Asking for TX10 re-plans such a handle as ONE
+    partition (one transform can still overlap the filter) instead of failing; beyond 3841 taps it fails."""
+    import ctypes as C
+    ovl, parts, adv = C.c_int(0), C.c_int(0), C.c_int(0)
+    api.check(L.load().sfe_dsp_fir_plan(n_taps, C.byref(ovl), C.byref(parts), C.byref(adv)))
+    assert parts.value == 2
+    taps = (synth.lowpass_taps(n_taps, 0.1) * 0.8).astype(np.float32)
+    n = 60000
+    x = (0.5 * synth.synth_f32(n, ch=4)).astype(np.float32)
+    yf = np.convolve(x.astype(np.float64), taps.astype(np.float64))[:n].astype(np.float32)
+    want = orc.tx_f32_to_10bit(yf)
+    f = api.Fir(taps, data_complex=False, algo=L.FIR_ALGO_FFT)
+    f.set_output_format(L.FMT_TX10)
+    d_in = api.DeviceArray.from_numpy(x)
+    d_out = api.DeviceArray(n // 4 * 5 // 4 + 8)
+    d_out.zero()
+    f.process_stream(d_in, d_out, n)
+    got = d_out.to_numpy().view(np.uint8)[: n // 4 * 5]
+    b5a, b5b = got.reshape(-1, 5).astype(np.int32), want.reshape(-1, 5).astype(np.int32)
+    va = np.stack([((b5a[:, 0] >> (2 * k)) & 3) << 8 | b5a[:, 1 + k] for k in range(4)], 1)
+    vb = np.stack([((b5b[:, 0] >> (2 * k)) & 3) << 8 | b5b[:, 1 + k] for k in range(4)], 1)
+    assert np.abs(va - vb).max() <= 1 and np.count_nonzero(va != vb) <= 0.004 * va.size
+    # and the float output of a re-planned handle still is the filter (switching back keeps the single plan)
+    f.set_output_format(L.FMT_F32)
+    f.reset()
+    d_f = api.DeviceArray(n)
+    f.process_stream(d_in, d_f, n)
+    assert synth.rel_rms(d_f.to_numpy(), yf) <= TOL
+    with pytest.raises(api.SfeError):
+        api.Fir((synth.lowpass_taps(4100, 0.1)).astype(np.float32), data_complex=False).set_output_format(L.FMT_TX10)
+
+
 @pytest.mark.parametrize("ctaps", [False, True])
 def test_fir_tx10_output_fused_complex(api, L, orc, ctaps):
     """Complex stream with the transmit converter fused into the store
@@ -947,6 +982,12 @@ def test_fir_pipe_takes_the_u8_wire_format(api, L, orc, cplx):
     lib = L.load()
     p = C.c_void_p()
     api.check(lib.sfe_dsp_fir_pipe_create(f._h, 1 << 16, C.byref(p)))
+    # the pipe froze the handle's item formats -- switching them (the pipe's device batches hold
+    # 1-2 bytes per item) or destroying the handle under the pipe is refused, not undefined
+    assert lib.sfe_dsp_fir_set_input_format(f._h, L.FMT_F32) == L.SFE_ESTATE
+    assert lib.sfe_dsp_fir_set_output_format(f._h, L.FMT_TX10) == L.SFE_ESTATE
+    assert lib.sfe_dsp_fir_set_input_format(f._h, L.FMT_U8) == L.SFE_OK            # unchanged format: fine
+    assert lib.sfe_dsp_fir_destroy(f._h) == L.SFE_ESTATE
     out = np.zeros(per * n, np.float32)
     taken, got = C.c_size_t(0), C.c_size_t(0)
     off = k = 0
@@ -965,6 +1006,7 @@ def test_fir_pipe_takes_the_u8_wire_format(api, L, orc, cplx):
             break
         k += got.value
     lib.sfe_dsp_pipe_destroy(p)
+    assert lib.sfe_dsp_fir_set_input_format(f._h, L.FMT_F32) == L.SFE_OK           # released with the pipe
     assert k == n
     # the bulk call on the same bytes, cut where the pipe cut its batches (the FFT kernel's results do not depend on the cut)
     g = api.Fir(taps, data_complex=cplx)
@@ -992,6 +1034,8 @@ def test_rs_pipe_takes_the_u8_wire_format(api, L, orc, g5):
     lib = L.load()
     p = C.c_void_p()
     api.check(lib.sfe_dsp_rs_pipe_create(r._h, 1 << 15, rate, C.byref(p)))
+    assert lib.sfe_dsp_rs_set_input_format(r._h, L.FMT_F32) == L.SFE_ESTATE        # frozen by the pipe
+    assert lib.sfe_dsp_rs_destroy(r._h) == L.SFE_ESTATE
     out = np.zeros(2 * (int(n / rate) + 4096), np.float32)
     taken, got = C.c_size_t(0), C.c_size_t(0)
     off = k = i = 0

@@ -1,0 +1,95 @@
+"""The three data-movement variants of the cf32 FIR kernel (register loads / LDS-DMA / LDS-DMA into a
+wave-private layout) compute the same bits, and a handle picks among them by measuring on the
+device at hand (the choice flips sign by box, so it is not compiled in)."""
+import numpy as np
+import pytest
+
+from simplefe_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    from simplefe_amd import api as a
+    return a
+
+
+@pytest.fixture(scope="module")
+def L():
+    from simplefe_amd import lib
+    return lib
+
+
+@pytest.mark.parametrize("n,nch", [(1 << 20, 1), (3840 * 7 + 17, 3), (100, 1), (1 << 16, 2)])
+def test_variants_are_bit_identical(api, L, n, nch):
+    taps = synth.taps_cfg2()
+    stride = n + (n & 1)                       # channels on 16-byte boundaries: the LDS-DMA variants' precondition
+    x = api.DeviceArray(2 * stride * nch)
+    x.zero()
+    for c in range(nch):
+        x.fill_synth(synth.SEED, channel=3 + c, n_floats=2 * n - (2 * n) % 4, offset=2 * stride * c)
+    outs = []
+    for var in (L.FIR_VARIANT_REGISTER_LOADS, L.FIR_VARIANT_LDS_DMA, L.FIR_VARIANT_WAVE_PRIVATE):
+        f = api.Fir(taps, data_complex=True, n_channels=nch, algo=L.FIR_ALGO_FFT)
+        f.set_variant(var)
+        y = api.DeviceArray(2 * stride * nch)
+        y.zero()
+        f.process_stream(x, y, n, in_stride=stride, out_stride=stride)
+        f.process_stream(x, y, n, in_stride=stride, out_stride=stride)          # second call: carried history
+        assert f.get_variant()[0] == var and f.get_variant()[1] == 0      # fixed: nothing was measured
+        outs.append(y.to_numpy())
+        f.close()
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+def test_first_large_call_measures_once_per_shape_and_the_process_remembers(api, L, orc):
+    LL = L.load()
+    LL.sfe_dsp_fir_forget_calibrations()
+    taps = synth.taps_cfg2()
+    n = 1 << 25                                   # 8739 transforms: above the threshold
+    x = api.DeviceArray(2 * n)
+    x.fill_synth(synth.SEED, channel=9)
+    y = api.DeviceArray(2 * n)
+    f = api.Fir(taps, data_complex=True)
+    assert f.get_variant()[0] == L.FIR_VARIANT_AUTO
+    f.process_stream(x, y, n)
+    v, cal, ms = f.get_variant()
+    assert cal == 1 and v in (0, 1, 2) and all(m > 0 for m in ms), (v, cal, ms)
+    assert ms[v] == min(ms)                       # the smallest median was taken
+    f.process_stream(x, y, n)                     # the same handle does not measure again
+    assert f.get_variant()[:2] == (v, 1)
+    # the measured call's output is the stream's output: windows against the oracle, and the next call continues it
+    W = 1 << 13
+    got = y.to_numpy(2 * W, offset=2 * (n - W))
+    xs = x.to_numpy(2 * (W + 255), offset=2 * (n - W - 255))
+    for part in (0, 1):
+        ref = orc.Blkconv(taps, 4096).stream(np.ascontiguousarray(xs[part::2]))[255:]
+        assert synth.rel_rms(got[part::2], ref) <= 1e-5
+    g = api.Fir(taps, data_complex=True)          # another handle, same device and shape: remembered
+    g.process_stream(x, y, n)
+    assert g.get_variant()[:2] == (v, 0)
+    h = api.Fir(taps, data_complex=True)          # a small call never measures and takes the default
+    h.process_stream(x, y, 1 << 16)
+    assert h.get_variant()[:2] == (L.FIR_VARIANT_LDS_DMA, 0)
+    LL.sfe_dsp_fir_forget_calibrations()
+    k = api.Fir(taps, data_complex=True)
+    k.process_stream(x, y, n)
+    assert k.get_variant()[1] == 1                # forgotten: measured again
+    # the measured first call equals a fixed-variant call bit for bit (same arithmetic in every variant)
+    y2 = api.DeviceArray(2 * n)
+    m = api.Fir(taps, data_complex=True)
+    m.set_variant(L.FIR_VARIANT_LDS_DMA)
+    m.process_stream(x, y2, n)
+    k2 = api.Fir(taps, data_complex=True)
+    LL.sfe_dsp_fir_forget_calibrations()
+    k2.process_stream(x, y, n)                    # measuring call, fresh state like m
+    assert k2.get_variant()[1] == 1
+    assert np.array_equal(y.to_numpy(1 << 20), y2.to_numpy(1 << 20))
+    assert np.array_equal(y.to_numpy(1 << 20, offset=2 * n - (1 << 20)), y2.to_numpy(1 << 20, offset=2 * n - (1 << 20)))
+
+
+def test_set_variant_rejects_garbage(api, L):
+    f = api.Fir(synth.taps_cfg2(), data_complex=True)
+    with pytest.raises(api.SfeError):
+        f.set_variant(7)

@@ -97,6 +97,36 @@ def test_product_library_reads_no_environment():
     assert "getenv" not in syms, [l for l in syms.splitlines() if "getenv" in l]
 
 
+def test_default_fir_kernels_use_no_scratch_and_keep_four_workgroups_per_cu():
+    """ADVICE r2 (counted vmcnt waits): what hipcc reported for the kernels of the built library
+    (simplefe_amd/build/*.resources.json, written by build.py from -Rpass-analysis=kernel-resource-usage).
+    The LDS-DMA kernels of the default path spill nothing; every product FIR and transform-domain
+    resampler kernel fits 128 VGPRs (4 workgroups per CU), and none spills more than 8 VGPRs."""
+    import json
+    from simplefe_amd import build as b
+    rj = os.path.join(ROOT, "simplefe_amd", "build", "fir_fft.hip.resources.json")
+    if not os.path.exists(rj):
+        pytest.skip("library was not built by simplefe_amd/build.py in this tree")
+    fir = json.load(open(rj))
+    seen_default = 0
+    for k, r in fir.items():
+        fl = b.fir_kernel_flags(k)
+        if not fl:
+            continue
+        assert r["VGPRs"] <= 128 and r["Occupancy"] >= 4, (k, r)
+        assert r["VGPRs Spill"] <= 8, (k, r)
+        if fl["DMA"] and not fl["WP"]:
+            seen_default += 1
+            assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0, (k, r)
+    assert seen_default >= 2          # shared filter and per-channel filters
+    pf = json.load(open(os.path.join(ROOT, "simplefe_amd", "build", "poly_fft.hip.resources.json")))
+    kernels = {k: r for k, r in pf.items() if "poly_fft256_kernel" in k}
+    assert len(kernels) >= 52
+    for k, r in kernels.items():
+        assert r["VGPRs"] <= 128 and r["Occupancy"] >= 4 and r["VGPRs Spill"] <= 2, (k, r)
+    assert kernels and all(r["ScratchSize"] == 0 for k, r in kernels.items() if "<5, 3, 2, false, false" in k)      # the headline shape
+
+
 # ------------------------------------------------------------------ time-law replay
 def _plan_stream(L, U, B, n_total, rate, out_len):
     from simplefe_amd import api, lib
