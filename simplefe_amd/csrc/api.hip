@@ -1633,6 +1633,7 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
     a.U = r->U;
     a.plen = r->plen;
     int rc;
+    bool hist_fused = false;
     if (int_step) {
         // closed form of the law: output k at pos0 + k*S, emitted while pos <= n_in*U - 2
         // (pos == n_in*U - 1 is the reference's "leftover": it comes out first next call).
@@ -1662,12 +1663,16 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         }
         const PolyTiledPlan *pl = (mp || fp) ? nullptr : get_tiled_plan(r->plans, r->h_taps_pm, r->U, r->plen, (int)S, pos0, &rc);
         if (rc != SFE_OK) return rc;
+        // the transform-domain and the tiled kernels write the next call's history themselves (one launch per call)
+        const bool can_fuse = n_in >= (size_t)r->hl && K > 0;
         if (fp) {
             PolyFftArgs fa;
             memset(&fa, 0, sizeof(fa));
             fa.in = d_in;
             fa.out = d_out;
             fa.hist = r->d_hist[r->cur];
+            fa.hist_out = can_fuse ? r->d_hist[r->cur ^ 1] : nullptr;
+            hist_fused = can_fuse;
             fa.H = fp->d_H;
             fa.tw = fp->d_tw;
             fa.n_in = (long long)n_in;
@@ -1702,6 +1707,8 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
             ta.in = d_in;
             ta.out = d_out;
             ta.hist = r->d_hist[r->cur];
+            ta.hist_out = can_fuse ? r->d_hist[r->cur ^ 1] : nullptr;
+            hist_fused = can_fuse;
             ta.G = pl->d_G;
             ta.n_in = (long long)n_in;
             ta.in_stride = (long long)in_stride;
@@ -1829,9 +1836,11 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         r->ts = st;
         *n_out = K;
     }
-    rc = launch_history_update(d_in, (long long)n_in, (long long)in_stride, r->d_hist[r->cur],
-                               r->d_hist[r->cur ^ 1], r->hl, r->data_complex ? 2 : 1, r->n_channels, s, r->in_u8);
-    if (rc != SFE_OK) return rc;
+    if (!hist_fused) {
+        rc = launch_history_update(d_in, (long long)n_in, (long long)in_stride, r->d_hist[r->cur],
+                                   r->d_hist[r->cur ^ 1], r->hl, r->data_complex ? 2 : 1, r->n_channels, s, r->in_u8);
+        if (rc != SFE_OK) return rc;
+    }
     r->cur ^= 1;
     return SFE_OK;
 }

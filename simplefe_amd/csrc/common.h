@@ -122,6 +122,7 @@ struct PolyTiledArgs {
     const void *in;
     void       *out;
     const void *hist;
+    void       *hist_out = nullptr;   // if non-null (needs n_in >= hl): tile 0's workgroup also writes the next call's history
     const float *G;
     long long   n_in, in_stride, out_stride, n_out;
     int         hl, Lp, e_max;
@@ -170,9 +171,12 @@ struct PolyFftArgs {
     const void *in;
     void       *out;
     const void *hist;
+    void       *hist_out;        // if non-null (needs n_in >= hl): the kernel also writes the NEXT call's history,
+                                 // in[n_in - hl .. n_in) as float32, saving the separate carry-over launch
     const float *H, *tw;
     long long   n_in, in_stride, out_stride, n_out;
-    long long   n_pass;          // set by the launcher: passes of R segments
+    long long   n_pass;          // set by the launcher: passes of R segments per channel
+    unsigned    total;           // set by the launcher (work counters): passes over all channels, channel-major tickets
     int         hl, e_max, ovl, V;
     unsigned   *ticket;          // [POLY_TICKET_GROUPS][32] work counters, zero between launches (null: fixed-stride walk)
     unsigned    tgroups;         // set by the launcher

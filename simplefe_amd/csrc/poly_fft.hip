@@ -87,7 +87,7 @@ __device__ __forceinline__ unsigned pf_cell(unsigned c, unsigned k)
 // DIAG (instantiated under -DSFE_DIAG only, scripts/ablate.py): bit 0 = input loads replaced by
 // constants, bit 1 = output stores folded into one never-taken store, bit 2 = no spectrum stage.
 // TICKET: passes are drawn from per-XCD work counters instead of walked at a fixed stride
-// (fir_fft.hip has the reasoning and the measurements); single-channel launches only.
+// (fir_fft.hip has the reasoning and the measurements), channel-major over all channels.
 // LATE (diagnostic): 1 = the next pass's samples are requested after S3 instead of before it,
 // 2 = the first half of its segments before S3 and the second half after.
 template <int SP, int UP, int R, bool IN_U8, bool PAIR, int DIAG = 0, bool TICKET = false, int LATE = 0, int WPS = 4>
@@ -99,7 +99,9 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
     __shared__ v2f lds[16 * PF_AREA + 96];     // 16 group areas + the six twiddle bases per lane
     __shared__ unsigned s_next;
     const unsigned t = threadIdx.x, l = t & 15u, g = t >> 4;
-    const int ch = blockIdx.y;
+    // TICKET: one grid dimension, passes of ALL channels drawn channel-major (ticket k = channel k / n_pass,
+    // pass k % n_pass); otherwise blockIdx.y is the workgroup's channel for good
+    int ch = TICKET ? 0 : blockIdx.y;          // channel of the pass being staged / transformed forward
     // Which transform a lane group runs.  Areas are indexed by JOB (forward job f = seg*SP + c' ->
     // area f, inverse job v = seg*UP + r -> area F + v).  With UP > 1 the UP inverse jobs of a
     // segment sit in ONE wave (the top UP groups of wave 3 - seg), so that a store instruction of
@@ -128,9 +130,9 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
 
     constexpr int ISZ = (IN_U8 ? 2 : 8) / (PAIR ? 2 : 1);    // bytes per input sample
     constexpr int ESZ = PAIR ? 4 : 8;                         // bytes per float32 sample (history, output)
-    const char *in_c = static_cast<const char *>(a.in) + (size_t)ch * a.in_stride * ISZ;
-    char *out_c = static_cast<char *>(a.out) + (size_t)ch * a.out_stride * ESZ;
-    const char *hist_c = static_cast<const char *>(a.hist) + (size_t)ch * a.hl * ESZ;
+    auto in_of = [&](int c) -> const char * { return static_cast<const char *>(a.in) + (size_t)c * a.in_stride * ISZ; };
+    auto out_of = [&](int c) -> char * { return static_cast<char *>(a.out) + (size_t)c * a.out_stride * ESZ; };
+    auto hist_of = [&](int c) -> const char * { return static_cast<const char *>(a.hist) + (size_t)c * a.hl * ESZ; };
 
     const v2f *tw = reinterpret_cast<const v2f *>(a.tw);
     // the six twiddle bases per lane W_256^(l k), W_256^(4 l k) sit in LDS and are re-read every
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
         }
     };
     // sample idx of the virtual stream history ++ input ++ zeros (edge segments only)
-    auto load_guarded = [&](long long idx) -> v2f {
+    auto load_guarded = [&](const char *in_c, const char *hist_c, long long idx) -> v2f {
         if (idx >= 0) return idx < a.n_in ? load_in(in_c + idx * ISZ, 0u) : (v2f){0.0f, 0.0f};
         if (idx + a.hl < 0) return (v2f){0.0f, 0.0f};
         if constexpr (PAIR) return (v2f){reinterpret_cast<const float *>(hist_c)[idx + a.hl], 0.0f};
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
     };
     // the R*SP*256 staged samples of a pass, thread t: sample t + 256 i of each segment.  PAIR:
     // transform (pass*R + sg) carries real segments 2*(pass*R + sg) in .x and the next one in .y.
-    auto load_pass = [&](v2f (&s)[R * SP], long long pass, int sg_lo = 0, int sg_hi = R) {
+    auto load_pass = [&](v2f (&s)[R * SP], const char *in_c, long long pass, int sg_lo = 0, int sg_hi = R) {
         if constexpr (DIAG & 1) {       // ablation: no input loads
             unsigned u = t + ((unsigned)pass << 12);
             asm volatile("" : "+v"(u));
@@ -204,7 +206,8 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
         return s0 >= 0 && s1 + span <= a.n_in;
     };
     // an edge pass (history in front, ragged end): every staged sample guarded, one at a time, into its cell
-    auto stage_edge_pass = [&](long long pass, auto cell_of) {
+    auto stage_edge_pass = [&](int c, long long pass, auto cell_of) {
+        const char *in_c = in_of(c), *hist_c = hist_of(c);
 #pragma unroll 1
         for (int sg = 0; sg < R; sg++) {
             const long long sidx = (pass * R + sg) * (PAIR ? 2 : 1);
@@ -213,8 +216,8 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
             for (int i = 0; i < SP; i++) {
                 const unsigned j = t + 256u * i;
                 const long long idx = start + (long long)j;
-                v2f v = load_guarded(idx);
-                if constexpr (PAIR) v.y = load_guarded(idx + (long long)a.V * SP).x;
+                v2f v = load_guarded(in_c, hist_c, idx);
+                if constexpr (PAIR) v.y = load_guarded(in_c, hist_c, idx + (long long)a.V * SP).x;
                 lds[(sg * SP + j % SP) * PF_AREA + cell_of(j % SP, j / SP)] = v;
             }
         }
@@ -228,16 +231,15 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     constexpr int NCHUNK = 32 * SP + 1;                       // 16-byte chunks covering 256*SP samples at any phase
     constexpr bool WIDE = IN_U8 && !PAIR && NCHUNK <= 256;
-    const bool base16 = (reinterpret_cast<uintptr_t>(in_c) & 15u) == 0;
     auto seg_start = [&](long long pass, int sg) -> long long {
         return ((pass * R + sg) * a.V - a.ovl) * SP + a.e_max - (SP - 1);
     };
-    auto pass_is_wide = [&](long long pass) -> bool {
-        if (!WIDE || !base16) return false;
+    auto pass_is_wide = [&](int c, long long pass) -> bool {
+        if (!WIDE || (reinterpret_cast<uintptr_t>(in_of(c)) & 15u) != 0) return false;
         const long long a0 = seg_start(pass, 0) & ~7LL, a1 = seg_start(pass, R - 1) & ~7LL;
         return a0 >= 0 && a1 + 8LL * NCHUNK <= a.n_in;
     };
-    auto load_pass_wide = [&](v4u (&raw)[R], long long pass) {
+    auto load_pass_wide = [&](v4u (&raw)[R], const char *in_c, long long pass) {
 #pragma unroll
         for (int sg = 0; sg < R; sg++) {
             const long long a0 = seg_start(pass, sg) & ~7LL;
@@ -248,7 +250,8 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
     // work counters: group g = blockIdx.x % tgroups draws the passes g, g + tgroups, ... from its own
     // counter (128 bytes apart); the launch's last draw of a group zeroes it for the next launch
     const unsigned tg = a.tgroups, grp = TICKET ? blockIdx.x % tg : 0u;
-    const unsigned np32 = (unsigned)a.n_pass;
+    const unsigned npc32 = (unsigned)a.n_pass;                            // passes per channel
+    const unsigned np32 = TICKET ? a.total : npc32;                       // tickets in the launch: all channels' passes
     // (runs of Q = 2^tqs consecutive passes per counter, as fir_fft.hip: neighbours' overlaps meet in one XCD's L2)
     const unsigned Q = 1u << a.tqs, row = tg << a.tqs, rem = TICKET ? np32 % row : 0u;
     const unsigned mine = TICKET ? (np32 / row << a.tqs) + (rem > grp * Q ? (rem - grp * Q < Q ? rem - grp * Q : Q) : 0u) : 0u;
@@ -264,15 +267,37 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
         return k < np32 ? (unsigned)k : 0xFFFFFFFFu;
     };
     auto draw = [&]() -> unsigned { return draw_finish(draw_issue()); };
+    // ticket -> (channel, pass of that channel); "no ticket" -> pass = n_pass
+    auto decode = [&](unsigned k, int &c, long long &p) {
+        if (k == 0xFFFFFFFFu) {
+            p = a.n_pass;
+        } else {
+            const unsigned cc = k / npc32;
+            c = (int)cc;
+            p = (long long)(k - cc * npc32);
+        }
+    };
     long long first = blockIdx.x;
     if constexpr (TICKET) {
         if (t == 0) s_next = draw();
         lds_barrier();
-        const unsigned k = __builtin_amdgcn_readfirstlane(s_next);
-        first = k == 0xFFFFFFFFu ? a.n_pass : (long long)k;
+        decode(__builtin_amdgcn_readfirstlane(s_next), ch, first);
         lds_barrier();
     }
+    // state carry-over fused in: the workgroup that takes a channel's pass 0 also writes the
+    // NEXT call's history, in[n_in - hl .. n_in) as float32 -- one launch per call instead of two
+    auto carry_history = [&](int c) {
+        const char *src = in_of(c) + (a.n_in - a.hl) * ISZ;
+        char *ho = static_cast<char *>(a.hist_out) + (size_t)c * a.hl * ESZ;
+#pragma unroll 1
+        for (unsigned i = t; i < (unsigned)a.hl; i += 256u) {
+            const v2f smp = load_in(src, i);
+            if constexpr (PAIR) reinterpret_cast<float *>(ho)[i] = smp.x;
+            else reinterpret_cast<v2f *>(ho)[i] = smp;
+        }
+    };
     long long prev = -1;       // pass whose inverse transforms run in this iteration
+    int pch = ch;              // ... and its channel
     v2f s[R * SP];
     v4u raw[R];
     // passes are dealt so that at any moment the resident workgroups read one compact window of the
@@ -283,11 +308,11 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
     bool cur_wide = false;      // this pass's samples were requested ahead: as wide raw lanes (WIDE) ...
     bool cur_fast = false;      // ... or as per-sample registers s[] (interior pass of a non-WIDE kernel)
     if (first < a.n_pass) {
-        cur_wide = pass_is_wide(first);
-        if (cur_wide) load_pass_wide(raw, first);
+        cur_wide = pass_is_wide(ch, first);
+        if (cur_wide) load_pass_wide(raw, in_of(ch), first);
         else if (!WIDE) {
             cur_fast = pass_interior(first);
-            if (cur_fast) load_pass(s, first);
+            if (cur_fast) load_pass(s, in_of(ch), first);
         }
     }
     for (long long pass = first;;) {
@@ -314,7 +339,7 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
             }
         } else if (cur && !cur_fast) {
             // an edge pass: nothing was requested ahead
-            stage_edge_pass(pass, [](unsigned c, unsigned k) { return pf_cell<SP, ROT>(c, k); });
+            stage_edge_pass(ch, pass, [](unsigned c, unsigned k) { return pf_cell<SP, ROT>(c, k); });
         } else if (cur) {
             unsigned tt = t;
             asm volatile("" : "+v"(tt));      // recompute the scatter cells here instead of keeping R*SP of them live
@@ -394,6 +419,7 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
             // ovu <= x < lim as ONE unsigned compare per store: (x - ovu) < (lim - ovu)
             const unsigned span = lim > ovu ? (unsigned)(lim - ovu) : 0u;
             const unsigned xb = (unsigned)(nu - ovu);
+            char *const out_c = out_of(pch);
             char *op = out_c + (ko0 + nu) * ESZ;
             if constexpr (PAIR) {
                 // .x belongs to real segment 2*sigma, .y to segment 2*sigma + 1, V*UP outputs further on
@@ -426,20 +452,20 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
         }
         lds_barrier();
         long long next = pass + gridDim.x;
-        if constexpr (TICKET) {
-            const unsigned k = __builtin_amdgcn_readfirstlane(s_next);
-            next = k == 0xFFFFFFFFu ? a.n_pass : (long long)k;
-        }
+        int nch = ch;
+        if constexpr (TICKET) decode(__builtin_amdgcn_readfirstlane(s_next), nch, next);
+        // v[] is dead and the next pass's samples are not requested yet: the point of least register pressure
+        if (a.hist_out && cur && pass == 0) carry_history(ch);
         // request the next pass's samples now: v[] is dead, they land while S3 and the barrier run
         // (requesting them a whole pass ahead instead measured the same: latency is not what binds)
         auto request_next = [&](int sg_lo, int sg_hi) {
             if (next < a.n_pass) {
-                cur_wide = pass_is_wide(next);
+                cur_wide = pass_is_wide(nch, next);
                 if (cur_wide) {
-                    if (sg_lo == 0) load_pass_wide(raw, next);
+                    if (sg_lo == 0) load_pass_wide(raw, in_of(nch), next);
                 } else if (!WIDE) {
                     cur_fast = pass_interior(next);
-                    if (cur_fast) load_pass(s, next, sg_lo, sg_hi);
+                    if (cur_fast) load_pass(s, in_of(nch), next, sg_lo, sg_hi);
                 }
             } else {
                 cur_wide = cur_fast = false;
@@ -466,7 +492,9 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
         if (LATE == 1) request_next(0, R);
         if (LATE == 2) request_next((R + 1) / 2, R);
         prev = cur ? pass : -1;
+        pch = ch;
         pass = next;
+        ch = nch;
     }
 }
 
@@ -492,11 +520,13 @@ int launch_one(const PolyFftArgs &a0, int n_channels, hipStream_t s)
 #ifdef SFE_DIAG
     if (const char *e = getenv("SFE_RS_WG_FACTOR")) factor = atoi(e) > 0 ? atoi(e) : factor;
 #endif
-    long long cap = (factor * resident + n_channels - 1) / n_channels;
+    long long cap = TICKET ? factor * resident : (factor * resident + n_channels - 1) / n_channels;
     if (cap < 1) cap = 1;
-    dim3 grid((unsigned)(a.n_pass < cap ? a.n_pass : cap), (unsigned)n_channels);
+    const long long total = a.n_pass * (TICKET ? n_channels : 1);
+    dim3 grid((unsigned)(total < cap ? total : cap), TICKET ? 1u : (unsigned)n_channels);
     if (TICKET) {
-        if (n_channels != 1 || !a.ticket || a.n_pass + grid.x >= 0xFFFFFFFFLL) return SFE_ESTATE;
+        if (!a.ticket || total + grid.x >= 0xFFFFFFFFLL) return SFE_ESTATE;
+        a.total = (unsigned)total;
         a.tgroups = POLY_TICKET_GROUPS < grid.x ? POLY_TICKET_GROUPS : grid.x;
         a.tqs = 3;            // `t` against `t^3!1` (scripts/ab_rs.py): -0.6 % time, the overlap re-read leaves HBM
         a.halo_keep = 1;
@@ -567,7 +597,8 @@ int launch_poly_fft(const PolyFftPlan &plan, const PolyFftArgs &a0, int data_com
         }
     }
 #endif
-    const bool tk = n_channels == 1 && a.ticket != nullptr;
+    // work counters whenever the passes of all channels fit the 32-bit ticket (else the fixed-stride walk per channel)
+    const bool tk = a.ticket != nullptr && a.n_pass * (long long)n_channels < 0xFFF00000LL;
 #define SFE_PF1(sp, up, r, U8, PR) (tk ? launch_one<sp, up, r, U8, PR, 0, true>(a, n_channels, s) : launch_one<sp, up, r, U8, PR>(a, n_channels, s))
 #define SFE_PF(sp, up, r)                                                                         \
     if (plan.SP == sp && plan.UP == up)                                                           \

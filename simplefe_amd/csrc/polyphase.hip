@@ -161,6 +161,15 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
     const T *hist = static_cast<const T *>(a.hist) + (size_t)ch * a.hl;
     T *out = static_cast<T *>(a.out) + (size_t)ch * a.out_stride;
 
+    // state carry-over fused in: the workgroup of a channel's tile 0 also writes the NEXT call's
+    // history, in[n_in - hl .. n_in) as float32 (the launcher passes hist_out only when n_in >= hl)
+    if (a.hist_out && blockIdx.x == 0) {
+        T *ho = static_cast<T *>(a.hist_out) + (size_t)ch * a.hl;
+        for (unsigned i = tid; i < (unsigned)a.hl; i += 256u) {
+            if constexpr (IN_U8) ho[i] = vload_u8<CPLX>(in8, hist, a.n_in - a.hl + i, a.n_in, a.hl);
+            else ho[i] = in[a.n_in - a.hl + i];
+        }
+    }
     const long long m0 = (long long)blockIdx.x * TM;
     const long long n_org = (long long)SP * m0 + a.e_max - (a.Lp - 1);   // stream index of local sample 0
     const int n_tile = SP * TM + a.Lp;
