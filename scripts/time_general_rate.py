@@ -13,7 +13,9 @@ y = api.DeviceArray(2 * cap)
 r = api.Rs(taps, 4, 4096, mode=lib.RS_RESAMPLE, data_complex=True)
 for rate in (1.77, 2.0):
     r.reset()
+    t0 = time.perf_counter()
     r.process_stream(x, n, y, cap, rate); api.sync()
+    print(f"rate {rate}: first call (builds the plan memo) {(time.perf_counter() - t0) * 1e3:.2f} ms")
     t0 = time.perf_counter()
     for _ in range(3):
         k = r.process_stream(x, n, y, cap, rate)

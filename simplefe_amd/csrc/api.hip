@@ -768,6 +768,21 @@ struct Rs {
     float *h_mu = nullptr;
     void *d_segs = nullptr, *d_chunks = nullptr, *h_segs = nullptr, *h_chunks = nullptr;   // run-length plans
     size_t segs_cap = 0, chunks_cap = 0;
+    // General rate: the plan of one blksize-sample reference call depends only on the time state the call
+    // starts in, and that state is a multiple of the float32 grid of the call's LAST binade inside
+    // [-1, step) -- a few thousand possible values (blksize*U = 16384: 2^-10 apart) -- so plans are
+    // memoised per start state: a 2^28-sample call replays 65 536 reference calls as table look-ups
+    // instead of 65 536 x ~40 runs of float arithmetic (36 ms -> ~2 ms on the host), and the run table
+    // lives on the device across calls (only what is new is uploaded).
+    struct SegPlanRef {
+        int seg_first, n_seg, n_out;
+        sfe_rs_timestate after;
+    };
+    std::unordered_map<uint64_t, SegPlanRef> seg_memo;
+    std::vector<TlSeg> seg_table;          // runs of the memoised calls, in the order they were first met
+    size_t seg_uploaded = 0;               // leading entries of seg_table already in d_segs
+    float memo_rate = 0.0f;                // the memo is for one (rate, blksize)
+    int memo_m = 0;
     hipStream_t stream = nullptr;
     int esz() const { return data_complex ? 8 : 4; }
 };
@@ -1738,9 +1753,19 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         }
         // Replay the float32 recurrence call by call (blksize samples each), as the reference
         // object would see the stream -- in closed form: each call becomes a few constant-increment
-        // runs (timelaw.h) that one workgroup expands on the GPU.
+        // runs (timelaw.h) that one workgroup expands on the GPU.  A call's runs are a function of
+        // the state it starts in; full-size calls are memoised per start state (Rs::seg_memo).
         sfe_rs_timestate st = r->ts;
-        std::vector<TlSeg> segs;
+        if (r->memo_rate != rate || r->memo_m != r->blksize) {
+            r->seg_memo.clear();
+            r->seg_table.clear();
+            r->seg_uploaded = 0;
+            r->memo_rate = rate;
+            r->memo_m = r->blksize;
+        }
+        constexpr size_t MEMO_MAX_SEGS = (size_t)2 << 20;       // 64 MiB of runs: beyond, calls are planned without the memo
+        std::vector<TlSeg> extra;                               // runs of calls that are not memoised (the ragged last one)
+        std::vector<size_t> extra_chunks;
         std::vector<SegChunk> chunks;
         chunks.reserve(n_in / (size_t)r->blksize + 1);
         size_t K = 0;
@@ -1752,13 +1777,37 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
             c.in_off = (long long)off;
             c.k_first = (long long)K;
             c.m = m;
-            c.seg_first = (int)segs.size();
-            c.n_out = time_law_segments(&st, r->U, m, cap, rate, segs);
-            c.n_seg = (int)segs.size() - c.seg_first;
+            if (m == r->blksize && r->seg_table.size() < MEMO_MAX_SEGS) {
+                uint32_t mu_bits;
+                memcpy(&mu_bits, &st.mu, 4);
+                const uint64_t key = ((uint64_t)(uint32_t)(st.pos + 1) << 33) | ((uint64_t)mu_bits << 1) | (uint64_t)(st.leftover ? 1 : 0);   // pos >= -1
+                auto it = r->seg_memo.find(key);
+                if (it == r->seg_memo.end()) {
+                    Rs::SegPlanRef ref;
+                    ref.seg_first = (int)r->seg_table.size();
+                    ref.n_out = time_law_segments(&st, r->U, m, cap, rate, r->seg_table);
+                    ref.n_seg = (int)r->seg_table.size() - ref.seg_first;
+                    ref.after = st;
+                    it = r->seg_memo.emplace(key, ref).first;
+                } else {
+                    st = it->second.after;
+                }
+                c.seg_first = it->second.seg_first;
+                c.n_seg = it->second.n_seg;
+                c.n_out = it->second.n_out;
+            } else {
+                c.seg_first = (int)extra.size();                 // + the table's final size, below
+                c.n_out = time_law_segments(&st, r->U, m, cap, rate, extra);
+                c.n_seg = (int)extra.size() - c.seg_first;
+                extra_chunks.push_back(chunks.size());
+            }
             chunks.push_back(c);
             K += (size_t)c.n_out;
             max_m = m > max_m ? m : max_m;
         }
+        const size_t n_table = r->seg_table.size(), n_segs = n_table + extra.size();
+        for (size_t ci : extra_chunks) chunks[ci].seg_first += (int)n_table;
+        auto seg_at = [&](size_t i) -> const TlSeg & { return i < n_table ? r->seg_table[i] : extra[i - n_table]; };
         if (K > out_cap) {
             set_error("rs_process_stream: need room for %zu outputs, got %zu", K, out_cap);
             return SFE_ERANGE;
@@ -1777,15 +1826,16 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         sa.plen = r->plen;
         sa.n_chunks = (int)chunks.size();
         sa.max_m = max_m;
-        // plan tables: grow-only device + pinned staging; the previous call's kernel may still
-        // be reading them, so wait for the stream before overwriting
+        // plan tables: grow-only device + pinned staging; the previous call's copies may still be
+        // reading the staging, so wait for the stream before overwriting it
         SFE_HIP(hipStreamSynchronize(s));
-        if (segs.size() > r->segs_cap) {
+        if (n_segs > r->segs_cap) {
             if (r->d_segs) (void)hipFree(r->d_segs);
             if (r->h_segs) (void)hipHostFree(r->h_segs);
             r->d_segs = r->h_segs = nullptr;
             r->segs_cap = 0;
-            const size_t cap2 = segs.size() * 2 + 1024;
+            r->seg_uploaded = 0;
+            const size_t cap2 = n_segs * 2 + 1024;
             SFE_HIP(hipMalloc(&r->d_segs, cap2 * sizeof(TlSeg)));
             SFE_HIP(hipHostMalloc(&r->h_segs, cap2 * sizeof(TlSeg)));
             r->segs_cap = cap2;
@@ -1800,9 +1850,18 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
             SFE_HIP(hipHostMalloc(&r->h_chunks, cap2 * sizeof(SegChunk)));
             r->chunks_cap = cap2;
         }
-        memcpy(r->h_segs, segs.data(), segs.size() * sizeof(TlSeg));
+        // upload what the device does not hold yet: the table's new tail, then this call's own runs behind it
+        {
+            TlSeg *hs = static_cast<TlSeg *>(r->h_segs);
+            const size_t from = r->seg_uploaded < n_table ? r->seg_uploaded : n_table;
+            if (n_table > from) memcpy(hs + from, r->seg_table.data() + from, (n_table - from) * sizeof(TlSeg));
+            if (!extra.empty()) memcpy(hs + n_table, extra.data(), extra.size() * sizeof(TlSeg));
+            if (n_segs > from)
+                SFE_HIP(hipMemcpyAsync(static_cast<TlSeg *>(r->d_segs) + from, hs + from, (n_segs - from) * sizeof(TlSeg),
+                                       hipMemcpyHostToDevice, s));
+            r->seg_uploaded = n_table;
+        }
         memcpy(r->h_chunks, chunks.data(), chunks.size() * sizeof(SegChunk));
-        SFE_HIP(hipMemcpyAsync(r->d_segs, r->h_segs, segs.size() * sizeof(TlSeg), hipMemcpyHostToDevice, s));
         SFE_HIP(hipMemcpyAsync(r->d_chunks, r->h_chunks, chunks.size() * sizeof(SegChunk), hipMemcpyHostToDevice, s));
         sa.segs = r->d_segs;
         sa.chunks = static_cast<const SegChunk *>(r->d_chunks);
@@ -1814,7 +1873,7 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
             std::vector<float> mu(K);
             for (const SegChunk &c : chunks)
                 for (int i = 0; i < c.n_seg; i++) {
-                    const TlSeg &g = segs[(size_t)c.seg_first + i];
+                    const TlSeg &g = seg_at((size_t)c.seg_first + i);
                     for (int q = 0; q < g.count; q++) {
                         const double t = g.t0 + (double)q * (double)g.d, fl = floor(t);
                         pos[(size_t)c.k_first + g.k0 + q] = c.in_off * r->U + (long long)fl;

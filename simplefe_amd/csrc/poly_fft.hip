@@ -349,6 +349,12 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
             constexpr unsigned INV = SP == 3 ? 11u : SP == 5 ? 13u : SP == 7 ? 7u : 1u;      // SP^-1 mod 16
             constexpr bool LOW_FIXED = ROT && (SP == 1 || SP == 2 || SP == 3 || SP == 4 || SP == 5 || SP == 7 || SP == 8);
             const unsigned low = (SP & 1) ? (INV * tt) & 15u : pf_cell<SP, ROT>(tt % SP, tt / SP) & 15u;
+            if constexpr (DIAG & 32) {      // ablation: the staged samples never reach LDS (bounds what taking S0 off the ds_write path can give)
+                v2f sink = s[0];
+#pragma unroll
+                for (int i = 1; i < R * SP; i++) sink += s[i];
+                if (sink.x == 1.2345e38f) lds[tt] = sink;
+            } else {
 #pragma unroll
             for (int sg = 0; sg < R; sg++)
 #pragma unroll
@@ -357,6 +363,7 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
                     const unsigned cell = LOW_FIXED ? ((k & ~15u) | low) : pf_cell<SP, ROT>(c, k);
                     lds[(sg * SP + c) * PF_AREA + cell] = s[sg * SP + i];
                 }
+            }
         }
         lds_barrier();
         unsigned drawn = 0u;
@@ -594,6 +601,9 @@ int launch_poly_fft(const PolyFftPlan &plan, const PolyFftArgs &a0, int data_com
             if (e[0] == 'h') return launch_one<5, 3, 2, false, false, 0, true, 2>(a, n_channels, s);         // half before S3, half after
             if (e[0] == 'e') return launch_one<5, 3, 2, false, false, 16, true, 0>(a, n_channels, s);        // t without the in-wave exchange (upper bound for doing it off the LDS)
             if (e[0] == 'w') return launch_one<5, 3, 2, false, false, 0, true, 0, 3>(a, n_channels, s);     // 3 workgroups per CU, 168 VGPRs: no spill
+            if (e[0] == 'z') return launch_one<5, 3, 2, false, false, 32, true, 0>(a, n_channels, s);        // t without the S0 scatter writes (bound for LDS-DMA staging)
+            if (e[0] == 'Z') return launch_one<5, 3, 2, false, false, 48, true, 0>(a, n_channels, s);        // neither the scatter nor the exchange
+            if (e[0] == 'y') return launch_one<5, 3, 2, false, false, 32, true, 0, 3>(a, n_channels, s);     // z at 3 workgroups per CU
         }
     }
 #endif
