@@ -539,6 +539,24 @@ static bool fir_choose_partition(int n_taps, int *ovl, int *parts)
     return *parts > 0;
 }
 
+// A stream that is being captured into a hipGraph: the launches recorded now will be REPLAYED with the same
+// arguments, so nothing of the stream's carried state may live on the host between a captured call and its
+// replays.  A captured bulk call therefore (a) updates the history IN PLACE with the separate carry-over
+// kernel behind the main launch (no double-buffer parity to flip on the host) and (b) is accepted only when
+// its arguments do not depend on where in the stream it sits: n >= the history length, and for the
+// resamplers an integer-valued step with n*U a multiple of it, so that every call starts in the time state
+// the captured one started in.  Replaying the graph then processes the NEXT n samples found in d_in, exactly
+// as the next eager call would (tests/test_gpu_graph.py).  VERDICT r2 item 8.
+static bool stream_is_capturing(hipStream_t s)
+{
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return cap != hipStreamCaptureStatusNone;
+}
+
 // ---- which data-movement variant of the cf32 kernel (common.h: FIR_VAR_*) ------------------------
 // The three variants compute the same bits and differ by a few percent in time, with a sign that
 // depends on the box (profiles/r02/fir_walk_vs_tickets.txt against DESIGN.md 4.1's earlier tables:
@@ -648,6 +666,12 @@ static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_st
     if (algo == SFE_FIR_ALGO_AUTO) algo = f->fft_ok ? SFE_FIR_ALGO_FFT : SFE_FIR_ALGO_DIRECT;
     int rc;
     bool hist_fused = false;
+    const bool capturing = stream_is_capturing(s);
+    if (capturing && n < (size_t)f->hl) {
+        set_error("fir_process_stream: a call captured into a hipGraph must bring at least the history length (%d samples): "
+                  "shorter calls carry state the replay cannot see", f->hl);
+        return SFE_ESTATE;
+    }
     if (algo == SFE_FIR_ALGO_FFT) {
         if (!f->fft_ok) {
             set_error("fir: %d taps exceed %d partitions of the 4096-point kernel", f->n_taps, FIR_MAX_PARTS);
@@ -657,7 +681,7 @@ static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_st
         a.in = d_in;
         a.out = d_out;
         a.hist = f->d_hist[f->cur];
-        hist_fused = n >= (size_t)f->hl;                 // else the old history still contributes
+        hist_fused = n >= (size_t)f->hl && !capturing;   // else the old history still contributes (captured: in place, below)
         a.tw1 = f->d_tw1;
         a.tw2 = f->d_tw2;
         a.n = (long long)n;
@@ -730,6 +754,11 @@ static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_st
         }
     }
     if (rc != SFE_OK) return rc;
+    if (capturing) {
+        // in place, behind everything that read the old history: with n >= hl the kernel reads `in` only
+        return launch_history_update(d_in, (long long)n, (long long)in_stride, f->d_hist[f->cur],
+                                     f->d_hist[f->cur], f->hl, f->data_complex ? 2 : 1, f->n_channels, s, f->in_u8);
+    }
     if (!hist_fused) {
         rc = launch_history_update(d_in, (long long)n, (long long)in_stride, f->d_hist[f->cur],
                                    f->d_hist[f->cur ^ 1], f->hl, f->data_complex ? 2 : 1, f->n_channels, s, f->in_u8);
@@ -1635,6 +1664,12 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
     const float stepf = rate * (float)r->U;
     const bool int_step = stepf >= 1.0f && stepf == floorf(stepf) && stepf < 1.0e6f && r->ts.mu == 0.0f &&
                           ((double)r->blksize * r->U + stepf) < 16777216.0;
+    const bool capturing = stream_is_capturing(s);
+    if (capturing && (!int_step || n_in < (size_t)r->hl || ((unsigned long long)n_in * (unsigned long long)r->U) % (unsigned long long)stepf != 0)) {
+        set_error("rs_process_stream: a call captured into a hipGraph must leave the time state where it found it "
+                  "(integer-valued step, n_in*upsample a multiple of it) and bring at least %d samples", r->hl);
+        return SFE_ESTATE;
+    }
     PolyArgs a;
     memset(&a, 0, sizeof(a));
     a.in = d_in;
@@ -1679,7 +1714,7 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         const PolyTiledPlan *pl = (mp || fp) ? nullptr : get_tiled_plan(r->plans, r->h_taps_pm, r->U, r->plen, (int)S, pos0, &rc);
         if (rc != SFE_OK) return rc;
         // the transform-domain and the tiled kernels write the next call's history themselves (one launch per call)
-        const bool can_fuse = n_in >= (size_t)r->hl && K > 0;
+        const bool can_fuse = n_in >= (size_t)r->hl && K > 0 && !capturing;
         if (fp) {
             PolyFftArgs fa;
             memset(&fa, 0, sizeof(fa));
@@ -1895,6 +1930,9 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         r->ts = st;
         *n_out = K;
     }
+    if (capturing)          // in place behind the main launch: with n_in >= hl the kernel reads `in` only; the time state did not move
+        return launch_history_update(d_in, (long long)n_in, (long long)in_stride, r->d_hist[r->cur],
+                                     r->d_hist[r->cur], r->hl, r->data_complex ? 2 : 1, r->n_channels, s, r->in_u8);
     if (!hist_fused) {
         rc = launch_history_update(d_in, (long long)n_in, (long long)in_stride, r->d_hist[r->cur],
                                    r->d_hist[r->cur ^ 1], r->hl, r->data_complex ? 2 : 1, r->n_channels, s, r->in_u8);
