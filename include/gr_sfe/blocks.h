@@ -11,8 +11,14 @@
 // All of them batch: the scheduler's few-thousand-item calls are collected into GPU-sized pinned
 // batches and up to four batches are in flight on three streams (sfe_dsp_fir_pipe_* /
 // sfe_dsp_rs_pipe_*), so a call costs a memcpy, not a launch + two PCIe round trips.  They are
-// gr::block's (general_work): the output stream is exactly the reference classes', but an item may
-// come out a few calls after the inputs it depends on went in.
+// gr::block's (general_work): an item may come out a few calls after the inputs it depends on went in.
+// What the stream equals: the reference class fed the same samples in calls of the batch's size.  For
+// the FIR blocks and for integer-valued resampling steps (decimate_xxf, rational_resampler_xxf at any
+// interp/decim: the step is `decim`) that does not depend on where the calls are cut -- bit for bit
+// the reference whatever the scheduler does.  A source SLOWER than the block starves the pipe: the
+// scheduler then calls with no input, the partly filled batch is sent on its way (whole blksize
+// multiples first, sfe_dsp.h), and batching degenerates towards one round trip per call -- correct,
+// but no faster than the _sync blocks; size batch_items to the source's rate.
 // fir_ccf_sync / fir_fff_sync keep the one-round-trip-per-call sync_block form.
 #ifndef GR_SFE_BLOCKS_H_
 #define GR_SFE_BLOCKS_H_

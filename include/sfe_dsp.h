@@ -185,7 +185,12 @@ int sfe_dsp_fir_pipe_create(sfe_fir_t fir, size_t batch_items, sfe_pipe_t *out);
  * items, pull hands out the outputs of finished batches -- as many as the reference object would
  * have produced for those inputs.  batch_items is rounded up to whole `blksize`-sample reference
  * calls, so the result is the bulk call's (sfe_dsp_rs_process_stream, incl. sfe_dsp_rs_set_exact)
- * for any rate.  Declared after sfe_rs_t below. */
+ * for any rate.  A partly filled batch sent on its way early (pull with wait = 2) is cut on a whole
+ * number of blksize-sample calls when the step rate*upsample is not integer-valued -- where a
+ * reference caller's call would end -- and what is left (less than one call) stays for the next
+ * batch unless it is all there is (then it goes out as the short last call a reference caller
+ * makes at the end of a stream).  For an integer-valued step the items do not depend on the cuts.
+ * Declared after sfe_rs_t below. */
 int sfe_dsp_pipe_push(sfe_pipe_t p, const void *in, size_t n_items, size_t *n_taken);
 int sfe_dsp_pipe_pull(sfe_pipe_t p, void *out, size_t max_items, int wait, size_t *n_got);
 int sfe_dsp_pipe_pending(sfe_pipe_t p, size_t *items);

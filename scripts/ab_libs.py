@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Interleaved A/B of the SAME call through two builds of the library in one process (each loaded
+privately): ab_libs.py <libA.so> <libB.so> [real|cf32]   -- 256-tap FIR, 2^29 real / 2^28 cf32 samples."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from simplefe_amd import lib as L, synth  # noqa: E402
+
+paths = sys.argv[1:3]
+mode = sys.argv[3] if len(sys.argv) > 3 else "real"
+cplx = mode == "cf32"
+n = 1 << (28 if cplx else 29)
+libs = []
+for p in paths:
+    h = C.CDLL(os.path.abspath(p), mode=os.RTLD_LOCAL)
+    for name, (res, args) in L.SIGNATURES.items():
+        if hasattr(h, name):
+            getattr(h, name).restype, getattr(h, name).argtypes = res, args
+    libs.append(h)
+taps = synth.taps_cfg2()
+st = []
+for h in libs:
+    x, y, f, t = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert h.sfe_dsp_malloc(C.byref(x), 8 << 28) == 0 and h.sfe_dsp_malloc(C.byref(y), 8 << 28) == 0
+    assert h.sfe_dsp_synth_fill(x, 2 << 28, synth.SEED, 0, 0, None) == 0
+    assert h.sfe_dsp_fir_create(taps.ctypes.data, len(taps), 0, int(cplx), 1, 0, 0, C.byref(f)) == 0
+    assert h.sfe_dsp_timer_create(C.byref(t)) == 0
+    st.append((h, x, y, f, t))
+res = [[], []]
+for r in range(int(os.environ.get("ROUNDS", "10")) + 1):
+    for i, (h, x, y, f, t) in enumerate(st):
+        h.sfe_dsp_timer_start(t, None)
+        for _ in range(5):
+            assert h.sfe_dsp_fir_process_stream(f, x, y, n, n, n, None) == 0
+        h.sfe_dsp_timer_stop(t, None)
+        ms = C.c_float(0)
+        h.sfe_dsp_timer_elapsed_ms(t, C.byref(ms))
+        if r:
+            res[i].append(ms.value / 5)
+for p, a in zip(paths, res):
+    print(f"{os.path.basename(p):32s} median {np.median(a):.4f} ms  min {min(a):.4f}  max {max(a):.4f}")

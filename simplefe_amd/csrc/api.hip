@@ -2150,6 +2150,8 @@ struct FirPipe {
     float rate = 1.0f;
     int device = 0;
     size_t batch = 0, out_cap = 0, in_e = 0, out_e = 0;     // batch: input items per slot; out_cap: output items a slot can hold
+    size_t quantum = 1;             // a partly filled batch sent on its way early is cut on a multiple of this (rs pipes at a
+                                    // non-integer step: blksize, so the cut falls where a reference call ends; else 1)
     struct Slot {
         char *h_in = nullptr, *h_out = nullptr;
         void *d_in = nullptr, *d_out = nullptr;
@@ -2196,10 +2198,13 @@ static void pipe_free(FirPipe *p)
     delete p;
 }
 
-static int pipe_submit(FirPipe *p)
+// submits the first `count` items of the batch being filled (all of it when count == fill); what is left
+// moves to the front of the next slot (free: a partial submit only happens when nothing is in flight)
+static int pipe_submit(FirPipe *p, size_t count)
 {
     FirPipe::Slot &sl = p->slot[p->head];
-    sl.n = p->fill;
+    const size_t rem = p->fill - count;
+    sl.n = count;
     SFE_HIP(hipMemcpyAsync(sl.d_in, sl.h_in, sl.n * p->in_e, hipMemcpyHostToDevice, p->s_in));
     SFE_HIP(hipEventRecord(sl.ev_in, p->s_in));
     SFE_HIP(hipStreamWaitEvent(p->s_k, sl.ev_in, 0));
@@ -2221,7 +2226,8 @@ static int pipe_submit(FirPipe *p)
     SFE_HIP(hipEventRecord(sl.ev_out, p->s_out));
     sl.busy = true;
     p->head = (p->head + 1) % PIPE_SLOTS;
-    p->fill = 0;
+    if (rem) memcpy(p->slot[p->head].h_in, sl.h_in + count * p->in_e, rem * p->in_e);
+    p->fill = rem;
     return SFE_OK;
 }
 }  // namespace sfe
@@ -2309,6 +2315,11 @@ int sfe_dsp_rs_pipe_create(sfe_rs_t rs, size_t batch_items, float rate, sfe_pipe
     p->out_cap = (size_t)ceil((double)batch_items / (double)rate) + 8;
     p->out_e = (size_t)r->esz();
     p->in_e = r->in_u8 ? (r->data_complex ? 2 : 1) : p->out_e;      // u8 wire-format items in (integer-valued steps)
+    {
+        // an integer-valued step gives the same items wherever the calls are cut; any other step does not
+        const float stepf = rate * (float)r->U;
+        p->quantum = (stepf >= 1.0f && stepf == floorf(stepf)) ? 1 : (size_t)r->blksize;
+    }
     const int rc = pipe_alloc(p, out);
     if (rc == SFE_OK) r->piped++;
     return rc;
@@ -2332,7 +2343,7 @@ int sfe_dsp_pipe_push(sfe_pipe_t h, const void *in, size_t n_items, size_t *n_ta
         n_items -= m;
         *n_taken += m;
         if (p->fill == p->batch) {
-            int rc = pipe_submit(p);
+            int rc = pipe_submit(p, p->fill);
             if (rc != SFE_OK) return rc;
         }
     }
@@ -2352,7 +2363,10 @@ int sfe_dsp_pipe_pull(sfe_pipe_t h, void *out, size_t max_items, int wait, size_
         if (!sl.busy) {
             // nothing submitted: with wait == 2 a partly filled batch is sent on its way (end of stream / drain)
             if (wait == 2 && p->fill > 0 && p->tail == p->head) {
-                int rc = pipe_submit(p);
+                // whole reference calls first: the remainder -- less than one call -- goes out only when
+                // it is all there is, as the short last call a reference caller would make
+                const size_t whole = p->fill / p->quantum * p->quantum;
+                int rc = pipe_submit(p, whole ? whole : p->fill);
                 if (rc != SFE_OK) return rc;
                 continue;
             }

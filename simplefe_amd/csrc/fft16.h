@@ -190,8 +190,11 @@ __host__ __device__ __forceinline__ v2f tw16(v2f a)
 // 16-point DFT in registers.  Result element k is left in v[P16(k)].
 __host__ __device__ constexpr int P16(int k) { return (k >> 2) | ((k & 3) << 2); }
 
+// dft16 = dft16_head, then the four butterflies dft16_tail<DIR>(v, b), b = 0..3: butterfly b completes
+// the result elements b, b + 4, b + 8, b + 12 (in v[4b], v[4b + 1], v[4b + 2], v[4b + 3]), so a caller can
+// put each element to use -- store it -- while the remaining butterflies still run (fir_fft.hip).
 template <int DIR>
-__host__ __device__ __forceinline__ void dft16(v2f (&v)[16])
+__host__ __device__ __forceinline__ void dft16_head(v2f (&v)[16])
 {
 #pragma unroll
     for (int a = 0; a < 4; a++) dft4<DIR>(v[a], v[a + 4], v[a + 8], v[a + 12]);
@@ -205,8 +208,18 @@ __host__ __device__ __forceinline__ void dft16(v2f (&v)[16])
     v[3 + 4] = tw16<DIR, 3>(v[3 + 4]);
     v[3 + 8] = tw16<DIR, 6>(v[3 + 8]);
     v[3 + 12] = tw16<DIR, 9>(v[3 + 12]);
+}
+template <int DIR>
+__host__ __device__ __forceinline__ void dft16_tail(v2f (&v)[16], int b)
+{
+    dft4<DIR>(v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3]);
+}
+template <int DIR>
+__host__ __device__ __forceinline__ void dft16(v2f (&v)[16])
+{
+    dft16_head<DIR>(v);
 #pragma unroll
-    for (int b = 0; b < 4; b++) dft4<DIR>(v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3]);
+    for (int b = 0; b < 4; b++) dft16_tail<DIR>(v, b);
 }
 
 // The transposed schedule: takes input element n in v[P16(n)] (i.e. exactly what dft16 leaves

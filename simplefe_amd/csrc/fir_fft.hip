@@ -129,6 +129,9 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
     // constants, bit 1 = output stores folded into one never-taken store -- compile-time, so the
     // product kernel's instruction stream and register allocation are untouched.
     static_assert(!DMA || (IN_C && !IN_U8 && !PAIR && !SWZ && !PREFETCH), "LDS-DMA input: complex float32, padded layout");
+    // DIAG bit 3 (diagnostic library only, variants y / u): a row is stored as soon as the butterfly of the last DFT16
+    // that completes it is done, instead of behind the whole DFT16 (DESIGN.md 9 lead (ii); it spills: see the store section)
+    constexpr bool INTERLEAVE = (DIAG & 8) != 0;
     static_assert(!TICKET || !PREFETCH, "the register prefetch looks ahead by a fixed stride");
     __shared__ v2f lds[WP ? 4 * WP_REGION : FFT_ROWS * LDS_K2_STRIDE];
     __shared__ unsigned s_next;       // TICKET: the next transform drawn by lane 0
@@ -520,14 +523,19 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             landed = more && interior(nb);
             if (landed) dma_rows(in_of(nch), nb);
             counted = landed && !OUT_TX10 && row0 == 1 && blk * a.advance + a.advance <= a.n;
-            dft16<+1>(v);
+            if constexpr (INTERLEAVE) dft16_head<+1>(v); else dft16<+1>(v);
         } else {
-        dft16<+1>(v);
+        if constexpr (INTERLEAVE) dft16_head<+1>(v); else dft16<+1>(v);
         if (!SWZ) lds_barrier();   // LDS free for the next transform
         else __builtin_amdgcn_sched_barrier(0);
         }
+        // (INTERLEAVE: the last four butterflies of that DFT16 run below, next to the stores of the rows each completes)
 
         if constexpr (PAIR) {
+            if constexpr (INTERLEAVE) {
+#pragma unroll
+                for (int b = 0; b < 4; b++) dft16_tail<+1>(v, b);
+            }
             const long long oA = 2 * blk * a.advance - a.hl, oB = oA + a.advance;
             const bool wholeA = 2 * blk * a.advance + a.advance <= a.n, wholeB = wholeA && oB + a.hl + a.advance <= a.n;
 #pragma unroll
@@ -548,6 +556,11 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
                             store_group(d, u0, u1, u2, u3);
                         }
                     }
+                } else if (wholeB) {          // both segments inside the stream (the common transform): no per-row tests
+                    float *qa = reinterpret_cast<float *>(out_c + (oA + 256 * r) * 4) + t;
+                    float *qb = reinterpret_cast<float *>(out_c + (oB + 256 * r) * 4) + t;
+                    __builtin_nontemporal_store(ACC ? y.x + *qa : y.x, qa);
+                    __builtin_nontemporal_store(ACC ? y.y + *qb : y.y, qb);
                 } else {
                 if (wholeA || oA + 256 * r + (long long)t < a.n) {
                     float *q = reinterpret_cast<float *>(out_c + (oA + 256 * r) * 4) + t;
@@ -566,6 +579,41 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         char *const obase_p = out_c + obase * OSZ;           // uniform
         unsigned voff = t * OSZ;
         asm volatile("" : "+v"(voff));                       // keep the row offsets in the vector register, not in scalar pointers
+        // The common transform -- one discarded row, all 3840 outputs inside the stream -- stores its 15 rows
+        // unconditionally and in ONE basic block with the last DFT16, so the scheduler may issue a row's store as
+        // soon as its radix-4 group is done (DESIGN.md 9 lead (ii)); the guarded form below costs two branches and
+        // ~10 scalar instructions per row and starts only after the whole DFT16.  DIAG bit 2: always the guarded form.
+        const bool plain_rows = !(DIAG & 4) && !(OUT_TX10 && OUT_C) && whole && row0 == 1;
+        if (plain_rows) {
+            // Butterfly b completes rows b, b + 4, b + 8, b + 12 (fft16.h), so their stores could go out while
+            // the remaining butterflies run (DESIGN.md 9 lead (ii)).  Written that way (DIAG bit 3, diagnostic
+            // library only: variants y / u) the kernels SPILL -- 14 (LDS-DMA) to 26 (register loads) VGPRs, 22-54
+            // with the stores pinned by scheduling barriers -- against none for the whole DFT16 first and the
+            // fifteen stores behind it, which is what the product does.
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                if constexpr (INTERLEAVE) dft16_tail<+1>(v, b);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int r = b + 4 * c;
+                if (r == 0) continue;
+                if constexpr (DIAG & 2) continue;
+                v2f y = v[P16(r)];
+                char *rp = DMA ? obase_p + (voff + (unsigned)(256 * r * OSZ)) : out_c + (obase + 256 * r) * OSZ + (size_t)t * OSZ;
+                if constexpr (OUT_C) {
+                    if constexpr (ACC) y += *reinterpret_cast<const v2f *>(rp);
+                    __builtin_nontemporal_store(y, reinterpret_cast<v2f *>(rp));
+                } else {
+                    if constexpr (ACC) y.x += *reinterpret_cast<const float *>(rp);
+                    __builtin_nontemporal_store(y.x, reinterpret_cast<float *>(rp));
+                }
+            }
+            }
+        } else {
+        if constexpr (INTERLEAVE) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) dft16_tail<+1>(v, b);
+        }
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const long long orow = obase + 256 * r;          // uniform
@@ -599,6 +647,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
                     __builtin_nontemporal_store(y.x, reinterpret_cast<float *>(rp));
                 }
             }
+        }
         }
         if constexpr (DIAG & 2) {   // keeps every result alive behind one store that never happens
             v2f acc = v[0];
@@ -1043,6 +1092,11 @@ int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in
         else if (ev[0] == 'T') SFE_NEW_DG(false, true, false);
         else if (ev[0] == 'X') SFE_NEW_DG(true, true, false);
         else if (ev[0] == 'W') SFE_NEW_DG(true, true, true);           // + wave-private first/last layout
+        else if (ev[0] == 'y') SFE_NEW(true, true, 8, false);          // X, a row's store issued as soon as its butterfly is done (spills)
+        else if (ev[0] == 'u') SFE_NEW(false, true, 8, false);         // T, likewise
+        else if (ev[0] == 'x') SFE_NEW(true, true, 4, false);          // X with the round-2 guarded store loop
+        else if (ev[0] == 't') SFE_NEW(false, true, 4, false);         // T with the round-2 guarded store loop
+        else if (ev[0] == 'w') SFE_NEW(true, true, 4, true);           // W with the round-2 guarded store loop
         else if (ev[0] == '4' && diag) {                                                           // ablations of "4n.h"
             if (diag == 1) SFE_STATIC(4, false, false, true, 1);
             else if (diag == 2) SFE_STATIC(4, false, false, true, 2);
