@@ -449,10 +449,35 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
 #pragma unroll
                     for (int k0 = 1; k0 < 16; k0++) acc += v[k0];
                     if (acc.x == 1.2345e38f) *reinterpret_cast<v2f *>(op) = acc;
-                } else {
+                } else if constexpr ((DIAG & 64) || UP * SP > 15) {       // the round-2 form, one exec-masked store and one branch per row: A/B (DIAG bit 6), and
+                                                                          // the shapes whose 16+ spectra registers leave no room for the form below (5/4: 13 spilled VGPRs)
 #pragma unroll
                 for (int k0 = 0; k0 < 16; k0++)
                     if (xb - (unsigned)(16 * UP * k0) < span) __builtin_nontemporal_store(v[P16(k0)], reinterpret_cast<v2f *>(op - 16 * UP * 8 * k0));
+                } else {
+                    // Sixteen straight-line buffer stores through ONE descriptor over this pass's window of the output:
+                    // its record count ends the window at n_out (the hardware drops what lies beyond), and a lane whose
+                    // element is overlap (n < ovl) gets an offset no record count reaches -- a compare and a select per
+                    // row instead of an exec-mask save, a branch and a restore (16 branches per pass in the round-2 ISA).
+                    typedef int v2i __attribute__((ext_vector_type(2)));
+                    char *const wb = out_c + ku * 8;                                     // uniform; offsets below are >= ovu*8
+                    const long long recs = remu < 0 ? 0 : (remu > (1 << 26) ? (1 << 26) : remu);
+                    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(wb));
+                    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(wb) >> 32));
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                        reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo), 0, (int)(recs * 8), 0x00020000);
+                    const unsigned span2 = 256u * UP > (unsigned)ovu ? 256u * UP - (unsigned)ovu : 0u;      // x < 256 UP: n = 256 is bin 0, below
+                    // row k0 sits 16 UP elements below row k0 - 1: ONE per-lane offset (row 15's) selected against the
+                    // unreachable one, the row's distance from it as a constant the instruction's offset field / a scalar holds
+                    int vlow = (koff + nu) * 8 - 16 * UP * 8 * 15;
+                    asm volatile("" : "+v"(vlow));
+#pragma unroll
+                    for (int k0 = 0; k0 < 16; k0++) {
+                        const int sel = xb - (unsigned)(16 * UP * k0) < span2 ? vlow : (int)0x7FFF0000;
+                        constexpr int STEP = 16 * UP * 8;
+                        const int up = STEP * (15 - k0);                                  // 0 .. 15 STEP
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, v[P16(k0)]), rs, sel + (up & 2047), up & ~2047, 2 /* nt */);
+                    }
                 }
                 if (l == 0 && a.ovl == 0 && lim > 0) __builtin_nontemporal_store(v[P16(0)], reinterpret_cast<v2f *>(out_c + ko0 * 8));
             }
@@ -601,6 +626,7 @@ int launch_poly_fft(const PolyFftPlan &plan, const PolyFftArgs &a0, int data_com
             if (e[0] == 'h') return launch_one<5, 3, 2, false, false, 0, true, 2>(a, n_channels, s);         // half before S3, half after
             if (e[0] == 'e') return launch_one<5, 3, 2, false, false, 16, true, 0>(a, n_channels, s);        // t without the in-wave exchange (upper bound for doing it off the LDS)
             if (e[0] == 'w') return launch_one<5, 3, 2, false, false, 0, true, 0, 3>(a, n_channels, s);     // 3 workgroups per CU, 168 VGPRs: no spill
+            if (e[0] == 'b') return launch_one<5, 3, 2, false, false, 64, true, 0>(a, n_channels, s);        // t with the round-2 exec-masked stores
             if (e[0] == 'z') return launch_one<5, 3, 2, false, false, 32, true, 0>(a, n_channels, s);        // t without the S0 scatter writes (bound for LDS-DMA staging)
             if (e[0] == 'Z') return launch_one<5, 3, 2, false, false, 48, true, 0>(a, n_channels, s);        // neither the scatter nor the exchange
             if (e[0] == 'y') return launch_one<5, 3, 2, false, false, 32, true, 0, 3>(a, n_channels, s);     // z at 3 workgroups per CU
