@@ -58,6 +58,10 @@ for r in range(rounds + 1):
         ms = t.elapsed_ms() / 5
         if r:
             res[v].append(ms)
+if "P" in variants:
+    v_, cal, ms = f.get_variant()
+    print(f"# P = the product's dispatch: measured on this device at its first call, ran '{lib.FIR_VARIANT_NAMES.get(v_, v_)}' "
+          f"(calibration medians, ms: " + ", ".join(f"{lib.FIR_VARIANT_NAMES[i]} {m:.4f}" for i, m in enumerate(ms)) + ")")
 for v in variants:
     a = np.array(res[v])
     print(f"{v:8s} median {np.median(a):.4f} ms  min {a.min():.4f}  max {a.max():.4f}  -> {16.0 * n / np.median(a) / 1e6:.0f} GB/s alg, "

@@ -34,8 +34,17 @@ mkdir -p $R/gpurun_out/prof_${TAG}_tables
 timeout -k 10 300 python3 scripts/ablate.py fir > gpurun_out/prof_${TAG}_tables/fir_variants_ab.txt 2>&1 || exit 1
 timeout -k 10 300 python3 scripts/ablate.py resample > gpurun_out/prof_${TAG}_tables/resample_fft_ablation.txt 2>&1 || exit 1
 ROUNDS=8 timeout -k 10 300 python3 scripts/ab_fir.py 4n.h D T X W e:8 E e:300 > gpurun_out/prof_${TAG}_tables/fir_walk_vs_tickets.txt 2>&1 || exit 1
+# round 3: the three product variants with the straight-line store block (T X W) against the round-2 guarded store loop
+# (t x w) and against stores interleaved with the last DFT16 (u y); P = the product's own dispatch (measured choice)
+ROUNDS=10 timeout -k 10 300 python3 scripts/ab_fir.py T t X x W w u y P > gpurun_out/prof_${TAG}_tables/fir_store_block.txt 2>&1 || exit 1
 ROUNDS=8 timeout -k 10 300 python3 scripts/ab_fir.py e:8 b:8 g:8 G:8 e:300 b:300 g:300 > gpurun_out/prof_${TAG}_tables/fir_pattern_sync.txt 2>&1 || exit 1
 timeout -k 10 300 python3 scripts/ab_rs.py s t x l w > gpurun_out/prof_${TAG}_tables/resample_walk_vs_tickets.txt 2>&1 || exit 1
+# round 3: what taking work off the LDS could give at most (e no in-wave exchange, z no S0 scatter writes, Z neither, y = z at 3
+# workgroups per CU) and the buffer-store epilogue against the round-2 exec-masked one (b)
+ROUNDS=10 timeout -k 10 300 python3 scripts/ab_rs.py t b e z Z w y > gpurun_out/prof_${TAG}_tables/resample_lds_bounds.txt 2>&1 || exit 1
+timeout -k 10 300 python3 scripts/time_rs_channels.py > gpurun_out/prof_${TAG}_tables/resample_channels.txt 2>&1 || exit 1
+LOG2N=28 timeout -k 10 300 python3 scripts/time_general_rate.py > gpurun_out/prof_${TAG}_tables/general_rate.txt 2>&1 || exit 1
+timeout -k 10 300 python3 scripts/time_real_fir.py > gpurun_out/prof_${TAG}_tables/fir_real_data.txt 2>&1 || exit 1
 timeout -k 10 120 scripts/probes/hbm_mix > gpurun_out/prof_${TAG}_tables/hbm_mix.txt 2>&1
 timeout -k 10 200 python3 scripts/time_pipe.py > gpurun_out/prof_${TAG}_tables/host_pipe.txt 2>&1
 echo collected

@@ -1757,8 +1757,8 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
             ta.in = d_in;
             ta.out = d_out;
             ta.hist = r->d_hist[r->cur];
-            ta.hist_out = can_fuse ? r->d_hist[r->cur ^ 1] : nullptr;
-            hist_fused = can_fuse;
+            ta.hist_out = can_fuse && !r->exact_stream ? r->d_hist[r->cur ^ 1] : nullptr;      // exact kernels: separate carry-over launch
+            hist_fused = ta.hist_out != nullptr;
             ta.G = pl->d_G;
             ta.n_in = (long long)n_in;
             ta.in_stride = (long long)in_stride;

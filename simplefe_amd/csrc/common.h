@@ -122,7 +122,8 @@ struct PolyTiledArgs {
     const void *in;
     void       *out;
     const void *hist;
-    void       *hist_out = nullptr;   // if non-null (needs n_in >= hl): tile 0's workgroup also writes the next call's history
+    void       *hist_out = nullptr;   // if non-null (needs n_in >= hl): one extra workgroup per channel writes the next call's history
+    unsigned    tiles = 0;            // set by the launcher: tiles per channel (blockIdx.x == tiles is that extra workgroup)
     const float *G;
     long long   n_in, in_stride, out_stride, n_out;
     int         hl, Lp, e_max;

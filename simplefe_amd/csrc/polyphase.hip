@@ -161,14 +161,20 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
     const T *hist = static_cast<const T *>(a.hist) + (size_t)ch * a.hl;
     T *out = static_cast<T *>(a.out) + (size_t)ch * a.out_stride;
 
-    // state carry-over fused in: the workgroup of a channel's tile 0 also writes the NEXT call's
-    // history, in[n_in - hl .. n_in) as float32 (the launcher passes hist_out only when n_in >= hl)
-    if (a.hist_out && blockIdx.x == 0) {
+    // state carry-over fused in: ONE EXTRA workgroup per channel (blockIdx.x == the tile count) does
+    // nothing but write the NEXT call's history, in[n_in - hl .. n_in) as float32, and leaves (the launcher adds it
+    // only when n_in >= hl).  Done by tile 0's workgroup in front of its tile instead, the copy loop cost the
+    // decimator 12 VGPRs -- 82 instead of 70, five waves per SIMD instead of seven, 1.59 -> 2.05 ms at 2^30.
+    // (fused-arithmetic instantiations only: the exact-mode kernels -- the class-compatible path, a few thousand samples per
+    // call -- are left as they were, two of them sit on a register / scalar-register step that the extra arguments cross)
+    if (!EXACT && a.hist_out && blockIdx.x == a.tiles) {
         T *ho = static_cast<T *>(a.hist_out) + (size_t)ch * a.hl;
+#pragma unroll 1
         for (unsigned i = tid; i < (unsigned)a.hl; i += 256u) {
             if constexpr (IN_U8) ho[i] = vload_u8<CPLX>(in8, hist, a.n_in - a.hl + i, a.n_in, a.hl);
             else ho[i] = in[a.n_in - a.hl + i];
         }
+        return;
     }
     const long long m0 = (long long)blockIdx.x * TM;
     const long long n_org = (long long)SP * m0 + a.e_max - (a.Lp - 1);   // stream index of local sample 0
@@ -651,18 +657,21 @@ bool poly_tiled_supported(int SP, int UP, int Lp)
     return Lp / SP <= xc;
 }
 
-int launch_poly_tiled(const PolyTiledPlan &plan, const PolyTiledArgs &a, int data_complex, int exact,
+int launch_poly_tiled(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int data_complex, int exact,
                       int in_u8, int n_channels, hipStream_t s)
 {
-    if (a.n_out <= 0) return SFE_OK;
+    if (a0.n_out <= 0) return SFE_OK;
     if (!poly_tiled_supported(plan.SP, plan.UP, plan.Lp)) return SFE_ESTATE;
-    const long long mtot = (a.n_out + plan.UP - 1) / plan.UP;
+    const long long mtot = (a0.n_out + plan.UP - 1) / plan.UP;
     const long long tiles = (mtot + TM - 1) / TM;
     if (tiles > 0x7fffffffLL) {
         set_error("polyphase: too many tiles");
         return SFE_EINVAL;
     }
-    dim3 grid((unsigned)tiles, (unsigned)n_channels), block(256);
+    PolyTiledArgs a = a0;
+    a.tiles = (unsigned)tiles;
+    if (exact) a.hist_out = nullptr;
+    dim3 grid((unsigned)tiles + (a.hist_out ? 1u : 0u), (unsigned)n_channels), block(256);      // + the history workgroup
     const size_t esz = data_complex ? 8 : 4;
 #ifdef SFE_DIAG
     if (const char *e = getenv("SFE_TILED_DIAG")) {          // decimate by 8, cf32, fused numerics only
