@@ -142,9 +142,10 @@ int sfe_dsp_fir_set_algo(sfe_fir_t h, int algo);
  * register loads, LDS-DMA requested early, or LDS-DMA into a wave-private exchange layout
  * (DESIGN.md 4.1).  Same arithmetic, bit-identical output; which is fastest differs by a few
  * percent BETWEEN DEVICES of one pool, so by default (AUTO) a handle's first bulk call of >= 8192
- * transforms on a device and shape times all of them on that call's own buffers (three interleaved
- * rounds; the call then takes ~10x its usual time, and is not asynchronous) and the process
- * remembers the winner for that (device, channels, size class, overlap).  set_variant fixes the
+ * transforms on a device and shape times all of them on that call's own buffers (interleaved
+ * rounds for at least 80 ms, the last nine counted; that one call is not asynchronous) and the
+ * process remembers the choice for that (device, channels, size class, overlap): register loads,
+ * unless another variant's median is more than 1 % ahead.  set_variant fixes the
  * choice and turns the measurement off (latency-critical callers; a call inside a hipGraph capture
  * never measures).  get_variant: what the handle's last bulk call ran, how many measurements this
  * handle made, and (ms_by_variant: 3 floats, may be NULL) the medians of its last measurement.

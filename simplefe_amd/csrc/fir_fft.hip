@@ -1009,8 +1009,8 @@ int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in
     const bool pair = !in_complex && !out_complex;     // real stream, real taps: two segments per transform
     // LDS-DMA moves 16-byte lanes: every channel's first sample must sit on a 16-byte boundary
     const bool dma_ok = (reinterpret_cast<uintptr_t>(a.in) & 15u) == 0 && (n_channels == 1 || (a.in_stride & 1) == 0);
-    // data movement of an aligned cf32 stream: what the caller measured (api.hip: fir_pick_variant), else LDS-DMA
-    const int var = !dma_ok ? FIR_VAR_REG : (a.variant == FIR_VAR_REG || a.variant == FIR_VAR_WP ? a.variant : FIR_VAR_DMA);
+    // data movement of an aligned cf32 stream: what the caller measured (api.hip: fir_pick_variant), else register loads
+    const int var = !dma_ok ? FIR_VAR_REG : (a.variant == FIR_VAR_DMA || a.variant == FIR_VAR_WP ? a.variant : FIR_VAR_REG);
 #ifdef SFE_DIAG
     // SFE_FIR_VARIANT = "<waves 2-4><p|n>[s][h]" | "c" | "d" | "e",  SFE_FIR_DIAG = bit 0 no loads, bit 1 no stores,
     // SFE_FIR_WG_PER_CU: read per launch so scripts/ab_fir.py can interleave variants in one process

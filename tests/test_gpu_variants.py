@@ -56,7 +56,8 @@ def test_first_large_call_measures_once_per_shape_and_the_process_remembers(api,
     f.process_stream(x, y, n)
     v, cal, ms = f.get_variant()
     assert cal == 1 and v in (0, 1, 2) and all(m > 0 for m in ms), (v, cal, ms)
-    assert ms[v] == min(ms)                       # the smallest median was taken
+    # register loads unless another variant's median is more than 1 % ahead (then the smallest)
+    assert (v == 0 and min(ms[1:]) >= 0.99 * ms[0]) or (v != 0 and ms[v] == min(ms) and ms[v] < 0.99 * ms[0]), (v, ms)
     f.process_stream(x, y, n)                     # the same handle does not measure again
     assert f.get_variant()[:2] == (v, 1)
     # the measured call's output is the stream's output: windows against the oracle, and the next call continues it
@@ -71,7 +72,7 @@ def test_first_large_call_measures_once_per_shape_and_the_process_remembers(api,
     assert g.get_variant()[:2] == (v, 0)
     h = api.Fir(taps, data_complex=True)          # a small call never measures and takes the default
     h.process_stream(x, y, 1 << 16)
-    assert h.get_variant()[:2] == (L.FIR_VARIANT_LDS_DMA, 0)
+    assert h.get_variant()[:2] == (L.FIR_VARIANT_REGISTER_LOADS, 0)
     LL.sfe_dsp_fir_forget_calibrations()
     k = api.Fir(taps, data_complex=True)
     k.process_stream(x, y, n)
