@@ -96,8 +96,9 @@ int sfe_dsp_fir_create(const float *taps, int n_taps, int taps_complex, int data
 
 /* The same with a tap vector PER CHANNEL (what 64 reference objects with 64 different filters are):
  *   taps  [n_channels][n_taps] floats ([n_channels][n_taps] (re,im) pairs when taps_complex); copied.
- * Complex float32 streams, the FFT path (any n_taps it takes); one launch covers all channels, a
- * channel's spectrum is read per transform instead of being held in registers.  No host block. */
+ * Complex float32 streams, the FFT path (any n_taps it takes); one launch covers all channels: a
+ * workgroup holds its channel's spectrum in registers as for a shared filter and reloads it when
+ * the next transform it draws belongs to another channel (+3 % at 64 x 2^24).  No host block. */
 int sfe_dsp_fir_create_per_channel(const float *taps, int n_taps, int taps_complex, int n_channels,
                                    int device, sfe_fir_t *out);
 /* Host-only (no GPU): how a tap count is served by the 4096-point kernel -- the overlap of one

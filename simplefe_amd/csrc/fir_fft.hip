@@ -1146,7 +1146,7 @@ int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in
     }
 #endif
     //       IN_C   OUT_C  WAVES PREFETCH SWZ  HREG  IN_U8  PAIR   OUT_TX10 DMA DIAG TICKET ACC
-    if (a.hs_stride) {          // per-channel taps: the channel's spectrum is read per transform (cf32 streams only)
+    if (a.hs_stride) {          // per-channel taps: the channel's spectrum is reloaded into registers on a channel change (cf32 streams only)
         if (!in_complex || !out_complex || in_u8 || out_tx10) {
             set_error("fir_fft: per-channel taps are built for complex float32 streams");
             return SFE_EINVAL;

@@ -15,7 +15,10 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CITE = re.compile(r"profiles/[A-Za-z0-9_./-]*[A-Za-z0-9]\.(?:txt|csv|json|tsv|md)")
-MS = re.compile(r"(?<![\d.])(\d+\.\d{3,4})(?=(?:\s*(?:/|,|and|against|…|->|→|vs)\s*\d+\.\d+)*\s*ms\b)")
+# every figure of three or four decimals in a citing sentence that speaks of milliseconds -- not only the one the
+# unit follows: "`T` 0.7831, `X` 0.7889 and `P` 0.7846 ms" attributes three figures.  Percentages, exponents
+# (2.9e-7) and parts of longer numbers are left out.
+MS = re.compile(r"(?<![\d.\w-])(\d+\.\d{3,4})(?![\d%]|\s*%|e[-+]?\d)")
 NUM = re.compile(r"(?<![A-Za-z_])[-+]?\d+\.?\d*(?:[eE][-+]?\d+)?")
 
 
@@ -52,6 +55,8 @@ def claims():
     for s in sentences(text):
         cites = CITE.findall(s)
         if not cites:
+            continue
+        if not re.search(r"\bms\b", s):
             continue
         for m in MS.finditer(s):
             yield s, cites, m.group(1)
