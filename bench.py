@@ -634,6 +634,12 @@ def main():
             others.append(mk())
         except Exception as e:
             other_errors.append({"error": "%s: %s" % (type(e).__name__, e)})
+    if world > 1 and makers:
+        # the extra legs time and reduce collectively: they run only if EVERY rank could set all of them up
+        failed_somewhere = shard.max_over_ranks(1.0 if other_errors else 0.0, ctx_red) > 0
+        if failed_somewhere:
+            others = []
+            other_errors = other_errors or [{"error": "an other_configs leg could not be set up on another rank"}]
     other_rows = []
     precondition(ctx, others[0] if others else head, args.precondition)      # whichever leg runs first takes the chip through its start-up transient
     for leg in others:
