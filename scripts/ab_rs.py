@@ -31,7 +31,7 @@ for k in range(rounds + 1):
         os.environ["SFE_RS_TQS"] = vr[1] if len(vr) > 1 else "3"
         vv = vr[0].split(":")                              # t:8 = grid of 8 x the resident workgroups
         os.environ["SFE_RS_VARIANT"] = vv[0]
-        os.environ["SFE_RS_WG_FACTOR"] = vv[1] if len(vv) > 1 else ("1" if vv[0] in ("t", "x", "l", "h", "w", "e", "z", "Z", "y", "b") else "2")
+        os.environ["SFE_RS_WG_FACTOR"] = vv[1] if len(vv) > 1 else ("1" if vv[0] in ("t", "x", "l", "h", "w", "e", "z", "Z", "y", "b", "p", "q") else "2")
         t.start()
         for _ in range(5):
             r.process_stream(x, n, y, cap, 5.0 / 3.0)

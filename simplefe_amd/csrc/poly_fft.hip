@@ -134,6 +134,10 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
     auto out_of = [&](int c) -> char * { return static_cast<char *>(a.out) + (size_t)c * a.out_stride * ESZ; };
     auto hist_of = [&](int c) -> const char * { return static_cast<const char *>(a.hist) + (size_t)c * a.hl * ESZ; };
 
+    // DIAG bits 7 / 8 (diagnostic library only): static priority for the waves that host the inverse transforms and their
+    // global stores (waves 2, 3 of the 5/3 shape) / for the forward-only waves (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+    if constexpr (DIAG & 128) { if (t >= 128u) __builtin_amdgcn_s_setprio(1); }
+    if constexpr (DIAG & 256) { if (t < 128u) __builtin_amdgcn_s_setprio(1); }
     const v2f *tw = reinterpret_cast<const v2f *>(a.tw);
     // the six twiddle bases per lane W_256^(l k), W_256^(4 l k) sit in LDS and are re-read every
     // pass (6 ds_read_b64): 12 VGPRs the prefetched samples need more (measured +4 % over
@@ -626,6 +630,8 @@ int launch_poly_fft(const PolyFftPlan &plan, const PolyFftArgs &a0, int data_com
             if (e[0] == 'h') return launch_one<5, 3, 2, false, false, 0, true, 2>(a, n_channels, s);         // half before S3, half after
             if (e[0] == 'e') return launch_one<5, 3, 2, false, false, 16, true, 0>(a, n_channels, s);        // t without the in-wave exchange (upper bound for doing it off the LDS)
             if (e[0] == 'w') return launch_one<5, 3, 2, false, false, 0, true, 0, 3>(a, n_channels, s);     // 3 workgroups per CU, 168 VGPRs: no spill
+            if (e[0] == 'p') return launch_one<5, 3, 2, false, false, 128, true, 0>(a, n_channels, s);       // t, waves 2-3 (inverse transforms + stores) at priority 1
+            if (e[0] == 'q') return launch_one<5, 3, 2, false, false, 256, true, 0>(a, n_channels, s);       // t, waves 0-1 (forward only) at priority 1
             if (e[0] == 'b') return launch_one<5, 3, 2, false, false, 64, true, 0>(a, n_channels, s);        // t with the round-2 exec-masked stores
             if (e[0] == 'z') return launch_one<5, 3, 2, false, false, 32, true, 0>(a, n_channels, s);        // t without the S0 scatter writes (bound for LDS-DMA staging)
             if (e[0] == 'Z') return launch_one<5, 3, 2, false, false, 48, true, 0>(a, n_channels, s);        // neither the scatter nor the exchange
