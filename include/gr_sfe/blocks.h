@@ -288,6 +288,89 @@ typename rational_resampler_xxf<CPLX>::sptr rational_resampler_xxf<CPLX>::make(u
 typedef rational_resampler_xxf<true> rational_resampler_ccf;
 typedef rational_resampler_xxf<false> rational_resampler_fff;
 
+// ---------------------------------------------------------- FIR between the wire formats, batched
+// gr-simplefe's own blocks ARE the converters: source_c turns the device's u8 offset-binary (I,Q)
+// bytes into gr_complex (lib/source_c_impl.cc:121-132), sink_c turns gr_complex into the 10-bit
+// packed transmit format, 2 samples in 5 bytes (lib/sink_c_impl.cc:118-144).  These blocks take /
+// hand out those byte streams directly and run the conversion inside the FIR kernel's load and store
+// (SURVEY.md 8(f) N2 at the block level): a receive chain feeds the device's bytes straight in
+// (2 instead of 8 bytes per sample over PCIe and from HBM), a transmit chain gets the bytes the USB
+// writer sends.  Items:  IN_U8  -> one item = one (I,Q) byte pair (item size 2; real: 1 byte)
+//                        OUT_TX10 -> unsigned char items, in whole 5-byte groups (output multiple 5)
+//   rx_fir_bc  = u8 pairs in, gr_complex out        fir_tx_cb = gr_complex in, 10-bit bytes out
+//   rx_fir_tx_bb = wire to wire (the source_c -> FIR -> sink_c flowgraph as one block)
+template <bool CPLX, bool IN_U8, bool OUT_TX10>
+class fir_wire : virtual public gr::block
+{
+public:
+    typedef typename sptr_of<fir_wire>::type sptr;
+    static sptr make(const std::vector<float> &taps, int batch_items = 0, int device = 0);
+};
+
+template <bool CPLX, bool IN_U8, bool OUT_TX10>
+class fir_wire_impl : public fir_wire<CPLX, IN_U8, OUT_TX10>
+{
+    enum { GS = CPLX ? 2 : 4,                                                   // samples per 10-bit group
+           IN_SZ = IN_U8 ? (CPLX ? 2 : 1) : (CPLX ? (int)sizeof(gr_complex) : (int)sizeof(float)),
+           OUT_SZ = OUT_TX10 ? 1 : (CPLX ? (int)sizeof(gr_complex) : (int)sizeof(float)) };
+
+public:
+    fir_wire_impl(const std::vector<float> &taps, int batch_items, int device)
+        : gr::block("sfe_fir_wire", gr::io_signature::make(1, 1, IN_SZ), gr::io_signature::make(1, 1, OUT_SZ)), d_h(0), d_p(0)
+    {
+        check(sfe_dsp_fir_create(taps.data(), (int)taps.size(), 0, CPLX ? 1 : 0, 1, 0, device, &d_h), "fir_wire");
+        int rc = IN_U8 ? sfe_dsp_fir_set_input_format(d_h, SFE_FMT_U8) : SFE_OK;
+        if (rc == SFE_OK && OUT_TX10) rc = sfe_dsp_fir_set_output_format(d_h, SFE_FMT_TX10);
+        if (rc == SFE_OK) rc = sfe_dsp_fir_pipe_create(d_h, (size_t)(batch_items > 0 ? batch_items : 0), &d_p);
+        if (rc != SFE_OK) {
+            sfe_dsp_fir_destroy(d_h);
+            check(rc, "fir_wire setup");
+        }
+        if (OUT_TX10) {
+            this->set_output_multiple(5);
+            this->set_relative_rate(5.0 / GS);
+        } else
+            this->set_relative_rate(1.0);
+    }
+    ~fir_wire_impl()
+    {
+        sfe_dsp_pipe_destroy(d_p);
+        sfe_dsp_fir_destroy(d_h);
+    }
+    void forecast(int, gr_vector_int &req)
+    {
+        size_t pend = 0;
+        sfe_dsp_pipe_pending(d_p, &pend);
+        for (size_t i = 0; i < req.size(); i++) req[i] = pend ? 0 : 1;
+    }
+    int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
+                     gr_vector_void_star &output_items)
+    {
+        const size_t room = OUT_TX10 ? (size_t)noutput_items / 5 : (size_t)noutput_items;      // pipe items: 5-byte groups / samples
+        size_t taken = 0, got = 0;
+        if (ninput_items[0] > 0) check(sfe_dsp_pipe_push(d_p, input_items[0], (size_t)ninput_items[0], &taken), "fir_wire::push");
+        check(sfe_dsp_pipe_pull(d_p, output_items[0], room, 0, &got), "fir_wire::pull");
+        if (taken == 0 && got == 0) check(sfe_dsp_pipe_pull(d_p, output_items[0], room, ninput_items[0] > 0 ? 1 : 2, &got), "fir_wire::pull");
+        this->consume_each((int)taken);
+        return (int)(OUT_TX10 ? got * 5 : got);
+    }
+
+private:
+    sfe_fir_t d_h;
+    sfe_pipe_t d_p;
+};
+
+template <bool CPLX, bool IN_U8, bool OUT_TX10>
+typename fir_wire<CPLX, IN_U8, OUT_TX10>::sptr fir_wire<CPLX, IN_U8, OUT_TX10>::make(const std::vector<float> &taps, int batch_items, int device)
+{
+    return typename fir_wire<CPLX, IN_U8, OUT_TX10>::sptr(new fir_wire_impl<CPLX, IN_U8, OUT_TX10>(taps, batch_items, device));
+}
+typedef fir_wire<true, true, false> rx_fir_bc;        // source_c's bytes in, gr_complex out
+typedef fir_wire<true, false, true> fir_tx_cb;        // gr_complex in, sink_c's bytes out
+typedef fir_wire<true, true, true> rx_fir_tx_bb;      // wire to wire
+typedef fir_wire<false, true, false> rx_fir_bf;       // source_f's bytes in, float out
+typedef fir_wire<false, false, true> fir_tx_fb;       // float in, sink_f's bytes out
+
 }  // namespace sfe
 }  // namespace gr
 

@@ -169,7 +169,9 @@ int sfe_dsp_fir_set_zero_copy_max(sfe_fir_t h, size_t max_samples);
  * hands a block a few thousand items per work() call (gr-simplefe/lib/sink_c_impl.cc:157-174,
  * source_c_impl.cc:134-153); one synchronous round trip per call is launch/sync bound.  A pipe
  * over a single-channel FIR handle (float32 items, or u8 wire-format items in when the handle's
- * input format is SFE_FMT_U8; float32 items out) collects pushed items in pinned batches of
+ * input format is SFE_FMT_U8; float32 items out, or -- output format SFE_FMT_TX10 -- the 10-bit
+ * transmit wire format: an output ITEM is then one 5-byte group = 2 complex / 4 real samples, only
+ * whole groups are ever sent on their way) collects pushed items in pinned batches of
  * `batch_items` (0 = 262144) and keeps up to four batches in flight on three streams (copy in,
  * filter, copy out); pull hands out finished items in order.  Item k out is the filter's output
  * for item k in: no delay is inserted, only latency.  While a pipe exists, drive its handle only

@@ -2159,6 +2159,8 @@ struct FirPipe {
     size_t batch = 0, out_cap = 0, in_e = 0, out_e = 0;     // batch: input items per slot; out_cap: output items a slot can hold
     size_t quantum = 1;             // a partly filled batch sent on its way early is cut on a multiple of this (rs pipes at a
                                     // non-integer step: blksize, so the cut falls where a reference call ends; else 1)
+    size_t tx_gs = 0;               // 10-bit packed output: samples per 5-byte group (2 complex / 4 real); an output ITEM is one group.
+                                    // Cuts then fall on whole groups ONLY (less than a group is never sent: the converter emits whole groups)
     struct Slot {
         char *h_in = nullptr, *h_out = nullptr;
         void *d_in = nullptr, *d_out = nullptr;
@@ -2220,7 +2222,7 @@ static int pipe_submit(FirPipe *p, size_t count)
     int rc;
     if (p->f) {
         rc = fir_run(p->f, sl.d_in, sl.d_out, sl.n, sl.n, sl.n, p->s_k);
-        sl.n_out = sl.n;
+        sl.n_out = p->tx_gs ? sl.n / p->tx_gs : sl.n;
     } else {
         // the output count is known on the host as soon as the launch is made (closed form for
         // integer-valued steps, the replayed float32 recurrence otherwise): the copy-out is sized by it
@@ -2267,11 +2269,12 @@ int sfe_dsp_fir_pipe_create(sfe_fir_t fir, size_t batch_items, sfe_pipe_t *out)
     if (!out) return SFE_EINVAL;
     *out = nullptr;
     Fir *f = as_fir(fir);
-    if (!f || f->n_channels != 1 || f->out_tx10) {
-        set_error("fir_pipe_create: needs a single-channel FIR handle with float32 output");
+    if (!f || f->n_channels != 1) {
+        set_error("fir_pipe_create: needs a single-channel FIR handle");
         return SFE_EINVAL;
     }
     if (batch_items == 0) batch_items = (size_t)1 << 18;
+    batch_items = (batch_items + 3) & ~(size_t)3;          // whole 10-bit groups per batch, whatever the output format
     if (batch_items < 256 || batch_items > ((size_t)1 << 26)) {
         set_error("fir_pipe_create: batch of %zu items out of range (256 .. 2^26)", batch_items);
         return SFE_EINVAL;
@@ -2286,6 +2289,13 @@ int sfe_dsp_fir_pipe_create(sfe_fir_t fir, size_t batch_items, sfe_pipe_t *out)
     // 2 bytes per complex item, 1 per real one -- a receive chain hands the device's bytes straight in)
     p->in_e = f->in_u8 ? (f->data_complex ? 2 : 1) : (f->data_complex ? 8 : 4);
     p->out_e = f->out_complex ? 8 : 4;
+    if (f->out_tx10) {
+        // the transmit wire format out (sink_c_impl.cc:118-144 / sink_f_impl.cc:117-143): an output item is one 5-byte group
+        p->tx_gs = f->out_complex ? 2 : 4;
+        p->quantum = p->tx_gs;
+        p->out_e = 5;
+        p->out_cap = p->batch / p->tx_gs;
+    }
     const int rc = pipe_alloc(p, out);
     if (rc == SFE_OK) f->piped++;          // the handle's formats are frozen while the pipe lives
     return rc;
@@ -2373,6 +2383,7 @@ int sfe_dsp_pipe_pull(sfe_pipe_t h, void *out, size_t max_items, int wait, size_
                 // whole reference calls first: the remainder -- less than one call -- goes out only when
                 // it is all there is, as the short last call a reference caller would make
                 const size_t whole = p->fill / p->quantum * p->quantum;
+                if (!whole && p->tx_gs) break;           // less than one 10-bit group: nothing the converter would emit
                 int rc = pipe_submit(p, whole ? whole : p->fill);
                 if (rc != SFE_OK) return rc;
                 continue;
@@ -2411,7 +2422,7 @@ int sfe_dsp_pipe_pending(sfe_pipe_t h, size_t *items)
 {
     FirPipe *p = as_pipe(h);
     if (!p || !items) return SFE_EINVAL;
-    size_t n = p->fill;
+    size_t n = p->tx_gs ? p->fill / p->tx_gs : p->fill;         // (10-bit output: in groups, the unit pull hands out)
     for (int i = 0; i < PIPE_SLOTS; i++)
         if (p->slot[i].busy) n += p->slot[i].n_out - (i == p->tail ? p->out_off : 0);
     *items = n;

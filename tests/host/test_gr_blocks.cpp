@@ -97,9 +97,69 @@ static std::vector<float> run_fir_batched(typename Block::sptr b, const std::vec
     return y;
 }
 
+static std::vector<unsigned char> slurp_bytes(const char *p)
+{
+    FILE *f = fopen(p, "rb");
+    if (!f) { perror(p); exit(2); }
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<unsigned char> v((size_t)n);
+    if (fread(v.data(), 1, v.size(), f) != v.size()) exit(2);
+    fclose(f);
+    return v;
+}
+
+// a wire-format block the way the scheduler drives it: byte streams in and / or out; in_sz / out_sz = item sizes,
+// out_mult = the block's output multiple (5 for the 10-bit format); input-less calls after the input ends, until
+// a call produces nothing
+template <class Sptr>
+static std::vector<unsigned char> run_wire(Sptr b, const unsigned char *x, size_t n_items, int in_sz, int out_sz, size_t out_items_max)
+{
+    std::vector<unsigned char> y((out_items_max + 65536) * (size_t)out_sz);
+    size_t off = 0, produced = 0;
+    int si = 0, idle = 0;
+    const int mult = b->output_multiple();
+    while (idle < 2) {
+        int room = sizes[si++ % 5];
+        room = room / mult * mult;
+        if (room == 0) room = mult;
+        gr_vector_int req(1, 0);
+        b->forecast(room, req);
+        const int avail = (int)(n_items - off < (size_t)sizes[si % 5] ? n_items - off : (size_t)sizes[si % 5]);
+        if (avail < req[0]) break;
+        gr_vector_int nin(1, avail);
+        gr_vector_const_void_star in(1, x + off * (size_t)in_sz);
+        gr_vector_void_star out(1, y.data() + produced * (size_t)out_sz);
+        const int r = b->general_work(room, nin, in, out);
+        if (r % mult) exit(4);
+        off += (size_t)b->consumed();
+        produced += (size_t)r;
+        idle = (r == 0 && b->consumed() == 0 && off == n_items) ? idle + 1 : 0;
+    }
+    y.resize(produced * (size_t)out_sz);
+    return y;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 5) return 2;
+    if (!strcmp(argv[1], "rx_fir") || !strcmp(argv[1], "fir_tx") || !strcmp(argv[1], "rx_fir_tx")) {
+        // wire-format blocks: x is a byte file (u8 (I,Q) pairs) for rx_*, a float file (interleaved cf32) for fir_tx
+        std::vector<float> taps = slurp(argv[2]);
+        std::vector<unsigned char> xb = slurp_bytes(argv[3]), yb;
+        if (!strcmp(argv[1], "rx_fir"))
+            yb = run_wire(gr::sfe::rx_fir_bc::make(taps, 8192), xb.data(), xb.size() / 2, 2, 8, xb.size() / 2);
+        else if (!strcmp(argv[1], "fir_tx"))
+            yb = run_wire(gr::sfe::fir_tx_cb::make(taps, 8192), xb.data(), xb.size() / 8, 8, 1, xb.size() / 8 / 2 * 5);
+        else
+            yb = run_wire(gr::sfe::rx_fir_tx_bb::make(taps, 8192), xb.data(), xb.size() / 2, 2, 1, xb.size() / 2 / 2 * 5);
+        FILE *f = fopen(argv[4], "wb");
+        fwrite(yb.data(), 1, yb.size(), f);
+        fclose(f);
+        printf("%zu\n", yb.size());
+        return 0;
+    }
     std::vector<float> taps = slurp(argv[2]), x = slurp(argv[3]);
     const int n = (int)(x.size() / 2);
     std::vector<float> y;

@@ -194,6 +194,49 @@ def test_gr_float_item_blocks_bit_exact(gr_exe, tmp_path, g5, orc):
     assert len(ref) - len(y) <= 2 and np.array_equal(y, ref[: len(y)])
 
 
+def test_gr_wire_format_blocks(gr_exe, tmp_path, orc):
+    """The FIR blocks that speak gr-simplefe's wire formats (include/gr_sfe/blocks.h: rx_fir_bc, fir_tx_cb,
+    rx_fir_tx_bb): u8 (I,Q) pairs in as source_c receives them (lib/source_c_impl.cc:121-132), 10-bit packed
+    bytes out as sink_c sends them (lib/sink_c_impl.cc:118-144), driven with scheduler-sized calls.
+    rx: within the bar of the oracle's converter -> filter; tx: the oracle's packing of the filter's own float
+    output, byte for byte except codes on a quantiser step (<= 1 LSB); whole 5-byte groups only."""
+    from simplefe_amd import api, lib, synth
+    taps = synth.taps_cfg2()
+    n = 100003                                        # odd: the last sample forms no group
+    raw = np.random.default_rng(11).integers(0, 256, size=2 * n, dtype=np.uint8)
+    taps.astype(np.float32).tofile(tmp_path / "t.f32")
+    raw.tofile(tmp_path / "x.u8")
+
+    def run(kind, xfile):
+        r = subprocess.run([gr_exe, kind, str(tmp_path / "t.f32"), str(tmp_path / xfile), str(tmp_path / "y.bin")],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return np.fromfile(tmp_path / "y.bin", dtype=np.uint8)
+
+    xf = orc.rx_u8_to_cf32(raw)                       # the receive converter, host twin
+    ref = np.empty(2 * n, np.float32)
+    for part in (0, 1):
+        ref[part::2] = orc.Blkconv(taps, 4096).stream(np.ascontiguousarray(xf[part::2]))
+    # receive: bytes in, gr_complex out
+    y = run("rx_fir", "x.u8").view(np.float32)
+    assert len(y) == 2 * n
+    for part in (0, 1):
+        assert synth.rel_rms(y[part::2], ref[part::2]) <= 1e-5
+    # transmit: gr_complex in, 10-bit bytes out
+    (0.6 * xf).astype(np.float32).tofile(tmp_path / "x.f32")
+    got = run("fir_tx", "x.f32")
+    want = orc.tx_f32_to_10bit((0.6 * ref).astype(np.float32))       # linear filter: 0.6 x -> 0.6 y, to float rounding
+    assert len(got) == (n // 2) * 5 == len(want)
+    dv = np.abs(_unpack10(got) - _unpack10(want))
+    assert dv.max() <= 1 and np.count_nonzero(dv) <= 0.004 * len(dv)
+    # wire to wire: the source_c -> FIR -> sink_c flowgraph as one block
+    got = run("rx_fir_tx", "x.u8")
+    want = orc.tx_f32_to_10bit(ref)
+    assert len(got) == (n // 2) * 5
+    dv = np.abs(_unpack10(got) - _unpack10(want))
+    assert dv.max() <= 1 and np.count_nonzero(dv) <= 0.004 * len(dv)
+
+
 # ------------------------------------------ bpsk pipeline end to end on the GPU path (N3)
 def _bpsk_stream(n_blocks, blk):
     """The process thread's symbol generator of examples/bpsk_gpu/bpsk_gpu.cpp, in Python."""
