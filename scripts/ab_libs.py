@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B of the SAME call through two builds of the library in one process (each loaded
-privately): ab_libs.py <libA.so> <libB.so> [real|cf32]   -- 256-tap FIR, 2^29 real / 2^28 cf32 samples."""
+privately): ab_libs.py <libA.so> <libB.so> [real|cf32|tx10|wire|rtx10|rwire]   -- 256-tap FIR, 2^29 real / 2^28 cf32 samples;
+tx10 = cf32 in, 10-bit packed out; wire = u8 (I,Q) bytes in, 10-bit packed out; rtx10 / rwire = the same for a real stream."""
 import ctypes as C
 import os
 import sys
@@ -12,7 +13,7 @@ from simplefe_amd import lib as L, synth  # noqa: E402
 
 paths = sys.argv[1:3]
 mode = sys.argv[3] if len(sys.argv) > 3 else "real"
-cplx = mode == "cf32"
+cplx = mode in ("cf32", "tx10", "wire")
 n = 1 << (28 if cplx else 29)
 libs = []
 for p in paths:
@@ -28,6 +29,10 @@ for h in libs:
     assert h.sfe_dsp_malloc(C.byref(x), 8 << 28) == 0 and h.sfe_dsp_malloc(C.byref(y), 8 << 28) == 0
     assert h.sfe_dsp_synth_fill(x, 2 << 28, synth.SEED, 0, 0, None) == 0
     assert h.sfe_dsp_fir_create(taps.ctypes.data, len(taps), 0, int(cplx), 1, 0, 0, C.byref(f)) == 0
+    if mode in ("wire", "rwire"):
+        assert h.sfe_dsp_fir_set_input_format(f, 1) == 0
+    if mode in ("tx10", "wire", "rtx10", "rwire"):
+        assert h.sfe_dsp_fir_set_output_format(f, 2) == 0
     assert h.sfe_dsp_timer_create(C.byref(t)) == 0
     st.append((h, x, y, f, t))
 res = [[], []]

@@ -538,6 +538,35 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             }
             const long long oA = 2 * blk * a.advance - a.hl, oB = oA + a.advance;
             const bool wholeA = 2 * blk * a.advance + a.advance <= a.n, wholeB = wholeA && oB + a.hl + a.advance <= a.n;
+            if (OUT_TX10 && wholeB && row0 == 1) {
+                if constexpr (OUT_TX10) {
+                // real stream into the transmit wire format, the common transform (both segments whole): thirty
+                // straight-line group stores through ONE buffer descriptor over the two segments' consecutive output
+                // bytes; lane 4g of a quad writes the group, the other three lanes' offsets lie beyond the records
+                char *const wb = out_c + (oA >> 2) * 5;                          // segment B's bytes follow at (advance / 4) * 5
+                const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(wb));
+                const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(wb) >> 32));
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo), 0, (2 * FFT_N / 4) * 5, 0x00020000);
+                int sel = (t & 3u) ? (int)0x7FFF0000 : (int)((t >> 2) * 5u);
+                asm volatile("" : "+v"(sel));
+                const int segB = (a.advance >> 2) * 5;                           // uniform
+#pragma unroll
+                for (int r = 1; r < 16; r++) {
+                    const v2f y = v[P16(r)];
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const unsigned u = (unsigned)((int)(short)(int)((q ? y.y : y.x) * 511.0f) + 512) & 0x3FFu;
+                        const unsigned u0 = quad_lane<0>(u), u1 = quad_lane<1>(u), u2 = quad_lane<2>(u), u3 = quad_lane<3>(u);
+                        const unsigned w = ((u0 >> 8) | ((u1 >> 8) << 2) | ((u2 >> 8) << 4) | ((u3 >> 8) << 6)) | ((u0 & 0xFFu) << 8) |
+                                           ((u1 & 0xFFu) << 16) | ((u2 & 0xFFu) << 24);
+                        const int up = 320 * r;                                  // (256 r / 4) groups of 5 bytes
+                        __builtin_amdgcn_raw_buffer_store_b32((int)w, rs, sel + up, q ? segB : 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)u3, rs, sel + up + 4, q ? segB : 0, 0);
+                    }
+                }
+                }
+            } else
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 if (r < row0) continue;
@@ -583,8 +612,35 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         // unconditionally and in ONE basic block with the last DFT16, so the scheduler may issue a row's store as
         // soon as its radix-4 group is done (DESIGN.md 9 lead (ii)); the guarded form below costs two branches and
         // ~10 scalar instructions per row and starts only after the whole DFT16.  DIAG bit 2: always the guarded form.
-        const bool plain_rows = !(DIAG & 4) && !(OUT_TX10 && OUT_C) && whole && row0 == 1;
-        if (plain_rows) {
+        const bool plain_rows = !(DIAG & 4) && whole && row0 == 1;
+        if (OUT_TX10 && OUT_C && plain_rows) {
+            if constexpr (OUT_TX10 && OUT_C) {
+            // complex stream into the transmit wire format, the common transform: fifteen straight-line group stores
+            // through ONE buffer descriptor over the transform's 9600 output bytes -- the even lane of a pair writes the
+            // group (its offset), the odd lane's offset lies beyond the descriptor's records and the hardware drops its
+            // store: no exec mask, no branch and no bounds test per row (the guarded form below has all three)
+            typedef int v1i;
+            char *const wb = out_c + (obase >> 1) * 5;                          // uniform; row r adds 640 r bytes, rows >= 1 only
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(wb));
+            const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(wb) >> 32));
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo), 0, (FFT_N / 2) * 5, 0x00020000);
+            int sel = (t & 1u) ? (int)0x7FFF0000 : (int)((t >> 1) * 5u);
+            asm volatile("" : "+v"(sel));
+#pragma unroll
+            for (int r = 1; r < 16; r++) {
+                const v2f y = v[P16(r)];
+                const unsigned u0 = (unsigned)((int)(short)(int)(y.x * 511.0f) + 512) & 0x3FFu;
+                const unsigned u1 = (unsigned)((int)(short)(int)(y.y * 511.0f) + 512) & 0x3FFu;
+                const unsigned u2 = quad_odd(u0), u3 = quad_odd(u1);
+                const unsigned w = ((u0 >> 8) | ((u1 >> 8) << 2) | ((u2 >> 8) << 4) | ((u3 >> 8) << 6)) | ((u0 & 0xFFu) << 8) |
+                                   ((u1 & 0xFFu) << 16) | ((u2 & 0xFFu) << 24);
+                const int up = 640 * r;                                          // (256 r / 2) groups of 5 bytes
+                __builtin_amdgcn_raw_buffer_store_b32((v1i)w, rs, sel + (up & 2047), up & ~2047, 0);
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)u3, rs, sel + (up & 2047) + 4, up & ~2047, 0);
+            }
+            }
+        } else if (plain_rows) {
             // Butterfly b completes rows b, b + 4, b + 8, b + 12 (fft16.h), so their stores could go out while
             // the remaining butterflies run (DESIGN.md 9 lead (ii)).  Written that way (DIAG bit 3, diagnostic
             // library only: variants y / u) the kernels SPILL -- 14 (LDS-DMA) to 26 (register loads) VGPRs, 22-54
