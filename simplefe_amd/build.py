@@ -34,14 +34,19 @@ def _deps():
 
 
 def csrc_hash():
-    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h: names and contents).  Stamped into
-    profiles/pmc_*.json when counters are collected; bench.py reports roofline.traffic only while
-    the stamp matches the tree (otherwise traffic: null, traffic_stale: true)."""
+    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h: file names and CODE -- `//` comments, blank
+    lines and indentation are left out, so that rewording a comment does not orphan a counter pass).
+    Stamped into profiles/pmc_*.json when counters are collected; bench.py reports roofline.traffic
+    only while the stamp matches the tree (otherwise traffic: null, traffic_stale: true)."""
     import hashlib
+    import re
     h = hashlib.sha256()
     for p in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))):
         h.update(os.path.basename(p).encode() + b"\0")
-        h.update(open(p, "rb").read())
+        for line in open(p, errors="replace"):
+            code = re.sub(r"\s+", " ", re.sub(r"//.*$", "", line)).strip()
+            if code:
+                h.update(code.encode() + b"\n")
         h.update(b"\0")
     return h.hexdigest()
 
