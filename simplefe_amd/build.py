@@ -34,7 +34,8 @@ def _deps():
 
 
 def csrc_hash():
-    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h: file names and CODE -- `//` comments, blank
+    """sha256 over the KERNEL sources (csrc/*.hip and csrc/*.h except api.hip, the host side: handles, plans,
+    launch choices -- what the counters count is the kernels' traffic; file names and CODE: `//` comments, blank
     lines and indentation are left out, so that rewording a comment does not orphan a counter pass).
     Stamped into profiles/pmc_*.json when counters are collected; bench.py reports roofline.traffic
     only while the stamp matches the tree (otherwise traffic: null, traffic_stale: true)."""
@@ -42,6 +43,8 @@ def csrc_hash():
     import re
     h = hashlib.sha256()
     for p in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))):
+        if os.path.basename(p) == "api.hip":
+            continue
         h.update(os.path.basename(p).encode() + b"\0")
         for line in open(p, errors="replace"):
             code = re.sub(r"\s+", " ", re.sub(r"//.*$", "", line)).strip()

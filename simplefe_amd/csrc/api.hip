@@ -619,8 +619,7 @@ static int fir_pick_variant(Fir *f, FirFftArgs &a, hipStream_t s, int *variant)
     // how they run at a clock the stream will never see again, so rounds go on until FIR_CAL_WARM_MS of
     // launches have run (and at least FIR_CAL_ROUNDS rounds) and only the last FIR_CAL_ROUNDS count
     float spent = 0.0f;
-    int rounds = 0;
-    for (int r = 0; r < FIR_CAL_MAX_ROUNDS && rc == SFE_OK && (r < FIR_CAL_ROUNDS || spent < FIR_CAL_WARM_MS); r++, rounds++)
+    for (int r = 0; r < FIR_CAL_MAX_ROUNDS && rc == SFE_OK && (r < FIR_CAL_ROUNDS || spent < FIR_CAL_WARM_MS); r++)
         for (int v = 0; v < nvar && rc == SFE_OK; v++) {
             a.variant = v;
             hipError_t e = hipEventRecord(e0, s);
@@ -636,7 +635,6 @@ static int fir_pick_variant(Fir *f, FirFftArgs &a, hipStream_t s, int *variant)
                 spent += ms;
             }
         }
-    (void)rounds;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (rc != SFE_OK) return rc;
@@ -1343,8 +1341,8 @@ int sfe_dsp_fir_set_output_format(sfe_fir_t h, int fmt)
 {
     Fir *f = as_fir(h);
     if (!f || (fmt != SFE_FMT_F32 && fmt != SFE_FMT_TX10)) return SFE_EINVAL;
-    if (f->piped && fmt != SFE_FMT_F32) {
-        set_error("fir_set_output_format: a pipe over this handle hands out float32 items (destroy the pipe first)");
+    if (f->piped && (fmt == SFE_FMT_TX10) != (f->out_tx10 != 0)) {
+        set_error("fir_set_output_format: a pipe over this handle has frozen its item format (destroy the pipe first)");
         return SFE_ESTATE;
     }
     if (fmt == SFE_FMT_TX10 && f->fft_ok && f->parts > 1 && f->data_complex == f->out_complex) {
