@@ -472,6 +472,25 @@ def test_rs_bulk_fft_path_cf32(api, L, orc, monkeypatch, U, S, n_taps, n, nch, c
             assert synth.rel_rms(got, ref[: len(got)]) <= TOL, (c, part)
 
 
+@pytest.mark.parametrize("chunk", [None, 70000])
+def test_rs_fft_path_channels_in_one_launch_equal_one_handle_per_channel(api, L, chunk):
+    """Round 3: the transform-domain kernel draws the passes of ALL channels from its work counters
+    (channel-major tickets) and writes every channel's next history itself.  Seven channels through
+    one handle -- one launch per call -- give, channel for channel and bit for bit, what seven
+    single-channel handles give, over chunked calls (carried history and time state per channel)."""
+    taps, U, S = synth.taps_cfg3(), 3, 5
+    rate = float(np.float32(S) / np.float32(U))
+    n, nch = 210007, 7
+    x = np.stack([synth.synth_cf32(n, ch=30 + c) for c in range(nch)])
+    many = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=True, n_channels=nch, algo=L.RS_ALGO_FFT)
+    y = many.resample_array(x, rate, chunk=chunk)
+    for c in range(nch):
+        one = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=True, algo=L.RS_ALGO_FFT)
+        yc = one.resample_array(x[c:c + 1], rate, chunk=chunk)[0]
+        assert yc.shape == y[c].shape and np.array_equal(yc, y[c]), c
+        one.close()
+
+
 @pytest.mark.parametrize("U,S,n_taps,n,nch,chunk", [
     (3, 5, 381, 100000, 1, None), (3, 5, 381, 250001, 2, 65536), (2, 3, 200, 90001, 1, None),
     (1, 4, 256, 80000, 2, 30001), (1, 8, 600, 120000, 1, None), (4, 5, 700, 90000, 1, None),
