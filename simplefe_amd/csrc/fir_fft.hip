@@ -377,7 +377,9 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             unsigned keep;
             // rows 0 and 15 (with hl = 256: the halo this transform re-reads and the one its successor will)
             // may stay in the L2: no nontemporal hint on their pieces when the launcher says so
-            const bool shared_row = !WP && ((a.halo_keep >> (4u * wv + (unsigned)(p >> 1))) & 1u);      // halo_keep: a mask over the 16 rows
+            // (WP: piece p carries rows p and p + 8 of the wave's columns -- kept when either row is in the mask)
+            const bool shared_row = WP ? (((a.halo_keep >> (unsigned)p) | (a.halo_keep >> (unsigned)(p + 8))) & 1u) != 0
+                                       : ((a.halo_keep >> (4u * wv + (unsigned)(p >> 1))) & 1u) != 0;      // halo_keep: a mask over the 16 rows
             if (shared_row)
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(off), "s"(gp), "s"(dst) : "memory");
