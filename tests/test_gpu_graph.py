@@ -155,36 +155,33 @@ def test_rs_call_captured_once_replays_the_next_chunks(api, L, which, U, S, n_ta
 
 
 def test_calls_whose_state_would_move_refuse_to_be_captured(api, L):
-    """A captured call whose replay would need host-side state is refused loudly, not replayed wrongly."""
+    """A captured call whose replay would need host-side state is refused loudly, not replayed wrongly:
+    a resampler call that leaves the time state elsewhere than it found it, a FIR call shorter than
+    the history."""
     hip = Hip()
-    taps = synth.taps_cfg3()
-    r = api.Rs(taps, 3, 4096, mode=L.RS_RESAMPLE, data_complex=True)
-    n = 5 * 231 * 40 + 1                                   # n*U not a multiple of the step
+    r = api.Rs(synth.taps_cfg3(), 3, 4096, mode=L.RS_RESAMPLE, data_complex=True)
+    f = api.Fir(synth.taps_cfg2(), data_complex=True)
+    n = 5 * 231 * 40 + 1                                   # n*U is not a multiple of the step 5
     d_in, d_out = api.DeviceArray(2 * n), api.DeviceArray(2 * n)
     d_in.zero()
-    r.process_stream(d_in, n - 1, d_out, n, 5.0 / 3.0)
+    r.process_stream(d_in, n - 1, d_out, n, 5.0 / 3.0)     # eager first: plans and tables exist
     api.sync()
-    errs = []
-    f = api.Fir(synth.taps_cfg2(), data_complex=True)
-
-    def body2(st):
-        try:
-            f.process_stream(d_in, d_out, 100, stream=st)           # shorter than the history
-        except api.SfeError as e:
-            errs.append(e.code)
+    codes = []
     s = C.c_void_p()
     hip.ok(hip.h.hipStreamCreate(C.byref(s)))
-    hip.ok(hip.h.hipStreamBeginCapture(s, 2))              # relaxed: the refused calls launch nothing
+    hip.ok(hip.h.hipStreamBeginCapture(s, 2))              # relaxed mode: the refused calls launch nothing
     try:
-        try:
-            r.process_stream(d_in, n, d_out, n, 5.0 / 3.0, stream=s.value)
-        except api.SfeError as e:
-            errs.append(e.code)
-        body2(s.value)
+        for call in (lambda: r.process_stream(d_in, n, d_out, n, 5.0 / 3.0, stream=s.value),
+                     lambda: f.process_stream(d_in, d_out, 100, stream=s.value)):
+            try:
+                call()
+                codes.append(L.SFE_OK)
+            except api.SfeError as e:
+                codes.append(e.code)
     finally:
         g = C.c_void_p()
         hip.h.hipStreamEndCapture(s, C.byref(g))
-    assert errs == [L.SFE_ESTATE, L.SFE_ESTATE], errs
+    assert codes == [L.SFE_ESTATE, L.SFE_ESTATE], codes
     if g.value:
         hip.h.hipGraphDestroy(g)
     hip.h.hipStreamDestroy(s)
