@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B of the SAME call through two builds of the library in one process (each loaded
-privately): ab_libs.py <libA.so> <libB.so> [real|cf32|tx10|wire|rtx10|rwire]   -- 256-tap FIR, 2^29 real / 2^28 cf32 samples;
-tx10 = cf32 in, 10-bit packed out; wire = u8 (I,Q) bytes in, 10-bit packed out; rtx10 / rwire = the same for a real stream."""
+privately): ab_libs.py <libA.so> <libB.so> [real|cf32|tx10|wire|rtx10|rwire|decimate|resample]   -- 256-tap FIR, 2^29 real / 2^28 cf32 samples;
+tx10 = cf32 in, 10-bit packed out; wire = u8 (I,Q) bytes in, 10-bit packed out; rtx10 / rwire = the same for a real stream; decimate = by 8, 64 taps, 2^30 cf32; resample = 5/3, 381 taps, 2^28 cf32."""
 import ctypes as C
 import os
 import sys
@@ -23,12 +23,20 @@ for p in paths:
             getattr(h, name).restype, getattr(h, name).argtypes = res, args
     libs.append(h)
 taps = synth.taps_cfg2()
+rs = mode in ("decimate", "resample")
+if rs:
+    taps, U, rate, n = (synth.taps_cfg4(), 1, 8.0, 1 << 30) if mode == "decimate" else (synth.taps_cfg3(), 3, float(np.float32(5) / np.float32(3)), 1 << 28)
+    cap = int(n / rate) + 64
 st = []
 for h in libs:
     x, y, f, t = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
-    assert h.sfe_dsp_malloc(C.byref(x), 8 << 28) == 0 and h.sfe_dsp_malloc(C.byref(y), 8 << 28) == 0
-    assert h.sfe_dsp_synth_fill(x, 2 << 28, synth.SEED, 0, 0, None) == 0
-    assert h.sfe_dsp_fir_create(taps.ctypes.data, len(taps), 0, int(cplx), 1, 0, 0, C.byref(f)) == 0
+    nx = (8 << 30) if mode == "decimate" else (8 << 28)
+    assert h.sfe_dsp_malloc(C.byref(x), nx) == 0 and h.sfe_dsp_malloc(C.byref(y), 8 << 28) == 0
+    assert h.sfe_dsp_synth_fill(x, nx // 4, synth.SEED, 0, 0, None) == 0
+    if rs:
+        assert h.sfe_dsp_rs_create(taps.ctypes.data, len(taps), U, 4096, 1, 1, 0, 1 if mode == "decimate" else 0, C.byref(f)) == 0
+    else:
+        assert h.sfe_dsp_fir_create(taps.ctypes.data, len(taps), 0, int(cplx), 1, 0, 0, C.byref(f)) == 0
     if mode in ("wire", "rwire"):
         assert h.sfe_dsp_fir_set_input_format(f, 1) == 0
     if mode in ("tx10", "wire", "rtx10", "rwire"):
@@ -40,7 +48,11 @@ for r in range(int(os.environ.get("ROUNDS", "10")) + 1):
     for i, (h, x, y, f, t) in enumerate(st):
         h.sfe_dsp_timer_start(t, None)
         for _ in range(5):
-            assert h.sfe_dsp_fir_process_stream(f, x, y, n, n, n, None) == 0
+            if rs:
+                k = C.c_size_t(0)
+                assert h.sfe_dsp_rs_process_stream(f, x, n, n, y, cap, cap, rate, C.byref(k), None) == 0
+            else:
+                assert h.sfe_dsp_fir_process_stream(f, x, y, n, n, n, None) == 0
         h.sfe_dsp_timer_stop(t, None)
         ms = C.c_float(0)
         h.sfe_dsp_timer_elapsed_ms(t, C.byref(ms))
