@@ -76,6 +76,21 @@ __global__ __launch_bounds__(256) void k_mix81(const v2f *in, v2f *out, size_t n
     }
 }
 
+// 5 parts read, 3 parts written (the 5/3 resampler's mix): a workgroup reads 10 x 256 8-byte lanes and writes 6 x 256
+// (the resampler's pass is 2310 samples in, 1386 out), all loads first, as that kernel issues them
+__global__ __launch_bounds__(256) void k_mix53(const v2f *in, v2f *out, size_t n_tiles)
+{
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const v2f *p = in + tile * (size_t)(10 * 256) + threadIdx.x;
+        v2f v[10];
+#pragma unroll
+        for (int u = 0; u < 10; u++) v[u] = __builtin_nontemporal_load(p + 256 * u);
+        v2f *q = out + tile * (size_t)(6 * 256) + threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < 6; u++) __builtin_nontemporal_store(v[u] + v[9 - u], q + 256 * u);
+    }
+}
+
 template <typename F>
 static void timeit(const char *name, double bytes, F launch)
 {
@@ -107,6 +122,14 @@ int main(int argc, char **argv)
     CK(hipMalloc(&out, bytes));
     CK(hipMemset(in, 1, bytes));
     CK(hipMemset(out, 0, bytes));
+    if (argc > 1 && argv[1][0] == '5') {       // only the resampler's mix (profiles/r03/hbm_mix_5to3.txt)
+        const size_t tiles = bytes / 8 / (10 * 256);
+        for (int g : {1024, 2048, 8192, 65536, (int)tiles}) {
+            printf("-- grid %d x 256 threads\n", g);
+            timeit("mix 5:3, 10 x 8 B loads, 6 x 8 B stores", 1.6 * (double)(tiles * 10 * 256 * 8), [&] { hipLaunchKernelGGL(k_mix53, dim3(g), dim3(256), 0, 0, (const v2f *)in, (v2f *)out, tiles); });
+        }
+        return 0;
+    }
     const int grids[] = {2048, 8192, 65536, 262144};
     for (int g : grids) {
         printf("-- grid %d x 256 threads\n", g);
