@@ -29,6 +29,9 @@ cd $R
 bash scripts/prof_pmc.sh prof_${TAG}_sq_fir fir_fft4096 -- python3 $R/bench.py --workload fir --steps 3 --warmup 1 --no-cpu --no-others > /dev/null 2>&1 || exit 1
 bash scripts/prof_pmc.sh prof_${TAG}_sq_decimate poly_tiled -- python3 $R/bench.py --workload decimate --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1 || exit 1
 bash scripts/prof_pmc.sh prof_${TAG}_sq_resample poly_fft256 -- python3 $R/bench.py --workload resample --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1 || exit 1
+# COUNTERS_ONLY=1: stop here -- the kernel-trace / counter passes above are what is stamped with the source hash; the tables
+# below are interleaved A/B runs of named variants and stay valid while those variants' code does
+if [ -n "$COUNTERS_ONLY" ]; then echo collected counters; exit 0; fi
 # ablation / variant tables from the diagnostic library (regenerable: scripts/ablate.py, scripts/ab_fir.py, scripts/ab_rs.py)
 mkdir -p $R/gpurun_out/prof_${TAG}_tables
 timeout -k 10 300 python3 scripts/ablate.py fir > gpurun_out/prof_${TAG}_tables/fir_variants_ab.txt 2>&1 || exit 1

@@ -89,7 +89,8 @@ __device__ __forceinline__ unsigned pf_cell(unsigned c, unsigned k)
 // TICKET: passes are drawn from per-XCD work counters instead of walked at a fixed stride
 // (fir_fft.hip has the reasoning and the measurements), channel-major over all channels.
 // LATE (diagnostic): 1 = the next pass's samples are requested after S3 instead of before it,
-// 2 = the first half of its segments before S3 and the second half after.
+// 2 = the first half of its segments before S3 and the second half after, 3 = a whole pass AHEAD: requested right
+// after S0 has staged the current pass (the draw runs one pass further ahead), held in registers through S1..S3.
 template <int SP, int UP, int R, bool IN_U8, bool PAIR, int DIAG = 0, bool TICKET = false, int LATE = 0, int WPS = 4>
 __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
 {
@@ -300,6 +301,15 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
             else reinterpret_cast<v2f *>(ho)[i] = smp;
         }
     };
+    // LATE == 3: the pass after `first` is known before the loop starts (and every later one a pass ahead)
+    [[maybe_unused]] long long nx = LATE == 3 ? first + gridDim.x : 0;
+    [[maybe_unused]] int nxch = ch;
+    if constexpr (TICKET && LATE == 3) {
+        if (t == 0) s_next = first < a.n_pass ? draw() : 0xFFFFFFFFu;
+        lds_barrier();
+        decode(__builtin_amdgcn_readfirstlane(s_next), nxch, nx);
+        lds_barrier();
+    }
     long long prev = -1;       // pass whose inverse transforms run in this iteration
     int pch = ch;              // ... and its channel
     v2f s[R * SP];
@@ -370,8 +380,22 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
             }
         }
         lds_barrier();
+        if constexpr (LATE == 3) {      // s[] was consumed by S0: the next pass's samples have S1..S3 to land
+            if (nx < a.n_pass) {
+                cur_wide = pass_is_wide(nxch, nx);
+                if (cur_wide) {
+                    load_pass_wide(raw, in_of(nxch), nx);
+                } else if (!WIDE) {
+                    cur_fast = pass_interior(nx);
+                    if (cur_fast) load_pass(s, in_of(nxch), nx);
+                }
+            } else {
+                cur_wide = cur_fast = false;
+            }
+        }
         unsigned drawn = 0u;
-        const bool drawing = TICKET && cur;
+        bool drawing = TICKET && cur;
+        if constexpr (LATE == 3) drawing = drawing && nx < a.n_pass;      // one failing draw per workgroup either way
         if (drawing && t == 0) drawn = draw_issue();       // finished and published before the barrier that ends S2
         // ---- S1: the transform (forward groups: staged samples; inverse groups: Y of the last pass)
         v2f v[16];
@@ -493,7 +517,9 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
         // v[] is dead and the next pass's samples are not requested yet: the point of least register pressure
         if (a.hist_out && cur && pass == 0) carry_history(ch);
         // request the next pass's samples now: v[] is dead, they land while S3 and the barrier run
-        // (requesting them a whole pass ahead instead measured the same: latency is not what binds)
+        // (requesting them a whole pass ahead -- LATE == 3, variants A / B of the diagnostic library -- needs three
+        // workgroups per CU or spills, and is no faster than this point at the same residency:
+        // profiles/r03/resample_ahead.txt.  Latency is not what binds.)
         auto request_next = [&](int sg_lo, int sg_hi) {
             if (next < a.n_pass) {
                 cur_wide = pass_is_wide(nch, next);
@@ -529,8 +555,15 @@ __global__ __launch_bounds__(256, WPS) void poly_fft256_kernel(PolyFftArgs a)
         if (LATE == 2) request_next((R + 1) / 2, R);
         prev = cur ? pass : -1;
         pch = ch;
-        pass = next;
-        ch = nch;
+        if constexpr (LATE == 3) {      // `next` / `nch` decoded above are the pass AFTER nx
+            pass = nx;
+            ch = nxch;
+            nx = TICKET ? next : nx + gridDim.x;
+            nxch = nch;
+        } else {
+            pass = next;
+            ch = nch;
+        }
     }
 }
 
@@ -636,6 +669,8 @@ int launch_poly_fft(const PolyFftPlan &plan, const PolyFftArgs &a0, int data_com
             if (e[0] == 'z') return launch_one<5, 3, 2, false, false, 32, true, 0>(a, n_channels, s);        // t without the S0 scatter writes (bound for LDS-DMA staging)
             if (e[0] == 'Z') return launch_one<5, 3, 2, false, false, 48, true, 0>(a, n_channels, s);        // neither the scatter nor the exchange
             if (e[0] == 'y') return launch_one<5, 3, 2, false, false, 32, true, 0, 3>(a, n_channels, s);     // z at 3 workgroups per CU
+            if (e[0] == 'A') return launch_one<5, 3, 2, false, false, 0, true, 3, 3>(a, n_channels, s);      // samples requested a whole pass ahead, 3 workgroups per CU (168 VGPRs)
+            if (e[0] == 'B') return launch_one<5, 3, 2, false, false, 0, true, 3, 4>(a, n_channels, s);      // ... at 4 per CU (spills)
         }
     }
 #endif
