@@ -124,6 +124,7 @@ struct PolyTiledArgs {
     const void *hist;
     void       *hist_out = nullptr;   // if non-null (needs n_in >= hl): one extra workgroup per channel writes the next call's history
     unsigned    tiles = 0;            // set by the launcher: tiles per channel (blockIdx.x == tiles is that extra workgroup)
+    unsigned    tpw = 1;              // poly_stream_kernel: consecutive tiles per workgroup (the extra workgroup is blockIdx.x == ceil(tiles / tpw))
     const float *G;
     long long   n_in, in_stride, out_stride, n_out;
     int         hl, Lp, e_max;

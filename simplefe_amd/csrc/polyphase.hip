@@ -15,6 +15,7 @@
 //                       (libdsp/resample.cxx:119-150).
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -252,7 +253,10 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
     // STEPs alternate two register sets so no pair is ever copied.
     const int nchunk = a.Lp / SP;                                   // even (host pads Lp)
     const P2 *xp = reinterpret_cast<const P2 *>(X) + tid + nchunk / 2;   // pair column (2*tid + cc)/2
-    const float *g = a.G + (size_t)(nchunk - 1) * SP;               // taps of chunk cc+1
+    // DIAG bit 2: the taps through the constant address space (scalar loads) instead of the generic pointer (vector loads
+    // with a uniform address) -- A/B in the diagnostic library
+    typedef const __attribute__((address_space(4))) float *cfp;
+    typename std::conditional<(DIAG & 4) != 0, cfp, const float *>::type g = (typename std::conditional<(DIAG & 4) != 0, cfp, const float *>::type)a.G + (size_t)(nchunk - 1) * SP;               // taps of chunk cc+1
     auto step = [&](P2 (&cur)[SP], const P2 (&nxt)[SP]) {
         xp -= 1;
 #pragma unroll
@@ -327,6 +331,250 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
         for (int i = 0; i < UP; i++) __builtin_nontemporal_store(Yp[tid + 256 * i], op + tid + 256 * i);
     }
 }
+
+#ifdef SFE_DIAG
+// ------------------------------------------------------ integer-step decimation, streamed (UP == 1)
+// DIAGNOSTIC LIBRARY ONLY (SFE_TILED_TPW=N, scripts/ab_dec.py tN): measured 3-10 % SLOWER than one tile per workgroup
+// on every box (profiles/r03/decimate_stream.txt) -- kept as the record of that experiment.
+// The same tile, the same LDS image and the same dot products as poly_tiled_kernel -- bit-identical results --
+// for the bulk decimator (UP == 1, fused arithmetic, float32 input, Lp <= 256): a workgroup takes a.tpw CONSECUTIVE
+// tiles, and
+//   * tile i + 1's SP*TM body samples are requested (into registers) as soon as tile i's have been staged, so they
+//     travel while tile i's dot products and stores run: the one-tile kernel has loads in flight for about half of a
+//     workgroup's life and LDS, not registers, bounds its residency (4 workgroups per CU at 70 VGPRs);
+//   * the Lp samples two consecutive tiles share stay in LDS (the last columns of tile i are the first of tile
+//     i + 1): every input sample is read from HBM once.
+// Workgroups whose tiles touch the history, the end of the input or the end of the output take the guarded
+// per-tile path (the first and the last workgroup of a channel).
+template <int SP, int UP, bool CPLX, bool EXACT>
+__device__ __forceinline__ void tiled_dot(const typename Elem<CPLX>::T *X, const float *G, int Lp, unsigned tid,
+                                          typename Elem<CPLX>::T (&acc)[2][UP])
+{
+    typedef typename Pair<CPLX>::P P2;
+    constexpr int ROWLEN = tiled_rowlen(SP);
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int r = 0; r < UP; r++) acc[b][r] = Elem<CPLX>::zero();
+    const int nchunk = Lp / SP;                                     // even (host pads Lp)
+    const P2 *xp = reinterpret_cast<const P2 *>(X) + tid + nchunk / 2;   // pair column (2*tid + cc)/2
+    // The taps are read through the CONSTANT address space: wave-uniform loads from it become scalar loads
+    // (s_load_dwordx4..x16 into SGPRs).  Through the generic pointer the compiler emits vector loads
+    // (global_load_dwordx4 with a uniform address), and a wait for one of those is a wait for every older
+    // vector-memory operation of the wave -- here the next tile's sixteen body loads, i.e. the whole prefetch.
+    typedef const __attribute__((address_space(4))) float *cfp;
+    cfp g = (cfp)G + (size_t)(nchunk - 1) * SP;                     // taps of chunk cc+1
+    auto step = [&](P2 (&cur)[SP], const P2 (&nxt)[SP]) {
+        xp -= 1;
+#pragma unroll
+        for (int p = 0; p < SP; p++) cur[p] = xp[p * (ROWLEN / 2)];
+#pragma unroll
+        for (int p = SP - 1; p >= 0; --p) {                          // chunk cc+1
+#pragma unroll
+            for (int r = 0; r < UP; r++) {
+                const float t = g[r * Lp + p];                       // wave-uniform
+                acc[0][r] = mac<EXACT>(acc[0][r], t, pair_hi(cur[p]));
+                acc[1][r] = mac<EXACT>(acc[1][r], t, pair_lo(nxt[p]));
+            }
+        }
+#pragma unroll
+        for (int p = SP - 1; p >= 0; --p) {                          // chunk cc
+#pragma unroll
+            for (int r = 0; r < UP; r++) {
+                const float t = g[r * Lp + p - SP];
+                acc[0][r] = mac<EXACT>(acc[0][r], t, pair_lo(cur[p]));
+                acc[1][r] = mac<EXACT>(acc[1][r], t, pair_hi(cur[p]));
+            }
+        }
+        g -= 2 * SP;
+    };
+    P2 pa[SP], pb[SP];
+#pragma unroll
+    for (int p = 0; p < SP; p++) pa[p] = xp[p * (ROWLEN / 2)];      // pairs at column 2*tid + nchunk
+    int steps = nchunk / 2;
+    if (steps & 1) {                                                 // odd count: peel one, landing in pa
+        step(pb, pa);
+#pragma unroll
+        for (int p = 0; p < SP; p++) pa[p] = pb[p];
+        steps--;
+    }
+    for (; steps > 0; steps -= 2) {
+        step(pb, pa);
+        step(pa, pb);
+    }
+}
+
+template <int SP, bool CPLX>
+__global__ __launch_bounds__(256, 4) void poly_stream_kernel(PolyTiledArgs a)      // 4 per SIMD: what the 37 KB tile image allows anyway
+{
+    typedef typename Elem<CPLX>::T T;
+    typedef typename Pair<CPLX>::P P2;
+    constexpr int ROWLEN = tiled_rowlen(SP);
+    constexpr int MAIN = SP * TM / 256;       // body loads per thread and tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T *X = reinterpret_cast<T *>(smem);
+
+    const unsigned tid = threadIdx.x;
+    const int ch = blockIdx.y;
+    const T *in = static_cast<const T *>(a.in) + (size_t)ch * a.in_stride;
+    const T *hist = static_cast<const T *>(a.hist) + (size_t)ch * a.hl;
+    T *out = static_cast<T *>(a.out) + (size_t)ch * a.out_stride;
+
+    const unsigned groups = (a.tiles + a.tpw - 1u) / a.tpw;
+    if (blockIdx.x == groups) {                  // the history workgroup (poly_tiled_kernel has the reasoning); the launcher adds it only with hist_out
+        T *ho = static_cast<T *>(a.hist_out) + (size_t)ch * a.hl;
+#pragma unroll 1
+        for (unsigned i = tid; i < (unsigned)a.hl; i += 256u) ho[i] = in[a.n_in - a.hl + i];
+        return;
+    }
+    const long long t0 = (long long)blockIdx.x * a.tpw;
+    const long long t1 = t0 + a.tpw < (long long)a.tiles ? t0 + a.tpw : (long long)a.tiles;
+    const int n_tile = SP * TM + a.Lp;
+    const long long org0 = (long long)SP * TM * t0 + a.e_max - (a.Lp - 1);          // stream index of tile t0's local sample 0
+    const long long org_last = org0 + (long long)SP * TM * (t1 - 1 - t0);
+    const bool fast = org0 >= 0 && org_last + n_tile <= a.n_in && t1 * TM <= a.n_out &&
+                      (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    T acc[2][1];
+    if (!fast) {
+        for (long long t = t0; t < t1; t++) {
+            const long long n_org = org0 + (long long)SP * TM * (t - t0);
+            for (unsigned s = tid; s < (unsigned)n_tile; s += 256)
+                X[(s % SP) * ROWLEN + s / SP] = vload<CPLX>(in, hist, n_org + s, a.n_in, a.hl);
+            __syncthreads();
+            tiled_dot<SP, 1, CPLX, false>(X, a.G, a.Lp, tid, acc);
+            const long long k = t * TM + 2 * tid;
+            if (k < a.n_out) out[k] = acc[0][0];
+            if (k + 1 < a.n_out) out[k + 1] = acc[1][0];
+            __syncthreads();                     // everyone is done reading X
+        }
+        return;
+    }
+
+    const unsigned uLp = (unsigned)a.Lp, C0 = uLp / SP;
+    const T *src = in + org0;                                           // uniform
+    if (tid < uLp) X[(tid % SP) * ROWLEN + tid / SP] = __builtin_nontemporal_load(src + tid);      // head of the first tile
+    T v[MAIN];
+#pragma unroll
+    for (int i = 0; i < MAIN; i++) v[i] = __builtin_nontemporal_load(src + uLp + tid + 256u * i);
+    // cell of body sample j = tid + 256 i (local sample Lp + j, Lp a multiple of SP): row j % SP, column C0 + j / SP;
+    // j = SP (q0 + c_i) + (r0 + d_i) with compile-time c_i, d_i (poly_tiled_kernel)
+    const unsigned q0 = tid / SP, r0 = tid % SP;
+    const unsigned cell0 = r0 * ROWLEN + q0 + C0;
+    const unsigned carry_src = r0 * ROWLEN + TM + q0, carry_dst = r0 * ROWLEN + q0;
+    P2 w = {};
+    for (long long t = t0;; t++) {
+#pragma unroll
+        for (int i = 0; i < MAIN; i++) {
+            constexpr unsigned W = SP * ROWLEN - 1;         // row wrap: -SP rows, +1 column
+            const unsigned ci = (256u * i) / SP, di = (256u * i) % SP;
+            const unsigned cell = cell0 + di * ROWLEN + ci;
+            X[(r0 + di >= (unsigned)SP) ? cell - W : cell] = v[i];
+        }
+        __syncthreads();
+        // the PREVIOUS tile's outputs go out here, in front of the next tile's requests: vector-memory operations
+        // retire in issue order, so a store issued behind those requests (right after its dot products) would be
+        // waited for -- write acknowledge included -- by the wait for the samples at the top of the next iteration
+        if (t > t0) __builtin_nontemporal_store(w, reinterpret_cast<P2 *>(out + (t - 1) * TM) + tid);
+        const bool more = t + 1 < t1;
+        if (more) {
+            src += SP * TM;
+#pragma unroll
+            for (int i = 0; i < MAIN; i++) v[i] = __builtin_nontemporal_load(src + uLp + tid + 256u * i);
+        }
+        tiled_dot<SP, 1, CPLX, false>(X, a.G, a.Lp, tid, acc);
+        if constexpr (CPLX) w = (v4f){acc[0][0].x, acc[0][0].y, acc[1][0].x, acc[1][0].y};
+        else w = (v2f){acc[0][0], acc[1][0]};
+        if (!more) {
+            __builtin_nontemporal_store(w, reinterpret_cast<P2 *>(out + t * TM) + tid);
+            break;
+        }
+        T carry = Elem<CPLX>::zero();
+        if (tid < uLp) carry = X[carry_src];     // the Lp samples the next tile starts with
+        __syncthreads();                         // every read of this tile's image is done
+        if (tid < uLp) X[carry_dst] = carry;
+    }
+}
+
+// Diagnostic (SFE_TILED_TPW=-N): the streamed decimator with its N tiles taken at the stride of the grid instead of
+// consecutively -- the tiles in flight chip-wide are then always consecutive ones (one compact window, as with one tile
+// per workgroup) and nothing is carried in LDS: every tile loads its whole span, the next tile's in flight meanwhile.
+template <int SP, bool CPLX>
+__global__ __launch_bounds__(256, 4) void poly_stream_strided_kernel(PolyTiledArgs a)
+{
+    typedef typename Elem<CPLX>::T T;
+    typedef typename Pair<CPLX>::P P2;
+    constexpr int ROWLEN = tiled_rowlen(SP);
+    constexpr int MAIN = SP * TM / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T *X = reinterpret_cast<T *>(smem);
+    const unsigned tid = threadIdx.x;
+    const int ch = blockIdx.y;
+    const T *in = static_cast<const T *>(a.in) + (size_t)ch * a.in_stride;
+    const T *hist = static_cast<const T *>(a.hist) + (size_t)ch * a.hl;
+    T *out = static_cast<T *>(a.out) + (size_t)ch * a.out_stride;
+    const unsigned groups = (a.tiles + a.tpw - 1u) / a.tpw;
+    if (blockIdx.x == groups) {
+        T *ho = static_cast<T *>(a.hist_out) + (size_t)ch * a.hl;
+#pragma unroll 1
+        for (unsigned i = tid; i < (unsigned)a.hl; i += 256u) ho[i] = in[a.n_in - a.hl + i];
+        return;
+    }
+    const int n_tile = SP * TM + a.Lp;
+    const unsigned uLp = (unsigned)a.Lp;
+    const bool al = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    auto org_of = [&](long long t) { return (long long)SP * TM * t + a.e_max - (a.Lp - 1); };
+    auto interior = [&](long long t) { return t < (long long)a.tiles && org_of(t) >= 0 && org_of(t) + n_tile <= a.n_in && (t + 1) * TM <= a.n_out && al; };
+    T v[MAIN], vt = Elem<CPLX>::zero();
+    auto request = [&](long long t) {
+        const T *src = in + org_of(t);
+#pragma unroll
+        for (int i = 0; i < MAIN; i++) v[i] = __builtin_nontemporal_load(src + tid + 256u * i);
+        if (tid < uLp) vt = __builtin_nontemporal_load(src + SP * TM + tid);
+    };
+    const unsigned q0 = tid / SP, r0 = tid % SP;
+    const unsigned cell0 = r0 * ROWLEN + q0;
+    long long t = blockIdx.x;
+    bool got = interior(t);
+    if (got) request(t);
+    P2 w = {};
+    long long tw = -1;              // tile whose outputs wait in w
+    T acc[2][1];
+    for (; t < (long long)a.tiles; t += groups) {
+        if (got) {
+#pragma unroll
+            for (int i = 0; i < MAIN; i++) {
+                constexpr unsigned W = SP * ROWLEN - 1;
+                const unsigned ci = (256u * i) / SP, di = (256u * i) % SP;
+                const unsigned cell = cell0 + di * ROWLEN + ci;
+                X[(r0 + di >= (unsigned)SP) ? cell - W : cell] = v[i];
+            }
+            if (tid < uLp) X[r0 * ROWLEN + TM + q0] = vt;
+        } else {
+            const long long n_org = org_of(t);
+            for (unsigned s = tid; s < (unsigned)n_tile; s += 256)
+                X[(s % SP) * ROWLEN + s / SP] = vload<CPLX>(in, hist, n_org + s, a.n_in, a.hl);
+        }
+        __syncthreads();
+        if (tw >= 0) __builtin_nontemporal_store(w, reinterpret_cast<P2 *>(out + tw * TM) + tid);
+        tw = -1;
+        const bool cur_fast = got;
+        got = interior(t + groups);
+        if (got) request(t + groups);
+        tiled_dot<SP, 1, CPLX, false>(X, a.G, a.Lp, tid, acc);
+        if (cur_fast) {
+            if constexpr (CPLX) w = (v4f){acc[0][0].x, acc[0][0].y, acc[1][0].x, acc[1][0].y};
+            else w = (v2f){acc[0][0], acc[1][0]};
+            tw = t;
+        } else {
+            const long long k = t * TM + 2 * tid;
+            if (k < a.n_out) out[k] = acc[0][0];
+            if (k + 1 < a.n_out) out[k + 1] = acc[1][0];
+        }
+        __syncthreads();                         // every read of this tile's image is done
+    }
+    if (tw >= 0) __builtin_nontemporal_store(w, reinterpret_cast<P2 *>(out + tw * TM) + tid);
+}
+#endif
 
 // ------------------------------------------- integer-step law on the matrix pipe (f32 MFMA)
 // OPT-IN (sfe_dsp_rs_set_algo(h, SFE_RS_ALGO_MFMA)), kept as measured evidence.  The 127-tap-per-arm resampler is VALU-bound
@@ -674,12 +922,47 @@ int launch_poly_tiled(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int da
     dim3 grid((unsigned)tiles + (a.hist_out ? 1u : 0u), (unsigned)n_channels), block(256);      // + the history workgroup
     const size_t esz = data_complex ? 8 : 4;
 #ifdef SFE_DIAG
+    // the streamed decimator (poly_stream_kernel): runs of consecutive tiles per workgroup with the next tile's samples
+    // in flight -- measured slower than one tile per workgroup, selectable in the diagnostic library only
+    if (plan.UP == 1 && !exact && !in_u8 && plan.Lp <= 256) {
+        long long tpw = 1;
+        if (const char *e = getenv("SFE_TILED_TPW")) tpw = atoi(e);
+        if (tpw <= -2 && plan.SP == 8 && data_complex) {          // the tiles of a workgroup at the stride of the grid (diagnostic)
+            a.tpw = (unsigned)-tpw;
+            const unsigned groups = (unsigned)((tiles + a.tpw - 1) / a.tpw);
+            dim3 sgrid(groups + (a.hist_out ? 1u : 0u), (unsigned)n_channels);
+            hipLaunchKernelGGL((poly_stream_strided_kernel<8, true>), sgrid, block, (size_t)8 * tiled_rowlen(8) * esz, s, a);
+            SFE_HIP(hipGetLastError());
+            return SFE_OK;
+        }
+        if (tpw >= 2) {
+            a.tpw = (unsigned)tpw;
+            const unsigned groups = (unsigned)((tiles + tpw - 1) / tpw);
+            dim3 sgrid(groups + (a.hist_out ? 1u : 0u), (unsigned)n_channels);
+#define SFE_S(SPv)                                                                                    \
+    case SPv: {                                                                                       \
+        const size_t sh = (size_t)SPv * tiled_rowlen(SPv) * esz;                                      \
+        if (data_complex) hipLaunchKernelGGL((poly_stream_kernel<SPv, true>), sgrid, block, sh, s, a);  \
+        else hipLaunchKernelGGL((poly_stream_kernel<SPv, false>), sgrid, block, sh, s, a);             \
+        SFE_HIP(hipGetLastError());                                                                   \
+        return SFE_OK;                                                                                \
+    }
+            switch (plan.SP) {
+                SFE_S(2) SFE_S(3) SFE_S(4) SFE_S(5) SFE_S(8)      // (10: twenty body loads per thread do not fit beside the dot product's registers)
+            default: break;
+            }
+#undef SFE_S
+        }
+    }
+#endif
+#ifdef SFE_DIAG
     if (const char *e = getenv("SFE_TILED_DIAG")) {          // decimate by 8, cf32, fused numerics only
         const int dg = atoi(e);
         if (dg && plan.SP == 8 && plan.UP == 1 && data_complex && !exact && !in_u8) {
             const size_t sh = (size_t)8 * tiled_rowlen(8) * esz;
             if (dg == 1) hipLaunchKernelGGL((poly_tiled_kernel<8, 1, true, false, false, 1>), grid, block, sh, s, a);
             else if (dg == 2) hipLaunchKernelGGL((poly_tiled_kernel<8, 1, true, false, false, 2>), grid, block, sh, s, a);
+            else if (dg == 4) hipLaunchKernelGGL((poly_tiled_kernel<8, 1, true, false, false, 4>), grid, block, sh, s, a);
             else hipLaunchKernelGGL((poly_tiled_kernel<8, 1, true, false, false, 3>), grid, block, sh, s, a);
             SFE_HIP(hipGetLastError());
             return SFE_OK;
