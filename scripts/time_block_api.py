@@ -25,6 +25,11 @@ def per_call(fn):
     return (time.perf_counter() - t0) / reps * 1e6
 
 
+# the floor under every per-block call: one trivial kernel launched and waited for (a 4-byte memset + a synchronise)
+_d = api.DeviceArray(16)
+us = per_call(lambda: (api.check(L.sfe_dsp_memset(_d.ptr, 0, 4, None)), api.check(L.sfe_dsp_sync(None))))
+print(f"floor: a 4-byte device memset + synchronise: {us:6.1f} us per call")
+
 b = api.blkconv(np.real(taps), 4096)
 blk = b.get_blksize()
 b.get_process_buf()[:blk] = np.random.default_rng(1).standard_normal(blk).astype(np.float32)
