@@ -198,6 +198,22 @@ int sfe_dsp_fir_pipe_create(sfe_fir_t fir, size_t batch_items, sfe_pipe_t *out);
 int sfe_dsp_pipe_push(sfe_pipe_t p, const void *in, size_t n_items, size_t *n_taken);
 int sfe_dsp_pipe_pull(sfe_pipe_t p, void *out, size_t max_items, int wait, size_t *n_got);
 int sfe_dsp_pipe_pending(sfe_pipe_t p, size_t *items);
+/* The same pipe without the two host copies -- what get_process_buf() is to blkconv (libdsp/blkconv.h:44-47:
+ * the caller works in the object's own buffer): the producer writes its items straight into the pipe's pinned
+ * input batch and the consumer reads finished items in place in the pinned output batch (a callback that
+ * receives device samples, simpleFE.c:625-653, or a generator such as bpsk.cxx:145-159 has no buffer of its own
+ * to copy from).  May be mixed freely with push / pull on the same pipe; same items, same order.
+ *   acquire  *buf = where the next item goes, *room_items = how many fit before the batch is sent on its way
+ *            (0, *buf NULL: every batch is in flight -- take finished items out first).  The pointer is valid until
+ *            the next commit / push on this pipe.
+ *   commit   n_items (<= room) have been written at the acquired pointer; a full batch is sent on its way.
+ *   peek     *out = the oldest finished items, *n_items of them contiguous (0: none ready); wait as for pull.
+ *            The pointer is valid until they are released.
+ *   release  n_items (<= what peek reported) have been consumed. */
+int sfe_dsp_pipe_acquire(sfe_pipe_t p, void **buf, size_t *room_items);
+int sfe_dsp_pipe_commit(sfe_pipe_t p, size_t n_items);
+int sfe_dsp_pipe_peek(sfe_pipe_t p, const void **out, size_t *n_items, int wait);
+int sfe_dsp_pipe_release(sfe_pipe_t p, size_t n_items);
 int sfe_dsp_pipe_destroy(sfe_pipe_t p);
 /* Fused receive converter: with SFE_FMT_U8 the bulk call reads the device
  * wire format directly -- u8 offset binary, one byte per real sample or an (I,Q) byte pair per

@@ -2365,6 +2365,63 @@ int sfe_dsp_pipe_push(sfe_pipe_t h, const void *in, size_t n_items, size_t *n_ta
     return SFE_OK;
 }
 
+// The oldest finished items, in place: *ptr / *count describe what is left of the oldest batch in flight once its
+// copy-out has completed (count 0: nothing is ready).  wait: 0 = never block, 1 = block for that batch, 2 = also send a
+// partly filled batch on its way when nothing else is in flight (end of stream / drain) and block for it.
+static int pipe_front(FirPipe *p, int wait, const char **ptr, size_t *count)
+{
+    *ptr = nullptr;
+    *count = 0;
+    for (;;) {
+        FirPipe::Slot &sl = p->slot[p->tail];
+        if (!sl.busy) {
+            if (wait == 2 && p->fill > 0 && p->tail == p->head) {
+                // whole reference calls first (ADVICE r2): the remainder -- less than one call -- goes out only when
+                // it is all there is, as the short last call a reference caller would make
+                const size_t whole = p->fill / p->quantum * p->quantum;
+                if (!whole && p->tx_gs) return SFE_OK;   // less than one 10-bit group: nothing the converter would emit
+                int rc = pipe_submit(p, whole ? whole : p->fill);
+                if (rc != SFE_OK) return rc;
+                continue;
+            }
+            return SFE_OK;
+        }
+        if (!p->tail_ready) {
+            if (wait) {
+                SFE_HIP(hipEventSynchronize(sl.ev_out));
+            } else {
+                hipError_t e = hipEventQuery(sl.ev_out);
+                if (e == hipErrorNotReady) return SFE_OK;
+                if (e != hipSuccess) return hip_fail(e, "hipEventQuery");
+            }
+            p->tail_ready = true;
+        }
+        if (sl.n_out == p->out_off) {        // a batch that produced nothing (a decimator fed less than one step): retire it
+            sl.busy = false;
+            p->tail = (p->tail + 1) % PIPE_SLOTS;
+            p->out_off = 0;
+            p->tail_ready = false;
+            continue;
+        }
+        *ptr = sl.h_out + p->out_off * p->out_e;
+        *count = sl.n_out - p->out_off;
+        return SFE_OK;
+    }
+}
+
+// `m` of the items pipe_front described have been consumed
+static void pipe_advance(FirPipe *p, size_t m)
+{
+    FirPipe::Slot &sl = p->slot[p->tail];
+    p->out_off += m;
+    if (p->out_off == sl.n_out) {
+        sl.busy = false;
+        p->tail = (p->tail + 1) % PIPE_SLOTS;
+        p->out_off = 0;
+        p->tail_ready = false;
+    }
+}
+
 int sfe_dsp_pipe_pull(sfe_pipe_t h, void *out, size_t max_items, int wait, size_t *n_got)
 {
     FirPipe *p = as_pipe(h);
@@ -2372,47 +2429,72 @@ int sfe_dsp_pipe_pull(sfe_pipe_t h, void *out, size_t max_items, int wait, size_
     *n_got = 0;
     SFE_ON_DEVICE(p->device);
     char *dst = static_cast<char *>(out);
-    bool block_now = wait != 0;          // wait == 1 blocks for the oldest batch only, wait == 2 for all of them
+    int w = wait;                        // wait == 1 blocks for the oldest batch only, wait == 2 for all of them
     while (max_items) {
-        FirPipe::Slot &sl = p->slot[p->tail];
-        if (!sl.busy) {
-            // nothing submitted: with wait == 2 a partly filled batch is sent on its way (end of stream / drain)
-            if (wait == 2 && p->fill > 0 && p->tail == p->head) {
-                // whole reference calls first (ADVICE r2): the remainder -- less than one call -- goes out only when
-                // it is all there is, as the short last call a reference caller would make
-                const size_t whole = p->fill / p->quantum * p->quantum;
-                if (!whole && p->tx_gs) break;           // less than one 10-bit group: nothing the converter would emit
-                int rc = pipe_submit(p, whole ? whole : p->fill);
-                if (rc != SFE_OK) return rc;
-                continue;
-            }
-            break;
-        }
-        if (!p->tail_ready) {
-            if (block_now) {
-                SFE_HIP(hipEventSynchronize(sl.ev_out));
-                if (wait == 1) block_now = false;
-            } else {
-                hipError_t e = hipEventQuery(sl.ev_out);
-                if (e == hipErrorNotReady) break;
-                if (e != hipSuccess) return hip_fail(e, "hipEventQuery");
-            }
-            p->tail_ready = true;
-        }
-        size_t m = sl.n_out - p->out_off;
+        const char *src;
+        size_t m;
+        int rc = pipe_front(p, w, &src, &m);
+        if (rc != SFE_OK) return rc;
+        if (!m) break;
+        if (wait == 1) w = 0;
         if (m > max_items) m = max_items;
-        copy_stream(dst, sl.h_out + p->out_off * p->out_e, m * p->out_e);
+        copy_stream(dst, src, m * p->out_e);
         dst += m * p->out_e;
-        p->out_off += m;
         max_items -= m;
         *n_got += m;
-        if (p->out_off == sl.n_out) {
-            sl.busy = false;
-            p->tail = (p->tail + 1) % PIPE_SLOTS;
-            p->out_off = 0;
-            p->tail_ready = false;
-        }
+        pipe_advance(p, m);
     }
+    return SFE_OK;
+}
+
+int sfe_dsp_pipe_acquire(sfe_pipe_t h, void **buf, size_t *room_items)
+{
+    FirPipe *p = as_pipe(h);
+    if (!p || !buf || !room_items) return SFE_EINVAL;
+    *buf = nullptr;
+    *room_items = 0;
+    FirPipe::Slot &sl = p->slot[p->head];
+    if (sl.busy) return SFE_OK;          // every batch in flight: take finished items out first
+    *buf = sl.h_in + p->fill * p->in_e;
+    *room_items = p->batch - p->fill;
+    return SFE_OK;
+}
+
+int sfe_dsp_pipe_commit(sfe_pipe_t h, size_t n_items)
+{
+    FirPipe *p = as_pipe(h);
+    if (!p) return SFE_EINVAL;
+    if (p->slot[p->head].busy ? n_items != 0 : n_items > p->batch - p->fill) {
+        set_error("pipe_commit: %zu items exceed the room the last acquire reported", n_items);
+        return SFE_EINVAL;
+    }
+    SFE_ON_DEVICE(p->device);
+    p->fill += n_items;
+    if (p->fill == p->batch) return pipe_submit(p, p->fill);
+    return SFE_OK;
+}
+
+int sfe_dsp_pipe_peek(sfe_pipe_t h, const void **out, size_t *n_items, int wait)
+{
+    FirPipe *p = as_pipe(h);
+    if (!p || !out || !n_items) return SFE_EINVAL;
+    SFE_ON_DEVICE(p->device);
+    const char *src;
+    int rc = pipe_front(p, wait, &src, n_items);
+    *out = src;
+    return rc;
+}
+
+int sfe_dsp_pipe_release(sfe_pipe_t h, size_t n_items)
+{
+    FirPipe *p = as_pipe(h);
+    if (!p) return SFE_EINVAL;
+    FirPipe::Slot &sl = p->slot[p->tail];
+    if (n_items && (!sl.busy || !p->tail_ready || n_items > sl.n_out - p->out_off)) {
+        set_error("pipe_release: %zu items exceed what the last peek reported", n_items);
+        return SFE_EINVAL;
+    }
+    if (n_items) pipe_advance(p, n_items);
     return SFE_OK;
 }
 

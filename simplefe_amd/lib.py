@@ -64,6 +64,10 @@ SIGNATURES = {
     "sfe_dsp_pipe_push": (i32, [vp, vp, sz, C.POINTER(sz)]),
     "sfe_dsp_pipe_pull": (i32, [vp, vp, sz, i32, C.POINTER(sz)]),
     "sfe_dsp_pipe_pending": (i32, [vp, C.POINTER(sz)]),
+    "sfe_dsp_pipe_acquire": (i32, [vp, C.POINTER(vp), C.POINTER(sz)]),
+    "sfe_dsp_pipe_commit": (i32, [vp, sz]),
+    "sfe_dsp_pipe_peek": (i32, [vp, C.POINTER(vp), C.POINTER(sz), i32]),
+    "sfe_dsp_pipe_release": (i32, [vp, sz]),
     "sfe_dsp_pipe_destroy": (i32, [vp]),
     "sfe_dsp_fir_load_history": (i32, [vp, vp, sz, sz, vp]),
     "sfe_dsp_rs_load_history": (i32, [vp, vp, sz, sz, vp]),

@@ -985,6 +985,74 @@ def test_rs_pipe_equals_the_reference_stream(api, L, orc, U, rate, blk, n_taps, 
     assert 0 <= len(ref) - k <= 1 and np.array_equal(out[:k], ref[:k])
 
 
+def test_pipe_without_host_copies_equals_push_and_pull(api, L):
+    """sfe_dsp_pipe_acquire / commit / peek / release: the producer writes into the pipe's pinned batch, the consumer
+    reads finished items in place (blkconv.h:44-47's get_process_buf() idea).  Same items in the same order as push /
+    pull, also when the two forms are mixed on one pipe; room and availability are enforced."""
+    import ctypes as C
+    lib = L.load()
+    taps = synth.taps_cfg2()
+    n = 300001
+    x = synth.synth_cf32(n, ch=5)
+
+    def run(mixed, copies=False):
+        f = api.Fir(taps, data_complex=True)
+        p = C.c_void_p()
+        api.check(lib.sfe_dsp_fir_pipe_create(f._h, 16384, C.byref(p)))
+        out = np.zeros(n, np.complex64)
+        buf, room, got, taken = C.c_void_p(), C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        src = C.c_void_p()
+        off = k = i = 0
+        sizes = [4096, 1000, 8191, 37, 20000]
+
+        def take(wait):
+            nonlocal k
+            if copies:
+                api.check(lib.sfe_dsp_pipe_pull(p, out.ctypes.data + 8 * k, 5000, wait, C.byref(got)))
+                k += got.value
+                return got.value
+            api.check(lib.sfe_dsp_pipe_peek(p, C.byref(src), C.byref(got), wait))
+            if got.value:
+                m = got.value if not mixed or (k & 1) == 0 else max(1, got.value // 3)      # partial releases too
+                out[k:k + m] = np.frombuffer((C.c_char * (8 * m)).from_address(src.value), np.complex64)
+                api.check(lib.sfe_dsp_pipe_release(p, m))
+                k += m
+            return got.value
+
+        while off < n:
+            want = min(sizes[i % 5], n - off)
+            i += 1
+            if copies or (mixed and i % 3 == 0):
+                api.check(lib.sfe_dsp_pipe_push(p, x.ctypes.data + 8 * off, want, C.byref(taken)))
+                off += taken.value
+                moved = taken.value
+            else:
+                api.check(lib.sfe_dsp_pipe_acquire(p, C.byref(buf), C.byref(room)))
+                moved = min(want, room.value)
+                if moved:
+                    C.memmove(buf.value, x.ctypes.data + 8 * off, 8 * moved)
+                    api.check(lib.sfe_dsp_pipe_commit(p, moved))
+                    off += moved
+            take(0 if moved else 1)
+        while take(2):
+            pass
+        # the contracts: nothing to release, nothing beyond the reported room
+        assert lib.sfe_dsp_pipe_release(p, 1) == L.SFE_EINVAL
+        api.check(lib.sfe_dsp_pipe_acquire(p, C.byref(buf), C.byref(room)))
+        assert room.value == 16384 and lib.sfe_dsp_pipe_commit(p, room.value + 1) == L.SFE_EINVAL
+        lib.sfe_dsp_pipe_destroy(p)
+        f.close()
+        assert k == n
+        return out
+
+    f = api.Fir(taps, data_complex=True)
+    bulk = f.filter(x.view(np.float32)).reshape(-1).view(np.complex64)
+    f.close()
+    ref = run(False, copies=True)          # push / pull: the same batches, hence the same transform positions and the same bits
+    assert np.array_equal(run(False), ref) and np.array_equal(run(True), ref)
+    assert np.sqrt(np.sum(np.abs(ref - bulk) ** 2) / np.sum(np.abs(bulk) ** 2)) < 1e-6      # (one bulk call cuts its transforms elsewhere)
+
+
 @pytest.mark.parametrize("cplx", [True, False])
 def test_fir_pipe_takes_the_u8_wire_format(api, L, orc, cplx):
     """sfe_dsp_fir_pipe_* over a handle whose input format is the receive wire format: u8 items in (2 bytes per
