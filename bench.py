@@ -187,6 +187,14 @@ def cpu_baseline_fir(taps, budget_s):
                                              orc.blkconv_stream_mt(taps, 4096, br, C, want_output=False)),
                                   nb, 0.4 * budget_s)
     out["host_cores"] = host_cores()
+    # BASELINE configs[0] ("plumbing, CPU only -- report CPU MS/s, no GPU number"): the 63-tap real
+    # filter at the block size libdsp/test uses it with, 2^20 real float32 samples through the same port, one thread
+    t1 = synth.taps_cfg1()
+    x1 = synth.synth_f32(1 << 20)
+    c1 = orc.Blkconv(t1, 1024)
+    reps, dt = _timed_reps(lambda: c1.stream(x1), 0.5, 64)
+    out["configs0_cpu_only"] = {"value": reps * (1 << 20) / dt / 1e6, "unit": "MS/s (real samples)", "cores": 1,
+                                "sample": f"{reps} x 2^20 real float32 samples, 63 taps, fft_len 1024 (blk 962), {dt:.1f} s"}
     return out
 
 
