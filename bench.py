@@ -43,6 +43,8 @@ BEFORE anything touches the GPU and relays rank 0's line.  It never prints an n_
                 sample of the same workload, rank 0, N = 1 only: `value` on one thread (the
                 reference is single-threaded), `all_cores` on every host core (spans with
                 n_taps-1 samples of overlap), `host_cores` stated.  A reported baseline.
+                `configs0_cpu_only` (fir workload) = BASELINE configs[0], the CPU-only plumbing case:
+                63-tap real filter, 2^20 real float32 samples, fft_len 1024, same port, one thread.
 """
 import argparse
 import json
