@@ -3,15 +3,21 @@
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from simplefe_amd import api, lib, synth
+from simplefe_amd import lib
+if os.environ.get("SFE_LIB"):                      # a saved build to compare against
+    lib.LIB_PATH = os.environ["SFE_LIB"]
+from simplefe_amd import api, synth
 log2n = int(os.environ.get("LOG2N", "24"))
 n = 1 << log2n
-taps = synth.lowpass_taps(31, 0.18, gain=4.0)
 x = api.DeviceArray(2 * n); x.fill_synth(synth.SEED)
-cap = int(n / 1.77) + 16
+cap = int(n / 1.77) + 8192
 y = api.DeviceArray(2 * cap)
-r = api.Rs(taps, 4, 4096, mode=lib.RS_RESAMPLE, data_complex=True)
-for rate in (1.77, 2.0):
+# a short filter (31 taps in 4 phases: 8 per dot product) and BASELINE cfg3's (381 taps in 3 phases: 127 per dot product)
+for name, taps, U, rates in (("31 taps, U = 4", synth.lowpass_taps(31, 0.18, gain=4.0), 4, (1.77, 2.0)),
+                             ("381 taps, U = 3", synth.taps_cfg3(), 3, (1.77,))):
+  r = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=True)
+  print(f"-- {name}")
+  for rate in rates:
     r.reset()
     t0 = time.perf_counter()
     r.process_stream(x, n, y, cap, rate); api.sync()

@@ -802,6 +802,8 @@ struct Rs {
     float *h_mu = nullptr;
     void *d_segs = nullptr, *d_chunks = nullptr, *h_segs = nullptr, *h_chunks = nullptr;   // run-length plans
     size_t segs_cap = 0, chunks_cap = 0;
+    hipEvent_t ev_plan = nullptr;          // recorded behind a call's plan uploads: the pinned staging is free again once it fires
+    hipStream_t plan_stream = nullptr;     // ... on this stream (the device-side plan arrays are ordered by it)
     // General rate: the plan of one blksize-sample reference call depends only on the time state the call
     // starts in, and that state is a multiple of the float32 grid of the call's LAST binade inside
     // [-1, step) -- a few thousand possible values (blksize*U = 16384: 2^-10 apart) -- so plans are
@@ -811,8 +813,11 @@ struct Rs {
     struct SegPlanRef {
         int seg_first, n_seg, n_out;
         sfe_rs_timestate after;
+        int next = -1;                     // index of the plan for the state this call ends in, once it has been met:
+                                           // a stream of full-size calls then walks the plans by index, no hashing
     };
-    std::unordered_map<uint64_t, SegPlanRef> seg_memo;
+    std::unordered_map<uint64_t, int> seg_memo;      // start state -> index into seg_refs
+    std::vector<SegPlanRef> seg_refs;
     std::vector<TlSeg> seg_table;          // runs of the memoised calls, in the order they were first met
     size_t seg_uploaded = 0;               // leading entries of seg_table already in d_segs
     float memo_rate = 0.0f;                // the memo is for one (rate, blksize)
@@ -854,6 +859,7 @@ static void rs_free(Rs *r)
     if (r->d_chunks) (void)hipFree(r->d_chunks);
     if (r->h_segs) (void)hipHostFree(r->h_segs);
     if (r->h_chunks) (void)hipHostFree(r->h_chunks);
+    if (r->ev_plan) (void)hipEventDestroy(r->ev_plan);
     if (r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
 }
@@ -1798,6 +1804,7 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         sfe_rs_timestate st = r->ts;
         if (r->memo_rate != rate || r->memo_m != r->blksize) {
             r->seg_memo.clear();
+            r->seg_refs.clear();
             r->seg_table.clear();
             r->seg_uploaded = 0;
             r->memo_rate = rate;
@@ -1810,6 +1817,7 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         chunks.reserve(n_in / (size_t)r->blksize + 1);
         size_t K = 0;
         int max_m = 0;
+        int prev_ref = -1;          // plan of the previous (memoised) call of this launch: its `next` link is followed / filled in
         for (size_t off = 0; off < n_in; off += (size_t)r->blksize) {
             const int m = (int)((n_in - off) < (size_t)r->blksize ? (n_in - off) : (size_t)r->blksize);
             const int cap = (int)ceilf((float)m / rate) + 2;
@@ -1818,24 +1826,35 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
             c.k_first = (long long)K;
             c.m = m;
             if (m == r->blksize && r->seg_table.size() < MEMO_MAX_SEGS) {
-                uint32_t mu_bits;
-                memcpy(&mu_bits, &st.mu, 4);
-                const uint64_t key = ((uint64_t)(uint32_t)(st.pos + 1) << 33) | ((uint64_t)mu_bits << 1) | (uint64_t)(st.leftover ? 1 : 0);   // pos >= -1
-                auto it = r->seg_memo.find(key);
-                if (it == r->seg_memo.end()) {
-                    Rs::SegPlanRef ref;
-                    ref.seg_first = (int)r->seg_table.size();
-                    ref.n_out = time_law_segments(&st, r->U, m, cap, rate, r->seg_table);
-                    ref.n_seg = (int)r->seg_table.size() - ref.seg_first;
-                    ref.after = st;
-                    it = r->seg_memo.emplace(key, ref).first;
-                } else {
-                    st = it->second.after;
+                int idx = prev_ref >= 0 ? r->seg_refs[(size_t)prev_ref].next : -1;
+                if (idx < 0) {
+                    uint32_t mu_bits;
+                    memcpy(&mu_bits, &st.mu, 4);
+                    const uint64_t key = ((uint64_t)(uint32_t)(st.pos + 1) << 33) | ((uint64_t)mu_bits << 1) | (uint64_t)(st.leftover ? 1 : 0);   // pos >= -1
+                    auto it = r->seg_memo.find(key);
+                    if (it == r->seg_memo.end()) {
+                        Rs::SegPlanRef ref;
+                        ref.seg_first = (int)r->seg_table.size();
+                        sfe_rs_timestate st2 = st;
+                        ref.n_out = time_law_segments(&st2, r->U, m, cap, rate, r->seg_table);
+                        ref.n_seg = (int)r->seg_table.size() - ref.seg_first;
+                        ref.after = st2;
+                        idx = (int)r->seg_refs.size();
+                        r->seg_refs.push_back(ref);
+                        r->seg_memo.emplace(key, idx);
+                    } else {
+                        idx = it->second;
+                    }
+                    if (prev_ref >= 0) r->seg_refs[(size_t)prev_ref].next = idx;
                 }
-                c.seg_first = it->second.seg_first;
-                c.n_seg = it->second.n_seg;
-                c.n_out = it->second.n_out;
+                const Rs::SegPlanRef &ref = r->seg_refs[(size_t)idx];
+                st = ref.after;
+                c.seg_first = ref.seg_first;
+                c.n_seg = ref.n_seg;
+                c.n_out = ref.n_out;
+                prev_ref = idx;
             } else {
+                prev_ref = -1;
                 c.seg_first = (int)extra.size();                 // + the table's final size, below
                 c.n_out = time_law_segments(&st, r->U, m, cap, rate, extra);
                 c.n_seg = (int)extra.size() - c.seg_first;
@@ -1866,9 +1885,16 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         sa.plen = r->plen;
         sa.n_chunks = (int)chunks.size();
         sa.max_m = max_m;
-        // plan tables: grow-only device + pinned staging; the previous call's copies may still be
-        // reading the staging, so wait for the stream before overwriting it
-        SFE_HIP(hipStreamSynchronize(s));
+        // plan tables: grow-only device arrays + pinned staging.  The previous call's UPLOADS may still be reading the
+        // staging: wait for them -- the event behind them -- not for the stream: that call's kernel runs on while this
+        // call is planned and queued (waiting for the stream here made every call a full host/device round trip).
+        // The device arrays themselves are ordered by the stream; a call on ANOTHER stream than the last waits for that one.
+        if (r->ev_plan) {
+            if (r->plan_stream != s) SFE_HIP(hipStreamSynchronize(r->plan_stream));
+            else SFE_HIP(hipEventSynchronize(r->ev_plan));
+        } else {
+            SFE_HIP(hipEventCreateWithFlags(&r->ev_plan, hipEventDisableTiming));
+        }
         if (n_segs > r->segs_cap) {
             if (r->d_segs) (void)hipFree(r->d_segs);
             if (r->h_segs) (void)hipHostFree(r->h_segs);
@@ -1903,6 +1929,8 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         }
         memcpy(r->h_chunks, chunks.data(), chunks.size() * sizeof(SegChunk));
         SFE_HIP(hipMemcpyAsync(r->d_chunks, r->h_chunks, chunks.size() * sizeof(SegChunk), hipMemcpyHostToDevice, s));
+        SFE_HIP(hipEventRecord(r->ev_plan, s));
+        r->plan_stream = s;
         sa.segs = r->d_segs;
         sa.chunks = static_cast<const SegChunk *>(r->d_chunks);
         rc = launch_poly_seg(sa, r->data_complex, r->exact_stream, r->n_channels, s);
@@ -1922,6 +1950,7 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
                 }
             rc = rs_ensure_sched(r, K + 1);
             if (rc != SFE_OK) return rc;
+            SFE_HIP(hipStreamSynchronize(s));        // the schedule staging may still be read by the previous call's uploads
             memcpy(r->h_pos, pos.data(), K * sizeof(long long));
             memcpy(r->h_mu, mu.data(), K * sizeof(float));
             SFE_HIP(hipMemcpyAsync(r->d_pos, r->h_pos, K * sizeof(long long), hipMemcpyHostToDevice, s));

@@ -774,6 +774,10 @@ struct DevSeg {          // == sfe::TlSeg (timelaw.h), restated here to keep thi
     int    k0, count, pad;
 };
 constexpr int SEG_MAX_LDS = 96;
+// >= plen + 1 (the shifted rows read one tap further), a multiple of 4 floats, and never a multiple of 64 floats: a wave's
+// lanes read up to U different rows at once (one per phase), and rows a multiple of 256 bytes apart would put the same
+// tap of every phase on the same banks -- a U-way conflict on every 16-byte tap read
+__host__ __device__ constexpr int seg_row(int plen) { return ((plen + 4) & ~3) % 64 == 0 ? ((plen + 4) & ~3) + 4 : (plen + 4) & ~3; }
 
 template <bool CPLX, bool EXACT>
 __global__ __launch_bounds__(256) void poly_seg_kernel(PolySegArgs a)
@@ -781,8 +785,13 @@ __global__ __launch_bounds__(256) void poly_seg_kernel(PolySegArgs a)
     typedef typename Elem<CPLX>::T T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DevSeg *sg = reinterpret_cast<DevSeg *>(smem);
+    // taps in LDS twice, rows padded to a multiple of four floats (16-byte rows): ts[ph][j] = taps[ph][j] and the same
+    // rows one tap to the left, tsh[ph][j] = taps[ph][j + 1] -- whichever a lane's second dot product needs (below),
+    // four taps come with one aligned 16-byte read
+    const int plp = seg_row(a.plen);
     float *ts = reinterpret_cast<float *>(smem + SEG_MAX_LDS * sizeof(DevSeg));
-    T *xs = reinterpret_cast<T *>(smem + SEG_MAX_LDS * sizeof(DevSeg) + (((size_t)a.U * a.plen * 4 + 15) & ~(size_t)15));
+    float *tsh = ts + (size_t)a.U * plp;
+    T *xs = reinterpret_cast<T *>(smem + SEG_MAX_LDS * sizeof(DevSeg) + (size_t)2 * a.U * plp * 4);
 
     const SegChunk c = a.chunks[blockIdx.x];
     const int ch = blockIdx.y;
@@ -793,24 +802,103 @@ __global__ __launch_bounds__(256) void poly_seg_kernel(PolySegArgs a)
 
     const int nsl = c.n_seg < SEG_MAX_LDS ? c.n_seg : SEG_MAX_LDS;
     for (int i = threadIdx.x; i < nsl; i += 256) sg[i] = gseg[i];
-    for (int i = threadIdx.x; i < a.U * a.plen; i += 256) ts[i] = a.taps[i];
+    for (int i = threadIdx.x; i < a.U * plp; i += 256) {
+        const int ph = i / plp, j = i - ph * plp;
+        ts[i] = j < a.plen ? a.taps[ph * a.plen + j] : 0.0f;
+        tsh[i] = j + 1 < a.plen ? a.taps[ph * a.plen + j + 1] : 0.0f;
+    }
     // tile: samples in_off - plen .. in_off + m - 1   (pos >= -1 reaches back plen samples)
     const int n_tile = c.m + a.plen;
-    for (int i = threadIdx.x; i < n_tile; i += 256) xs[i] = vload<CPLX>(in, hist, c.in_off - a.plen + i, a.n_in, a.hl);
+    const long long tile0 = c.in_off - a.plen;
+    if (tile0 >= 0 && tile0 + n_tile <= a.n_in) {
+        // an interior call: its samples are requested eight per thread at a time, all in flight together.  Through the
+        // guarded loop below every iteration is a branchy load -> wait -> LDS write of its own, one memory latency after
+        // the other: seventeen of them were ~25 of the ~29 us a workgroup took (2^28 samples at rate 1.77: 2.3 -> see
+        // profiles/r03/general_rate.txt)
+        const T *src = in + tile0;
+        for (int i0 = (int)threadIdx.x; i0 < n_tile; i0 += 256 * 8) {
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = i0 + 256 * u;
+                v[u] = i < n_tile ? __builtin_nontemporal_load(src + i) : Elem<CPLX>::zero();
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = i0 + 256 * u;
+                if (i < n_tile) xs[i] = v[u];
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < n_tile; i += 256) xs[i] = vload<CPLX>(in, hist, tile0 + i, a.n_in, a.hl);
+    }
     __syncthreads();
 
-    auto dot = [&](long long p) -> T {
-        const long long n = floordiv(p, a.U);
-        const int ph = (int)(p - n * a.U);
-        const float *tp = ts + ph * a.plen;
+    // floor(p / U) and p mod U without the 64-bit division (two per output, ~100 instructions each): inside a chunk p
+    // is small -- -U <= p < (m + 1) U -- so p + U is an unsigned 32-bit number and its quotient by the uniform U is one
+    // v_mul_hi by ceil(2^32 / U), exact while (p + U) U < 2^32 (U a power of two: the multiplier is 2^32 / U, exact
+    // outright).  Anything outside that range -- only the reference's out_len-exhausted state gets there -- takes the
+    // general path.
+    const unsigned Uu = (unsigned)a.U, Minv = Uu > 1u ? 0xFFFFFFFFu / Uu + 1u : 0u;
+    const long long fast_hi = (long long)(0xFFFFFFFFu / Uu) - Uu;
+    auto split = [&](long long p, long long &n, int &ph) {
+        if (p >= -(long long)Uu && p < fast_hi) {
+            const unsigned pu = (unsigned)((int)p + (int)Uu);
+            const unsigned q = Uu > 1u ? __umulhi(pu, Minv) : pu;
+            n = (long long)(int)q - 1;
+            ph = (int)(pu - q * Uu);
+        } else {
+            n = floordiv(p, a.U);
+            ph = (int)(p - n * a.U);
+        }
+    };
+    // s0 = s(p), s1 = s(p + 1) (resample.cxx:141-147) TOGETHER.  Position p + 1 is phase ph + 1 of the same input
+    // sample n, or -- ph = U - 1 -- phase 0 of sample n + 1 (sh = 1).  Either way both sums run over the SAME samples
+    // x[n - i]:   s0 += taps[ph][i] x[n - i],   s1 += taps[ph1][i + sh] x[n - i]   (sh = 1: after s1's own first term,
+    // taps[0][0] x[n + 1]) -- one sample read feeds two multiply-accumulates, each sum still in the reference's order
+    // (ascending tap index from 0.0f).  The taps come four at a time from the aligned rows: ts for s0 and for s1 with
+    // sh = 0, tsh (the rows shifted by one tap) for s1 with sh = 1.  Separately the two sums read every sample twice
+    // and their taps one float at a time: 11.1 -> see profiles/r03/general_rate.txt for 127 taps per sum.
+    // Samples before the tile (only reachable through the reference's out_len-exhausted state)
+    // read as zero instead of out of bounds: the sums stop at the tile's first sample.
+    auto dot2 = [&](long long p, T &s0, T &s1) {
+        long long n;
+        int ph;
+        split(p, n, ph);
+        const int sh = ph + 1 == a.U;
+        const int ph1 = sh ? 0 : ph + 1;
+        const long long reach = n + a.plen + 1;                    // samples x[n], x[n-1], ... inside the tile
+        const int L0 = reach < a.plen ? (reach > 0 ? (int)reach : 0) : a.plen;               // terms of s0
+        const long long reach1 = reach + sh;
+        const int J1 = reach1 < a.plen ? (reach1 > 0 ? (int)reach1 : 0) : a.plen;            // terms of s1
+        const int L1 = J1 - (sh && J1 > 0 ? 1 : 0);                                          // ... of them over x[n - i]
+        const float *ta = ts + ph * plp;
+        const float *tb = (sh ? tsh : ts) + ph1 * plp;
         const T *xp = xs + (n + a.plen);
-        T acc = Elem<CPLX>::zero();
-        // positions before the tile (only reachable through the reference's out_len-exhausted
-        // state) read as zero instead of out of bounds
-        const long long reach = n + a.plen + 1;
-        const int jn = reach < a.plen ? (reach > 0 ? (int)reach : 0) : a.plen;
-        for (int j = 0; j < jn; j++) acc = mac<EXACT>(acc, tp[j], xp[-j]);
-        return acc;
+        s0 = Elem<CPLX>::zero();
+        s1 = Elem<CPLX>::zero();
+        if (sh && J1 > 0) s1 = mac<EXACT>(s1, ts[0], xp[1]);     // taps[0][0] x[n + 1]
+        const int common = L0 < L1 ? L0 : L1;
+        int i = 0;
+        for (; i + 4 <= common; i += 4) {
+            const v4f a4 = *reinterpret_cast<const v4f *>(ta + i), b4 = *reinterpret_cast<const v4f *>(tb + i);
+            const T x0 = xp[-i], x1 = xp[-i - 1], x2 = xp[-i - 2], x3 = xp[-i - 3];
+            s0 = mac<EXACT>(s0, a4.x, x0);
+            s1 = mac<EXACT>(s1, b4.x, x0);
+            s0 = mac<EXACT>(s0, a4.y, x1);
+            s1 = mac<EXACT>(s1, b4.y, x1);
+            s0 = mac<EXACT>(s0, a4.z, x2);
+            s1 = mac<EXACT>(s1, b4.z, x2);
+            s0 = mac<EXACT>(s0, a4.w, x3);
+            s1 = mac<EXACT>(s1, b4.w, x3);
+        }
+        for (; i < common; i++) {
+            const T x0 = xp[-i];
+            s0 = mac<EXACT>(s0, ta[i], x0);
+            s1 = mac<EXACT>(s1, tb[i], x0);
+        }
+        for (int j = i; j < L0; j++) s0 = mac<EXACT>(s0, ta[j], xp[-j]);
+        for (int j = i; j < L1; j++) s1 = mac<EXACT>(s1, tb[j], xp[-j]);
     };
 
     int s = 0;                                          // runs are visited in order by each thread
@@ -824,8 +912,9 @@ __global__ __launch_bounds__(256) void poly_seg_kernel(PolySegArgs a)
         const double t = g.t0 + (double)(k - g.k0) * (double)g.d;       // exact (timelaw.h)
         const double fl = floor(t);
         const float mu = (float)(t - fl);
-        const long long p = (long long)fl;
-        const T s0 = dot(p), s1 = dot(p + 1);
+        const long long p = (fl > -2.0e9 && fl < 2.0e9) ? (long long)(int)fl : (long long)fl;      // (one v_cvt_i32_f64 instead of the 64-bit conversion sequence)
+        T s0, s1;
+        dot2(p, s0, s1);
         const float om = 1.0f - mu;                                       // resample.cxx:147
         if constexpr (CPLX) {
             if constexpr (EXACT) { const v2f l = s0 * (v2f){om, om}, r = (v2f){mu, mu} * s1; out[k] = l + r; }
@@ -1095,8 +1184,8 @@ int launch_poly_seg(const PolySegArgs &a, int data_complex, int exact, int n_cha
 {
     if (a.n_chunks <= 0) return SFE_OK;
     const size_t esz = data_complex ? 8 : 4;
-    const size_t sh = SEG_MAX_LDS * sizeof(DevSeg) + (((size_t)a.U * a.plen * 4 + 15) & ~(size_t)15) +
-                      (size_t)(a.max_m + a.plen) * esz;
+    const size_t sh = SEG_MAX_LDS * sizeof(DevSeg) + (size_t)2 * a.U * seg_row(a.plen) * 4 +
+                      (size_t)(a.max_m + a.plen + 1) * esz;
     if (sh > 64 * 1024) return SFE_ESTATE;
     dim3 grid((unsigned)a.n_chunks, (unsigned)n_channels), block(256);
 #define LAUNCH(C, E) hipLaunchKernelGGL((poly_seg_kernel<C, E>), grid, block, sh, s, a)
