@@ -104,7 +104,26 @@ __global__ __launch_bounds__(256) void poly_int_kernel(PolyArgs a, int tile_out,
     const long long n_hi = floordiv(p_last, a.U);
     const int tile_len = (int)(n_hi - n_lo + 1);
 
-    for (int i = threadIdx.x; i < tile_len; i += 256) xs[i] = vload<CPLX>(in, hist, n_lo + i, a.n_in, a.hl);
+    if (n_lo >= 0 && n_lo + tile_len <= a.n_in) {
+        // an interior tile: eight requests per thread in flight at a time (the guarded loop below is one load -> wait ->
+        // LDS write per iteration, one memory latency after the other; poly_seg_kernel has the measurement)
+        const T *src = in + n_lo;
+        for (int i0 = (int)threadIdx.x; i0 < tile_len; i0 += 256 * 8) {
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = i0 + 256 * u;
+                v[u] = i < tile_len ? __builtin_nontemporal_load(src + i) : Elem<CPLX>::zero();
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = i0 + 256 * u;
+                if (i < tile_len) xs[i] = v[u];
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < tile_len; i += 256) xs[i] = vload<CPLX>(in, hist, n_lo + i, a.n_in, a.hl);
+    }
     for (int i = threadIdx.x; i < a.U * a.plen; i += 256) ts[i] = a.taps[i];
     __syncthreads();
 
