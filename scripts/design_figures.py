@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Print the figures DESIGN.md quotes from profiles/<tag>/ in one place, so that a re-collection can be
 followed through the prose quickly (tests/test_design_numbers.py then checks the result).
-usage: scripts/design_figures.py [tag]"""
+usage: scripts/design_figures.py [tag] [--write]
+--write also regenerates DESIGN.md's block of the collection's own figures (between the collection:begin / :end markers):
+after a re-collection (scripts/collect_profiles.sh, scripts/summarise_profiles.py, the two bench lines) that is the only
+edit the prose needs."""
 import csv
 import json
 import os
@@ -12,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from simplefe_amd.build import fir_kernel_flags  # noqa: E402
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = next((a for a in sys.argv[1:] if not a.startswith("--")), "r03")
 P = os.path.join(ROOT, "profiles", tag)
 ALG = {"fir": 16 * 2 ** 28, "decimate": 9 * 2 ** 30, "resample": 8 * 2 ** 28 + 8 * 161061273}
 
@@ -63,3 +66,70 @@ for w, units in (("fir", 69906 * 4), ("resample", 116207 * 4)):
         vals = dict((m.group(1), float(m.group(2))) for m in (re.match(r"(\S+)\s+n=\s*\d+ mean=(\S+)", l) for l in open(f)) if m)
         print(f"  {w}: " + "  ".join(f"{k[9:]} {vals[k] / units:.0f}" for k in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM") if k in vals)
               + f"   WAIT_INST_LDS {vals.get('SQ_WAIT_INST_LDS', 0):.3g}  BANK_CONFLICT {vals.get('SQ_LDS_BANK_CONFLICT', 0):.0f}")
+
+
+# ---- `--write`: regenerate DESIGN.md's block of this collection's figures (between the collection:begin / :end markers)
+def _line(name):
+    return json.loads(open(os.path.join(P, name + ".json")).read().strip().splitlines()[-1])
+
+
+def _stats(w):
+    r = list(csv.DictReader(open(os.path.join(P, f"{w}_kernel_stats.csv"))))[0]
+    return int(r["Calls"]), float(r["AverageNs"])
+
+
+def _other(j, key):
+    return next(o for o in j["other_configs"] if key in o["workload"])
+
+
+def collection_block():
+    drv, dfl = _line("bench_driver_shape"), _line("bench_default")
+    rows = []
+    keys = {"fir": None, "resample": "381-tap", "decimate": "decimate by 8"}
+    for w, label in (("fir", "256-tap FIR, 2^28 cf32 (`fir_fft4096_kernel`, the variant the process measured as fastest)"),
+                     ("resample", "resample 5/3, 381 taps, 2^28 cf32 (`poly_fft256_kernel`)"),
+                     ("decimate", "decimate ÷8, 64 taps, 2^30 cf32 (`poly_tiled_kernel`)")):
+        calls, ns = _stats(w)
+        ms = ns / 1e6
+        pmc = json.load(open(os.path.join(ROOT, "profiles", f"pmc_{tag}_{w}.json")))
+        if keys[w] is None:
+            d_ms, d_fr, f_ms, f_fr = drv["roofline"]["kernel_ms"], drv["roofline"]["frac"], dfl["roofline"]["kernel_ms"], dfl["roofline"]["frac"]
+        else:
+            a, b = _other(drv, keys[w]), _other(dfl, keys[w])
+            d_ms, d_fr, f_ms, f_fr = a["ms"], a["frac"], b["ms"], b["frac"]
+        sp = lambda v: f"{v:,.0f}".replace(",", " ")
+        rows.append(f"| {label} | mean {sp(ns)} ns = {ms:.4f} ms over {calls} launches (`profiles/{tag}/{w}_kernel_stats.csv`) = "
+                    f"{ALG[w] / ms / 1e9:.2f} TB/s = **{ALG[w] / ms / 1e9 / 8 * 100:.1f} %** | {d_ms:.4f} ms, `frac` {d_fr:.3f} (`profiles/{tag}/bench_driver_shape.json`) | "
+                    f"{f_ms:.4f} ms, `frac` {f_fr:.3f} (`profiles/{tag}/bench_default.json`) | {pmc['hbm_bytes_per_launch'] / 1e9:.2f} GB, "
+                    f"+{(pmc['hbm_bytes_per_launch'] / ALG[w] - 1) * 100:.1f} % over algorithmic (`profiles/pmc_{tag}_{w}.json`) |")
+    r, c = drv["roofline"], drv["cpu_baseline"]
+    o = {k: _other(drv, k) for k in ("381-tap", "127-tap", "decimate by 8", "complex-tap")}
+    ch64 = [x for x in drv["other_configs"] if "64 channel" in x["workload"]][0]
+    head = (f"The driver's command shape measured by the builder (`python bench.py --gpus 1 --steps 20 --warmup 5`, `profiles/{tag}/bench_driver_shape.json`): "
+            f"**{drv['value']:,.0f} MS/s, `ms_per_step` {drv['ms_per_step']:.3f}, `roofline.frac` {r['frac']:.3f}** (kernel {r['kernel_ms']:.4f} ms mean, "
+            f"{r['kernel_ms_min']:.4f} min, {r['kernel_ms_max']:.4f} max; `traffic` {r['traffic'] / 1e9:.3f} GB; variant: {r['variant']['ran']}), parity "
+            f"{drv['parity']['rel_rms_max']:.1e}; `other_configs`: resample 5/3 {o['381-tap']['ms']:.4f} ms ({o['381-tap']['frac']:.3f}), with the 127-tap prototype "
+            f"{o['127-tap']['ms']:.4f} ms ({o['127-tap']['frac']:.3f}), decimate ÷8 {o['decimate by 8']['ms']:.4f} ms ({o['decimate by 8']['frac']:.3f}), 64 channels × 2^24 "
+            f"{ch64['ms']:.2f} ms ({ch64['frac']:.3f}), complex taps {o['complex-tap']['ms']:.4f} ms ({o['complex-tap']['frac']:.3f}), every parity check green; "
+            f"`cpu_baseline` {c['value']:.0f} MS/s on one thread, {c['all_cores']['value']:.0f} MS/s on the box's {c['host_cores']} host cores"
+            + (f", BASELINE configs[0] (CPU only) {c['configs0_cpu_only']['value']:.0f} real MS/s" if "configs0_cpu_only" in c else "") + ".")
+    head = head.replace(f"{drv['value']:,.0f}", f"{drv['value']:,.0f}".replace(",", " ")).replace(f"{r['traffic'] / 1e9:.3f} GB", f"{r['traffic'] / 1e9:.2f} GB")
+    earlier = []
+    for f in sorted(os.listdir(os.path.join(P, "earlier"))):
+        if f.endswith("bench_driver_shape.json"):
+            j = json.loads(open(os.path.join(P, "earlier", f)).read().strip().splitlines()[-1])
+            earlier.append(f"`{f.split('_')[0]}` {j['value']:,.0f} MS/s / {j['roofline']['frac']:.3f}".replace(",", " "))
+    tail = ("Earlier collections of the round, other boxes of the pool, same product kernels (`profiles/" + tag + "/earlier/`, driver shape, MS/s / `frac`): "
+            + ", ".join(earlier) + ".")
+    table = ("| kernel | under rocprofv3 (`bench.py --workload … --no-others --no-cpu`) | un-profiled, driver-shape line | un-profiled, default line | PMC traffic |\n"
+             "|---|---|---|---|---|\n" + "\n".join(rows))
+    return head + "\n\n" + table + "\n\n" + tail
+
+
+if "--write" in sys.argv:
+    path = os.path.join(ROOT, "DESIGN.md")
+    text = open(path).read()
+    b, e = "<!-- collection:begin -->", "<!-- collection:end -->"
+    i, j = text.index(b) + len(b), text.index(e)
+    open(path, "w").write(text[:i] + "\n" + collection_block() + "\n" + text[j:])
+    print("DESIGN.md: collection block rewritten")
