@@ -91,6 +91,37 @@ def test_rs_random_shapes_bit_exact(api, L, orc, seed):
         assert np.array_equal(got, ref[: len(got)]), (seed, U, n_taps, B, rate, cplx, chunk)
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_general_rate_random_shapes_every_bit(api, L, orc, seed):
+    """The general-rate kernel (poly_seg_kernel: an output's two sums run together over shared samples, taps four at a
+    time from aligned rows, the last phase's second sum one sample on) against the oracle, exact mode, on rates below
+    and above 1, up to eight phases, 1 to 40 taps per phase, streams that start in zero history -- compared as BIT
+    PATTERNS (the sign of a zero included, which == would let through)."""
+    rng = np.random.default_rng(5000 + seed)
+    U = int(rng.integers(1, 9))
+    plen = int(rng.integers(1, 41))
+    n_taps = max(U, U * plen - int(rng.integers(0, U)))
+    B = int(rng.choice([256, 1000, 1001, 4096]))
+    taps = rng.standard_normal(n_taps).astype(np.float32)
+    lo = 1.0 / U + 0.02
+    rate = float(np.float32(rng.uniform(lo, 1.0) if seed % 4 == 0 and U > 1 else rng.uniform(1.0, 6.0)))
+    cplx = bool(rng.integers(0, 2))
+    w = 2 if cplx else 1
+    n = int(rng.choice([700, 4096, 12345, 40000]))
+    x = synth.synth_f32(w * n, ch=200 + seed)
+    if seed % 5 == 0:
+        x[: w * 300] = 0.0                    # a silent start: sums of signed zeros
+    r = api.Rs(taps, U, B, mode=L.RS_RESAMPLE, data_complex=cplx)
+    r.set_exact(True)
+    chunk = int(rng.integers(1, 12)) * B       # bulk calls of whole blksize multiples: the run-length (poly_seg) path
+    y = r.resample_array(x, rate, chunk=chunk)[0]
+    for part in range(w):
+        ref, _ = orc.Resample(taps, U, B).stream(x[part::w], rate)
+        got = np.ascontiguousarray(y[part::w])
+        assert len(ref) - len(got) in (0, 1), (seed, U, n_taps, B, rate, len(ref), len(got))
+        assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(ref[: len(got)]).view(np.uint32)), (seed, U, n_taps, B, rate, cplx, chunk)
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_rs_fft_path_random_shapes(api, L, monkeypatch, seed):
     """Transform-domain kernel forced on, random instantiated (U, step) pairs, tap counts up to
