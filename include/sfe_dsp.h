@@ -205,7 +205,8 @@ int sfe_dsp_pipe_pending(sfe_pipe_t p, size_t *items);
  * to copy from).  May be mixed freely with push / pull on the same pipe; same items, same order.
  *   acquire  *buf = where the next item goes, *room_items = how many fit before the batch is sent on its way
  *            (0, *buf NULL: every batch is in flight -- take finished items out first).  The pointer is valid until
- *            the next commit / push on this pipe.
+ *            the next commit / push on this pipe, or a pull / peek with wait = 2 (which may send the open batch on
+ *            its way and move what is left of it).
  *   commit   n_items (<= room) have been written at the acquired pointer; a full batch is sent on its way.
  *   peek     *out = the oldest finished items, *n_items of them contiguous (0: none ready); wait as for pull.
  *            The pointer is valid until they are released.
