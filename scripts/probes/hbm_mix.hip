@@ -122,6 +122,15 @@ int main(int argc, char **argv)
     CK(hipMalloc(&out, bytes));
     CK(hipMemset(in, 1, bytes));
     CK(hipMemset(out, 0, bytes));
+    if (argc > 1 && argv[1][0] == '4') {       // the real-data FIR's lane width: 4-byte lanes against 8 and 16 (same bytes, same grid)
+        for (int g : {2048, 8192}) {
+            printf("-- grid %d x 256 threads\n", g);
+            timeit("copy   4 B lanes, nt load + nt store, 32 deep", 2.0 * bytes, [&] { hipLaunchKernelGGL((k_copy<float, true, true, 32>), dim3(g), dim3(256), 0, 0, (const float *)in, (float *)out, bytes / 4); });
+            timeit("copy   8 B lanes, nt load + nt store, 16 deep", 2.0 * bytes, [&] { hipLaunchKernelGGL((k_copy<v2f, true, true, 16>), dim3(g), dim3(256), 0, 0, (const v2f *)in, (v2f *)out, bytes / 8); });
+            timeit("copy  16 B lanes, nt load + nt store, 8 deep", 2.0 * bytes, [&] { hipLaunchKernelGGL((k_copy<v4f, true, true, 8>), dim3(g), dim3(256), 0, 0, (const v4f *)in, (v4f *)out, bytes / 16); });
+        }
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == '5') {       // only the resampler's mix (profiles/r03/hbm_mix_5to3.txt)
         const size_t tiles = bytes / 8 / (10 * 256);
         for (int g : {1024, 2048, 8192, 65536, (int)tiles}) {
