@@ -65,13 +65,14 @@ __global__ __launch_bounds__(256) void k_mix81(const v2f *in, v2f *out, size_t n
         v2f acc = v[0];
 #pragma unroll
         for (int u = 1; u < CH; u++) acc += v[u];
-        // lanes 0..CH*32-1 of the tile's output: fold eight lanes into one through a shuffle-free trick:
-        // every lane writes its sum for lane % 8 == 0 (an 8-byte store per eight lanes would scatter: use
-        // one 16-byte store per sixteen lanes instead, as the decimator's store is)
-        if ((threadIdx.x & 1) == 0) {
-            v4f w = {acc.x, acc.y, acc.x, acc.y};
-            if ((threadIdx.x & 15) == 0 || CH >= 16)
-                __builtin_nontemporal_store(w, reinterpret_cast<v4f *>(out + tile * (size_t)(CH * 32)) + (threadIdx.x >> 1) % (CH * 16));
+        // the tile's CH*32 output samples = CH*16 sixteen-byte lanes, contiguous, as the decimator's store is
+        // (every lane stores, so that no lane's loads are dead: 8 bytes per lane for CH = 8, 16 for CH = 16, 2 x 16 for CH = 32)
+        if constexpr (CH == 8) {
+            __builtin_nontemporal_store(acc, out + tile * (size_t)(CH * 32) + threadIdx.x);
+        } else {
+            const v4f w = {acc.x, acc.y, acc.x, acc.y};
+            for (unsigned q = threadIdx.x; q < (unsigned)(CH * 16); q += 256)
+                __builtin_nontemporal_store(w, reinterpret_cast<v4f *>(out + tile * (size_t)(CH * 32)) + q);
         }
     }
 }
@@ -122,6 +123,14 @@ int main(int argc, char **argv)
     CK(hipMalloc(&out, bytes));
     CK(hipMemset(in, 1, bytes));
     CK(hipMemset(out, 0, bytes));
+    if (argc > 1 && argv[1][0] == '8') {       // the decimator's 8:1 mix by tile size: one workgroup per tile of CH x 256 samples
+        const size_t n8 = bytes / 8;
+        printf("-- one workgroup per tile\n");
+        timeit("mix 8:1, tile 4096 samples (16 loads per lane)", 1.125 * bytes, [&] { hipLaunchKernelGGL((k_mix81<16>), dim3((unsigned)(n8 / (16 * 256))), dim3(256), 0, 0, (const v2f *)in, (v2f *)out, n8 / (16 * 256)); });
+        timeit("mix 8:1, tile 2048 samples (8 loads per lane)", 1.125 * bytes, [&] { hipLaunchKernelGGL((k_mix81<8>), dim3((unsigned)(n8 / (8 * 256))), dim3(256), 0, 0, (const v2f *)in, (v2f *)out, n8 / (8 * 256)); });
+        timeit("mix 8:1, tile 8192 samples (32 loads per lane)", 1.125 * bytes, [&] { hipLaunchKernelGGL((k_mix81<32>), dim3((unsigned)(n8 / (32 * 256))), dim3(256), 0, 0, (const v2f *)in, (v2f *)out, n8 / (32 * 256)); });
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == '4') {       // the real-data FIR's lane width: 4-byte lanes against 8 and 16 (same bytes, same grid)
         for (int g : {2048, 8192}) {
             printf("-- grid %d x 256 threads\n", g);
