@@ -11,6 +11,9 @@ Two libraries:
                         RefDecimate); present on the GPU box only as the prebuilt .so
   _ref/libsferef_blkconv.so -- the unmodified reference blkconv class on ROCm's libhipfftw
                         (RefBlkconv); runs on a GPU box only
+  _ref/libsferef_blkconv_fftw.so -- the unmodified reference blkconv class on the reference's
+                        OWN FFTW 3.3.5 binary (contrib/fftw-3.3.5-dll64/libfftw3f-3.dll, mapped
+                        in process by oracle/pe/; RefBlkconvFFTW); CPU, authoring container only
 """
 import ctypes as C
 import os
@@ -121,6 +124,40 @@ def ref_blkconv_lib():
     return _ref_blk
 
 
+FFTW_DLL = os.environ.get("SFE_FFTW_DLL") or "/root/reference/contrib/fftw-3.3.5-dll64/libfftw3f-3.dll"
+_ref_blk_fftw = None
+
+
+def ref_blkconv_fftw_lib():
+    """The compiled reference blkconv class on the reference's own FFTW 3.3.5 binary
+    (oracle/_ref/libsferef_blkconv_fftw.so, `make -C oracle ref_fftw`), or None where the DLL it
+    maps does not exist (the GPU box) or the library is not built."""
+    global _ref_blk_fftw
+    if _ref_blk_fftw is None:
+        if not os.path.exists(FFTW_DLL):
+            return None
+        p = os.path.join(HERE, "_ref", "libsferef_blkconv_fftw.so")
+        if not os.path.exists(p) and os.path.isdir("/root/reference"):
+            subprocess.check_call(["make", "-s", "-C", HERE, "ref_fftw"])
+        try:
+            R = _load(p)
+        except OSError:
+            R = None
+        if R is None:
+            return None
+        R.ref_blkconv_create.restype = C.c_void_p
+        R.ref_blkconv_create.argtypes = [_f32p, C.c_int, C.c_int]
+        R.ref_blkconv_blksize.argtypes = [C.c_void_p]
+        R.ref_blkconv_buf.restype = C.POINTER(C.c_float)
+        R.ref_blkconv_buf.argtypes = [C.c_void_p]
+        R.ref_blkconv_process.argtypes = [C.c_void_p]
+        R.ref_blkconv_destroy.argtypes = [C.c_void_p]
+        R.ref_blkconv_stream.argtypes = [C.c_void_p, _f32p, _f32p, C.c_long]
+        R.sfe_pe_fftwf_version.restype = C.c_char_p
+        _ref_blk_fftw = R
+    return _ref_blk_fftw
+
+
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
@@ -154,11 +191,14 @@ class Blkconv:
 class RefBlkconv:
     """The reference's own blkconv class (libdsp/blkconv.cxx:34-122), compiled unmodified."""
 
+    _getlib = staticmethod(ref_blkconv_lib)
+    _libname = "libsferef_blkconv.so"
+
     def __init__(self, taps, fft_len):
         taps = _f32(taps)
-        self._L = ref_blkconv_lib()
+        self._L = self._getlib()
         if self._L is None:
-            raise RuntimeError("oracle/_ref/libsferef_blkconv.so not built")
+            raise RuntimeError("oracle/_ref/%s not built or not usable here" % self._libname)
         self._h = self._L.ref_blkconv_create(taps, len(taps), int(fft_len))
         self.blk = self._L.ref_blkconv_blksize(self._h)
         p = self._L.ref_blkconv_buf(self._h)
@@ -184,6 +224,24 @@ class RefBlkconv:
         if getattr(self, "_h", None):
             self._L.ref_blkconv_destroy(self._h)
             self._h = None
+
+
+class RefBlkconvFFTW(RefBlkconv):
+    """The reference's own blkconv class on the reference's own FFTW 3.3.5 (the vendored Win64 DLL
+    mapped by oracle/pe/).  CPU; exists only where /root/reference does."""
+    _getlib = staticmethod(ref_blkconv_fftw_lib)
+    _libname = "libsferef_blkconv_fftw.so"
+
+    def stream(self, x):
+        x = _f32(x)
+        y = np.empty_like(x)
+        self._L.ref_blkconv_stream(self._h, x, y, len(x))
+        return y
+
+    @classmethod
+    def fftw_version(cls):
+        L = cls._getlib()
+        return L.sfe_pe_fftwf_version().decode() if L is not None else None
 
 
 class _Rs:

@@ -37,6 +37,16 @@ def g6():
 
 
 @pytest.fixture(scope="session")
+def g7():
+    """Outputs of the reference's blkconv class on the reference's OWN FFTW 3.3.5 binary
+    (tests/golden/make_golden_fftw.py; oracle/pe/): the pin at the FFTW boundary."""
+    return np.load(os.path.join(GOLDEN, "g7_blkconv_fftw.npz"))
+
+
+G7_CASES = ["kat", "bpsk", "cfg1", "cfg2", "rrc551"]
+
+
+@pytest.fixture(scope="session")
 def orc():
     from oracle import binding
     binding.lib()

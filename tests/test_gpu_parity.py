@@ -220,6 +220,37 @@ def _drive(obj, x, B, out_len, rate):
     return np.concatenate(ys), ns
 
 
+G7_SEEN = {}
+
+
+@pytest.mark.parametrize("name", ["kat", "bpsk", "cfg1", "cfg2", "rrc551"])
+def test_blkconv_class_vs_reference_on_its_own_fftw(api, orc, g7, name):
+    """THE PIN AT THE FFTW BOUNDARY.  g7 holds outputs of the reference itself
+    -- libdsp/blkconv.cxx:34-110 calling its own vendored FFTW 3.3.5 binary, run in the authoring
+    container (oracle/pe/, tests/golden/make_golden_fftw.py).  The drop-in class is driven the way
+    the reference's callers drive theirs (write [0, blk) of get_process_buf(), process(), read it
+    back), and the device-resident stream call is fed the same samples in one piece.
+    Tolerance: rel-RMS <= 1e-5 (north_star); observed figures are printed and bounded at 5e-7."""
+    taps, fft_len, x, want = g7[f"{name}_taps"], int(g7[f"{name}_fft_len"]), g7[f"{name}_x"], g7[f"{name}_y"]
+    c = api.blkconv(taps, fft_len)
+    blk = c.get_blksize()
+    buf = c.get_process_buf()
+    assert blk == fft_len + 1 - len(taps)
+    got = np.empty_like(x)
+    for off in range(0, len(x), blk):
+        buf[:blk] = x[off: off + blk]
+        c.process()
+        got[off: off + blk] = buf[:blk]
+    e_class = synth.rel_rms(got, want)
+    bulk = api.Fir(taps, data_complex=False).filter(x).reshape(-1)
+    e_bulk = synth.rel_rms(bulk, want)
+    G7_SEEN[name] = (e_class, e_bulk)
+    print(f"g7 {name}: class {e_class:.3e}  stream {e_bulk:.3e}  max abs {np.abs(got - want).max():.3e}")
+    assert e_class <= TOL and e_bulk <= TOL
+    assert e_class < 5e-7 and e_bulk < 5e-7
+    assert np.abs(got - want).max() < 2e-6 * max(1.0, float(np.abs(want).max()))
+
+
 @pytest.mark.parametrize("name", ["kat", "bpsk", "cfg1", "cfg2"])
 def test_blkconv_class_vs_reference_class(api, orc, g6, name):
     """The drop-in blkconv class against the reference's own (blkconv.cxx on libhipfftw): the

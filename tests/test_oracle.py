@@ -122,6 +122,25 @@ def test_blkconv_restatement_vs_reference_class(orc, g6, name):
     assert np.abs(got - want).max() < 2e-6 * max(1.0, float(np.abs(want).max()))
 
 
+@pytest.mark.parametrize("name", ["kat", "bpsk", "cfg1", "cfg2", "rrc551"])
+def test_blkconv_restatement_vs_reference_on_its_own_fftw(orc, g7, name):
+    """THE PIN AT THE FFTW BOUNDARY.  g7 = outputs of the reference itself: its blkconv.cxx calling
+    its own vendored FFTW 3.3.5 (libfftw3f-3.dll mapped in process, oracle/pe/), block by block.
+    The restatement carries an own float32 FFT, so equality is to float32 transform rounding:
+    observed 3.0e-8 (kat) and 2.6-3.0e-7 (the streams) against the 1e-5 bar."""
+    taps, fft_len, x, want = g7[f"{name}_taps"], int(g7[f"{name}_fft_len"]), g7[f"{name}_x"], g7[f"{name}_y"]
+    c = orc.Blkconv(taps, fft_len)
+    assert c.blk == fft_len + 1 - len(taps) and len(x) % c.blk == 0
+    got = np.empty_like(x)
+    for off in range(0, len(x), c.blk):
+        c.buf[: c.blk] = x[off: off + c.blk]
+        c.process()
+        got[off: off + c.blk] = c.buf[: c.blk]
+    assert synth.rel_rms(got, want) <= 1e-5           # north_star's bar
+    assert synth.rel_rms(got, want) < 5e-7            # what is observed, with margin
+    assert np.abs(got - want).max() < 2e-6 * max(1.0, float(np.abs(want).max()))
+
+
 def test_blkconv_pulse_shaping_vs_float64(orc, g1):
     """bpsk.cxx:122-164 shape (111 taps, fft 2048) against float64 direct convolution."""
     c = orc.Blkconv(g1["g2_taps"], int(g1["g2_fft_len"]))
