@@ -10,17 +10,15 @@
  * Pinning status (see DESIGN.md "Oracle"):
  *   - orc_resample_* / orc_decimate_* : pinned BIT-EXACT against the unmodified
  *     reference sources compiled in place into oracle/_ref/ (tests/golden fixtures).
- *   - orc_blkconv_* : PARITY UNPINNED at the FFTW boundary (round-1 verdict: the hipFFTW-linked
- *     reference build below counts as a stand-in library and pins nothing; no FFTW binary or
- *     golden vector for blkconv exists in this image or in the reference tree).  What is checked:
- *     the reference's FFT arithmetic lives in FFTW 3.3.5 (libfftw3f),
- *     which is not in this image and not vendored as source.  The reference class itself,
- *     blkconv.cxx unmodified, IS built -- against the reference's vendored fftw3.h and ROCm's
- *     libhipfftw.so (the FFTW3 API on hipFFT; runs on a GPU box only) -- and its outputs are
- *     the fixture tests/golden/g6_blkconv_reference.npz: the restatement matches them to
- *     float32 FFT rounding (rel-RMS 3e-7).  Also pinned by the reference's known-answer
- *     scenario (libdsp/test/test_blkconv.cxx:5-33) and float64 direct linear convolution.
- *     Unpinned: only FFTW's own rounding versus hipFFT's (no FFTW binary exists here).
+ *   - orc_blkconv_* : pinned at the FFTW boundary against OUTPUTS OF THE REFERENCE ITSELF RUN HERE
+ *     (round 4): the reference's FFT arithmetic lives in FFTW 3.3.5 (libfftw3f), vendored only as
+ *     a Win64 binary (contrib/fftw-3.3.5-dll64/libfftw3f-3.dll).  oracle/pe/ maps that x86-64
+ *     binary into the process (operating-system stubs only, no arithmetic) and the UNMODIFIED
+ *     blkconv.cxx calls it; tests/golden/g7_blkconv_fftw.npz holds the results (five shapes,
+ *     block by block).  The restatement carries an own float32 FFT, so it matches them to
+ *     transform rounding: rel-RMS 3e-8 .. 3.0e-7 against the 1e-5 bar.  Cross-checks kept from
+ *     earlier rounds: the same class on ROCm's libhipfftw (g6, GPU box only), the reference's
+ *     known-answer scenario (libdsp/test/test_blkconv.cxx:5-33), float64 direct convolution.
  */
 #ifndef SFE_ORACLE_H_
 #define SFE_ORACLE_H_
