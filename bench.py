@@ -80,6 +80,8 @@ def parse():
                     help="tx10: the FIR writes the 10-bit transmit wire format (fused TX converter, N2)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-others", action="store_true", help="skip the other_configs legs")
+    ap.add_argument("--no-calibrate", action="store_true",
+                    help="do not call sfe_dsp_fir_calibrate before the headline leg (run the default variant)")
     ap.add_argument("--other-steps", type=int, default=20)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--precondition", type=float, default=0.15, help="seconds of untimed launches before any warm-up")
@@ -239,7 +241,7 @@ def _p2(v):
 
 
 def make_fir_leg(ctx, name, taps, n, nch, ch0=0, algo="auto", in_fmt="f32", out_fmt="f32", x_share=None, per_channel=False,
-                 y_share=None):
+                 y_share=None, calibrate=False):
     """n samples per channel, nch channels on THIS rank, the first of them global channel ch0 (its
     seed): what one rank of a channel-sharded job holds (shard.channel_block)."""
     torch, api, lib, synth, shard = ctx["torch"], ctx["api"], ctx["lib"], ctx["synth"], ctx["shard"]
@@ -302,14 +304,29 @@ def make_fir_leg(ctx, name, taps, n, nch, ch0=0, algo="auto", in_fmt="f32", out_
     def step():
         leg.obj.process_stream(sp, yp, n, stream=stream)
     leg.step = step
-    # untimed first call: a large cf32 call measures the kernel's data-movement variants on THIS device
-    # once per shape (api.hip: fir_pick_variant) -- here, so that it can never fall into a timed step
+    # Stream calls never measure (api.hip: fir_pick_variant is a table look-up; register loads by default).
+    # The headline leg asks for the measurement explicitly, untimed, before any warm-up:
+    # sfe_dsp_fir_calibrate on rank 0, the choice handed to every rank so that all of them run ONE kernel
+    # (independently calibrating ranks were noise in a strong-scaling curve).
     step()
     torch.cuda.synchronize()
-    v, cal, ms = leg.obj.get_variant()
-    leg.variant = {"ran": lib.FIR_VARIANT_NAMES.get(v, str(v)), "measured_by_this_handle": bool(cal)}
-    if cal:
-        leg.variant["median_ms"] = {lib.FIR_VARIANT_NAMES[i]: round(m, 4) for i, m in enumerate(ms) if m > 0}
+    leg.variant = None
+    if calibrate:
+        chosen, cal, ms = 0, 0, []
+        if ctx["rank"] == 0:
+            chosen = leg.obj.calibrate(sp, yp, n, stream=stream)
+            _, cal, ms = leg.obj.get_variant()
+        if ctx["world"] > 1:
+            chosen = int(round(shard.sum_over_ranks([float(chosen)], ctx["red_dev"])[0]))     # only rank 0 contributes
+        leg.obj.set_variant(chosen)
+        leg.variant = {"ran": lib.FIR_VARIANT_NAMES.get(chosen, str(chosen)),
+                       "chosen_by": "sfe_dsp_fir_calibrate on rank 0, untimed" + (", broadcast to all ranks" if ctx["world"] > 1 else "")}
+        if cal:
+            leg.variant["median_ms"] = {lib.FIR_VARIANT_NAMES[i]: round(m, 4) for i, m in enumerate(ms) if m > 0}
+    else:
+        step()
+        v, _, _ = leg.obj.get_variant()
+        leg.variant = {"ran": lib.FIR_VARIANT_NAMES.get(v, str(v)), "chosen_by": "default (nothing measured)"}
 
     def check(full):
         """Windows of the LAST step's output against the oracle (history = the tail of the same
@@ -617,7 +634,8 @@ def main():
         if wl == "fir_ctaps":
             tr, ti = synth.complex_taps(256, 0.2)
             taps = (tr + 1j * ti).astype(np.complex64)
-        head = make_fir_leg(ctx, wl, taps, n_ch, nch, ch0=ch0, algo=args.algo, in_fmt=args.input, out_fmt=args.output)
+        head = make_fir_leg(ctx, wl, taps, n_ch, nch, ch0=ch0, algo=args.algo, in_fmt=args.input, out_fmt=args.output,
+                            calibrate=not args.no_calibrate)
     else:
         head = make_rs_leg(ctx, wl, args.log2n or (28 if wl == "resample" else 30), in_fmt=args.input)
 

@@ -142,14 +142,19 @@ int sfe_dsp_fir_set_algo(sfe_fir_t h, int algo);
 /* How the rows of an aligned complex float32 stream reach the FFT kernel's transform: guarded
  * register loads, LDS-DMA requested early, or LDS-DMA into a wave-private exchange layout
  * (DESIGN.md 4.1).  Same arithmetic, bit-identical output; which is fastest differs by a few
- * percent BETWEEN DEVICES of one pool, so by default (AUTO) a handle's first bulk call of >= 8192
- * transforms on a device and shape times all of them on that call's own buffers (interleaved
- * rounds for at least 80 ms, the last nine counted; that one call is not asynchronous) and the
- * process remembers the choice for that (device, channels, size class, overlap): register loads,
- * unless another variant's median is more than 1 % ahead.  set_variant fixes the
- * choice and turns the measurement off (latency-critical callers; a call inside a hipGraph capture
- * never measures).  get_variant: what the handle's last bulk call ran, how many measurements this
- * handle made, and (ms_by_variant: 3 floats, may be NULL) the medians of its last measurement.
+ * percent between devices of one pool and from run to run.  A stream call NEVER measures (round
+ * 4; round 3's first large call blocked for ~100 ms to do so): it runs what set_variant fixed,
+ * else what an earlier sfe_dsp_fir_calibrate chose for its (device, channels, size class,
+ * overlap, per-channel taps), else register loads.
+ * sfe_dsp_fir_calibrate is the measurement, made when the caller asks: it times every variant
+ * over the caller's own buffers -- a call shaped like the stream calls to come: same n, strides
+ * and channel count; d_out receives the filtered d_in each time -- in interleaved rounds for at
+ * least 80 ms of launches, the last nine counted, SYNCHRONOUSLY on `stream`, and the process
+ * remembers the choice for that shape: register loads unless another variant's median is more
+ * than 1 % ahead.  It does not advance the stream: carried state and position are as before.
+ * `chosen` (may be NULL) receives the variant.  Refused inside a hipGraph capture (SFE_ESTATE).
+ * get_variant: what the handle's last bulk call ran, how many measurements this handle made, and
+ * (ms_by_variant: 3 floats, may be NULL) the medians of its last measurement.
  * forget_calibrations drops the process-wide memory.  No reference counterpart: blkconv has one
  * code path (libdsp/blkconv.cxx:77-110). */
 #define SFE_FIR_VARIANT_AUTO          (-1)
@@ -159,6 +164,8 @@ int sfe_dsp_fir_set_algo(sfe_fir_t h, int algo);
 int sfe_dsp_fir_set_variant(sfe_fir_t h, int variant);
 int sfe_dsp_fir_get_variant(sfe_fir_t h, int *last_variant, int *calibrations, float *ms_by_variant);
 int sfe_dsp_fir_forget_calibrations(void);
+int sfe_dsp_fir_calibrate(sfe_fir_t h, const void *d_in, void *d_out, size_t n, size_t in_stride,
+                          size_t out_stride, sfe_stream_t stream, int *chosen);
 /* Host calls (blkconv::process() on the object's buffer, sfe_dsp_fir_process_host) of at most
  * max_samples samples let the kernel read and write pinned host memory itself -- one stream
  * operation instead of copy-in, launch, copy-out (default 2^20 samples; 0 = always the DMA copies).
@@ -241,6 +248,35 @@ int sfe_dsp_fir_reset(sfe_fir_t h);
 /* Replaces blkconv::~blkconv()  libdsp/blkconv.cxx:113-122. */
 int sfe_dsp_fir_destroy(sfe_fir_t h);
 
+/* ------------------------------------------------- channel groups: one process, several GPUs
+ * The reference's multi-channel form is one object per stream (libdsp/blkconv.h:35-62): channels
+ * are independent, so they shard across devices with no exchange.  A group makes
+ * that partition inside the library for a caller that owns several GPUs in ONE process:
+ *   channels are cut into n_devices contiguous blocks -- block k holds channels
+ *   [k*base + min(k, extra), ...) with base = n_channels / n_devices, extra = n_channels %
+ *   n_devices, the first `extra` blocks one channel longer -- block k lives on devices[k] (a
+ *   device may be named more than once) as an ordinary handle with a stream of its own there.
+ * create: taps as sfe_dsp_fir_create's, or (per_channel != 0) [n_channels][n_taps] as
+ *   sfe_dsp_fir_create_per_channel's (then the data are complex).  n_devices <= n_channels.
+ * process_stream: d_in[k] / d_out[k] are block k's buffers ON devices[k], channel-major with the
+ *   given strides, n samples per channel.  The launches go to every device before anything waits
+ *   (asynchronous on the blocks' own streams); sync waits for all of them.
+ * shard: what block k is -- its device, first channel, channel count, the underlying handle (for
+ *   sfe_dsp_fir_set_variant / load_history / calibrate ... on it) and its stream (to order the
+ *   caller's copies with the block's launches).  Any out pointer may be NULL.
+ * The result equals ONE handle over all n_channels on one device, bit for bit. */
+typedef void *sfe_fir_group_t;
+int sfe_dsp_fir_group_create(const float *taps, int n_taps, int taps_complex, int data_complex, int per_channel,
+                             int n_channels, const int *devices, int n_devices, sfe_fir_group_t *out);
+int sfe_dsp_fir_group_shards(sfe_fir_group_t g, int *n_shards);
+int sfe_dsp_fir_group_shard(sfe_fir_group_t g, int shard, int *device, int *first_channel, int *n_channels,
+                            sfe_fir_t *handle, sfe_stream_t *stream);
+int sfe_dsp_fir_group_process_stream(sfe_fir_group_t g, const void *const *d_in, void *const *d_out, size_t n,
+                                     size_t in_stride, size_t out_stride);
+int sfe_dsp_fir_group_sync(sfe_fir_group_t g);
+int sfe_dsp_fir_group_reset(sfe_fir_group_t g);
+int sfe_dsp_fir_group_destroy(sfe_fir_group_t g);
+
 /* -------------------------------------------------------------- resample / decimate
  * Polyphase interpolating resampler: outputs at upsampled-grid instants t (float32
  * recurrence t += rate*upsample), pos = floor(t), mu = t - pos,
@@ -305,6 +341,21 @@ int sfe_dsp_rs_seek(sfe_rs_t h, uint64_t first_sample, float rate);
 int sfe_dsp_rs_pipe_create(sfe_rs_t rs, size_t batch_items, float rate, sfe_pipe_t *out);
 int sfe_dsp_rs_reset(sfe_rs_t h);
 int sfe_dsp_rs_destroy(sfe_rs_t h);
+/* Channel groups of resample / decimate objects (one reference object per stream,
+ * libdsp/resample.h:33-61, libdsp/decimate.h:33-63): the same partition, calls and guarantees as
+ * sfe_dsp_fir_group_* above.  All blocks are fed in lockstep, so every channel produces the same
+ * *n_out; a block handle driven on its own makes the next group call fail with SFE_ESTATE. */
+typedef void *sfe_rs_group_t;
+int sfe_dsp_rs_group_create(const float *taps, int n_taps, int upsample, int blksize, int data_complex, int n_channels,
+                            const int *devices, int n_devices, int mode, sfe_rs_group_t *out);
+int sfe_dsp_rs_group_shards(sfe_rs_group_t g, int *n_shards);
+int sfe_dsp_rs_group_shard(sfe_rs_group_t g, int shard, int *device, int *first_channel, int *n_channels,
+                           sfe_rs_t *handle, sfe_stream_t *stream);
+int sfe_dsp_rs_group_process_stream(sfe_rs_group_t g, const void *const *d_in, size_t n_in, size_t in_stride,
+                                    void *const *d_out, size_t out_cap, size_t out_stride, float rate, size_t *n_out);
+int sfe_dsp_rs_group_sync(sfe_rs_group_t g);
+int sfe_dsp_rs_group_reset(sfe_rs_group_t g);
+int sfe_dsp_rs_group_destroy(sfe_rs_group_t g);
 
 /* Host-only: replay the time law of ONE process() call without touching the GPU
  * (resample.cxx:89,119-150).  state = {pos, mu, leftover} in/out.  Writes up to cap

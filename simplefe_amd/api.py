@@ -148,7 +148,8 @@ class Fir:
         check(self._L.sfe_dsp_fir_set_algo(self._h, algo))
 
     def set_variant(self, variant):
-        """lib.FIR_VARIANT_*: fix the cf32 kernel's data-movement variant (AUTO: measured per device and shape)."""
+        """lib.FIR_VARIANT_*: fix the cf32 kernel's data-movement variant (AUTO: what calibrate() chose for the
+        shape, register loads where nothing was calibrated)."""
         check(self._L.sfe_dsp_fir_set_variant(self._h, int(variant)))
 
     def get_variant(self):
@@ -157,6 +158,16 @@ class Fir:
         ms = (C.c_float * 3)()
         check(self._L.sfe_dsp_fir_get_variant(self._h, C.byref(v), C.byref(k), ms))
         return v.value, k.value, [float(m) for m in ms]
+
+    def calibrate(self, d_in, d_out, n, in_stride=None, out_stride=None, stream=None):
+        """sfe_dsp_fir_calibrate: time the kernel's variants over these buffers (synchronous; the stream
+        does not advance) and remember the choice for this shape; returns the chosen variant."""
+        pi = d_in.ptr if isinstance(d_in, DeviceArray) else int(d_in)
+        po = d_out.ptr if isinstance(d_out, DeviceArray) else int(d_out)
+        v = C.c_int(0)
+        check(self._L.sfe_dsp_fir_calibrate(self._h, pi, po, n, n if in_stride is None else in_stride,
+                                            n if out_stride is None else out_stride, stream, C.byref(v)))
+        return v.value
 
     def set_zero_copy_max(self, max_samples):
         check(self._L.sfe_dsp_fir_set_zero_copy_max(self._h, int(max_samples)))
@@ -208,11 +219,97 @@ class Fir:
         check(self._L.sfe_dsp_fir_process_block(self._h))
 
     def close(self):
+        """sfe_dsp_fir_destroy.  A handle a pipe still borrows is NOT destroyed (SFE_ESTATE): it is kept,
+        with a warning, rather than dropped on the floor with its GPU buffers."""
         if getattr(self, "_h", None):
-            self._L.sfe_dsp_fir_destroy(self._h)
+            rc = self._L.sfe_dsp_fir_destroy(self._h)
+            if rc == _l.SFE_ESTATE:
+                import warnings
+                warnings.warn("Fir.close: a pipe still borrows this handle (sfe_dsp_pipe_destroy first); handle kept",
+                              ResourceWarning, stacklevel=2)
+                return
             self._h = None
 
     __del__ = close
+
+
+class _Group:
+    """Channel blocks of one multi-channel job on several devices of THIS process (sfe_dsp_*_group_*;
+    the partition of shard.channel_block made inside the library)."""
+    _prefix = None
+
+    def _fn(self, name):
+        return getattr(self._L, "sfe_dsp_%s_group_%s" % (self._prefix, name))
+
+    def shards(self):
+        """[(device, first_channel, n_channels, handle, stream), ...]"""
+        n = C.c_int(0)
+        check(self._fn("shards")(self._g, C.byref(n)))
+        out = []
+        for k in range(n.value):
+            d, f, c, h, s = C.c_int(0), C.c_int(0), C.c_int(0), C.c_void_p(), C.c_void_p()
+            check(self._fn("shard")(self._g, k, C.byref(d), C.byref(f), C.byref(c), C.byref(h), C.byref(s)))
+            out.append((d.value, f.value, c.value, h.value, s.value))
+        return out
+
+    @staticmethod
+    def _ptrs(arrs):
+        return (C.c_void_p * len(arrs))(*[a.ptr if isinstance(a, DeviceArray) else int(a) for a in arrs])
+
+    def sync(self):
+        check(self._fn("sync")(self._g))
+
+    def reset(self):
+        check(self._fn("reset")(self._g))
+
+    def close(self):
+        if getattr(self, "_g", None):
+            self._fn("destroy")(self._g)
+            self._g = None
+
+    __del__ = close
+
+
+class FirGroup(_Group):
+    _prefix = "fir"
+
+    def __init__(self, taps, n_channels, devices, data_complex=True, per_channel=False):
+        self._L = _l.load()
+        taps = np.asarray(taps)
+        ctaps = bool(np.iscomplexobj(taps))
+        t = (np.ascontiguousarray(taps.astype(np.complex64)).view(np.float32) if ctaps else _f32(taps)).reshape(-1)
+        n_taps = taps.shape[-1]
+        dv = (C.c_int * len(devices))(*[int(d) for d in devices])
+        g = C.c_void_p()
+        check(self._L.sfe_dsp_fir_group_create(t.ctypes.data, n_taps, int(ctaps), int(data_complex), int(per_channel),
+                                               n_channels, dv, len(devices), C.byref(g)))
+        self._g = g.value
+
+    def process_stream(self, d_in, d_out, n, in_stride=None, out_stride=None):
+        """d_in / d_out: one DeviceArray (or raw device pointer) per shard; asynchronous on the shards' streams."""
+        check(self._L.sfe_dsp_fir_group_process_stream(self._g, self._ptrs(d_in), self._ptrs(d_out), n,
+                                                       n if in_stride is None else in_stride,
+                                                       n if out_stride is None else out_stride))
+
+
+class RsGroup(_Group):
+    _prefix = "rs"
+
+    def __init__(self, taps, upsample, blksize, n_channels, devices, mode=_l.RS_RESAMPLE, data_complex=True):
+        self._L = _l.load()
+        t = _f32(taps)
+        dv = (C.c_int * len(devices))(*[int(d) for d in devices])
+        g = C.c_void_p()
+        check(self._L.sfe_dsp_rs_group_create(t.ctypes.data, t.size, upsample, blksize, int(data_complex), n_channels,
+                                              dv, len(devices), mode, C.byref(g)))
+        self._g = g.value
+
+    def process_stream(self, d_in, n_in, d_out, out_cap, rate, in_stride=None, out_stride=None):
+        k = C.c_size_t(0)
+        check(self._L.sfe_dsp_rs_group_process_stream(self._g, self._ptrs(d_in), n_in, n_in if in_stride is None else in_stride,
+                                                      self._ptrs(d_out), out_cap, out_cap if out_stride is None else out_stride,
+                                                      rate, C.byref(k)))
+        return k.value
 
 
 class Rs:
@@ -305,8 +402,14 @@ class Rs:
         return np.concatenate(outs, axis=1) if outs else np.zeros((self.n_channels, 0), np.float32)
 
     def close(self):
+        """sfe_dsp_rs_destroy; a handle a pipe still borrows is kept, with a warning (see Fir.close)."""
         if getattr(self, "_h", None):
-            self._L.sfe_dsp_rs_destroy(self._h)
+            rc = self._L.sfe_dsp_rs_destroy(self._h)
+            if rc == _l.SFE_ESTATE:
+                import warnings
+                warnings.warn("Rs.close: a pipe still borrows this handle (sfe_dsp_pipe_destroy first); handle kept",
+                              ResourceWarning, stacklevel=2)
+                return
             self._h = None
 
     __del__ = close

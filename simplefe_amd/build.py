@@ -22,6 +22,8 @@ ARCH = "gfx950"
 # bit-exact restatements of the reference arithmetic: no implicit FMA contraction
 EXACT_SOURCES = ("polyphase.hip", "util.hip")
 TICKET_SOURCES = ("fir_fft.hip", "poly_fft.hip")
+# host side only (handles, plans, launch choices, device groups): not part of the kernel-source hash
+HOST_SOURCES = ("api.hip", "group.hip")
 
 
 def sources():
@@ -43,7 +45,7 @@ def csrc_hash():
     import re
     h = hashlib.sha256()
     for p in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))):
-        if os.path.basename(p) == "api.hip":
+        if os.path.basename(p) in HOST_SOURCES:
             continue
         h.update(os.path.basename(p).encode() + b"\0")
         for line in open(p, errors="replace"):
@@ -76,7 +78,10 @@ def parse_resources(text):
             cur[m.group(1).split(" [")[0]] = int(m.group(2))
     if out:
         names = list(out)
-        dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
+        try:
+            dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
+        except OSError:         # no binutils: keep the mangled names (check_resources then sees no FIR kernel names)
+            dem = []
         if len(dem) == len(names):
             out = {d: out[n] for d, n in zip(dem, names)}
     return out
@@ -152,6 +157,10 @@ def build_lib(force=False, verbose=False, extra=(), diag=False):
         if rc != 0:
             sys.stderr.write("\n".join(l for l in text.splitlines() if "-Rpass-analysis" not in l)[-8000:])
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
+        # -Wall diagnostics must not vanish into the log on a successful compile
+        warn = [l for l in text.splitlines() if "warning:" in l and "-Rpass-analysis" not in l]
+        if warn:
+            sys.stderr.write("\n".join(warn[:40]) + "\n")
         # registers / scratch / occupancy of every kernel in the file, kept beside the object
         with open(obj[:-2] + ".resources.json", "w") as o:
             json.dump(parse_resources(text), o, indent=0, sort_keys=True)

@@ -13,6 +13,7 @@
 #include <new>
 #include <tuple>
 #include <numeric>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -50,22 +51,7 @@ int device_cu_count()
     return c;
 }
 
-// Every entry point that touches a handle runs on the handle's device and puts the caller's
-// current device back afterwards (the library must not change the caller's HIP context state).
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = true;
-    explicit DeviceGuard(int device)
-    {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != device) ok = hipSetDevice(device) == hipSuccess;
-    }
-    ~DeviceGuard()
-    {
-        int cur = -1;
-        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
-    }
-};
+// DeviceGuard: common.h
 #define SFE_ON_DEVICE(dev)                                   \
     DeviceGuard guard__(dev);                                \
     if (!guard__.ok) {                                       \
@@ -374,6 +360,8 @@ struct Fir {
     PlanCache plans;
     void *d_hist[2] = {nullptr, nullptr};
     int cur = 0;
+    bool captured = false;      // a call of this handle sits in a hipGraph that names d_hist[cur]: the state stays there (fir_run)
+    bool started = false;       // samples have gone through since create / reset
     // class-compatible host block path
     float *h_buf = nullptr;     // pinned, block_hint+2 floats (blkconv.cxx:44 sizes it so)
     void *d_blk_in = nullptr, *d_blk_out = nullptr;
@@ -560,18 +548,18 @@ static bool stream_is_capturing(hipStream_t s)
 // ---- which data-movement variant of the cf32 kernel (common.h: FIR_VAR_*) ------------------------
 // The three variants compute the same bits and differ by a few percent in time, with a sign that
 // depends on the box (profiles/r02/fir_walk_vs_tickets.txt against DESIGN.md 4.1's earlier tables:
-// LDS-DMA from -5.7 % to +3.7 % against register loads).  So a handle's first LARGE bulk call on a
-// device and shape runs every variant on the call's own buffers -- same output each time, the
-// history carry-over and the work counters are idempotent -- FIR_CAL_ROUNDS interleaved rounds, HIP
-// events on the caller's stream, and the choice (register loads unless another variant's median is more than
-// 1 % ahead) is cached process-wide under
-// (device, channels, size class, overlap, per-channel taps).  Small calls, calls inside a stream
-// capture and everything that has only one variant take the default (register loads) and measure nothing.
+// LDS-DMA from -5.7 % to +3.7 % against register loads).  Round 4: NOTHING IS
+// MEASURED ON THE CALL PATH.  A stream call runs what sfe_dsp_fir_set_variant fixed, else what an
+// earlier sfe_dsp_fir_calibrate call chose for this (device, channels, size class, overlap,
+// per-channel taps), else register loads.  sfe_dsp_fir_calibrate is the measurement, made when the
+// caller asks for it, synchronously and outside the stream: every variant over the caller's buffers
+// (same output each time; the carried state and the stream position are not touched),
+// FIR_CAL_ROUNDS interleaved rounds behind FIR_CAL_WARM_MS of launches, HIP events on the caller's
+// stream; register loads unless another variant's median is more than 1 % ahead.
 constexpr int FIR_CAL_ROUNDS = 9;                         // rounds that count: the LAST nine
 constexpr float FIR_CAL_MARGIN = 0.99f;                   // another variant displaces register loads only by more than 1 %
 constexpr int FIR_CAL_MAX_ROUNDS = 24;                    // ... of at most this many, and of at least FIR_CAL_WARM_MS of launches:
 constexpr float FIR_CAL_WARM_MS = 80.0f;                  // the chip's first ~100 ms of work after idling run 5-6 % slow
-constexpr long long FIR_CAL_MIN_TRANSFORMS = 8192;        // ~2^25 samples: below, the launch is a few tens of microseconds
 struct FirVarKey {
     int device, n_channels, size_class, ovl, per_channel;
     bool operator<(const FirVarKey &o) const
@@ -582,35 +570,37 @@ struct FirVarKey {
 static std::mutex g_fir_var_mutex;
 static std::map<FirVarKey, int> g_fir_var_cache;
 
-static int fir_pick_variant(Fir *f, FirFftArgs &a, hipStream_t s, int *variant)
+static FirVarKey fir_var_key(const Fir *f, const FirFftArgs &a)
 {
-    *variant = f->variant;                      // sfe_dsp_fir_set_variant: a fixed choice, or FIR_VAR_AUTO
-    if (*variant != FIR_VAR_AUTO) return SFE_OK;
-    *variant = FIR_VAR_REG;                     // what runs without a measurement (small calls, captures, calls with one variant)
-    if (f->parts != 1 || a.nblk * f->n_channels < FIR_CAL_MIN_TRANSFORMS ||
-        !fir_fft_has_variants(a, f->data_complex, f->out_complex, f->in_u8, f->out_tx10, f->n_channels, 0))
-        return SFE_OK;
     int sc = 0;
     for (unsigned long long v = (unsigned long long)a.nblk * f->n_channels; v > 1; v >>= 1) sc++;
-    const FirVarKey key{f->device, f->n_channels, sc, f->ovl, f->per_channel};
-    {
-        std::lock_guard<std::mutex> lk(g_fir_var_mutex);
-        auto it = g_fir_var_cache.find(key);
-        if (it != g_fir_var_cache.end()) {
-            *variant = it->second;
-            return SFE_OK;
-        }
-    }
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
-        (void)hipGetLastError();
-        return SFE_OK;                          // a capture cannot be timed: default, and nothing is cached
-    }
+    return FirVarKey{f->device, f->n_channels, sc, f->ovl, f->per_channel};
+}
+
+static bool fir_has_variants(const Fir *f, const FirFftArgs &a)
+{
+    return f->parts == 1 && fir_fft_has_variants(a, f->data_complex, f->out_complex, f->in_u8, f->out_tx10, f->n_channels, 0);
+}
+
+// what a stream call runs: a map look-up, no device work
+static int fir_pick_variant(Fir *f, const FirFftArgs &a)
+{
+    if (f->variant != FIR_VAR_AUTO) return f->variant;     // sfe_dsp_fir_set_variant
+    if (!fir_has_variants(f, a)) return FIR_VAR_REG;
+    std::lock_guard<std::mutex> lk(g_fir_var_mutex);
+    auto it = g_fir_var_cache.find(fir_var_key(f, a));
+    return it != g_fir_var_cache.end() ? it->second : FIR_VAR_REG;
+}
+
+// the measurement (sfe_dsp_fir_calibrate): `a` describes the call, a.hist_out == nullptr
+static int fir_calibrate(Fir *f, FirFftArgs &a, hipStream_t s, int *chosen)
+{
+    *chosen = FIR_VAR_REG;
+    if (!fir_has_variants(f, a)) return SFE_OK;             // one variant: nothing to choose
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
         if (e0) (void)hipEventDestroy(e0);
-        (void)hipGetLastError();
-        return SFE_OK;
+        return hip_fail(hipGetLastError(), "fir_calibrate: hipEventCreate");
     }
     const int nvar = f->per_channel ? 2 : FIR_VAR_COUNT;      // per-channel taps: no wave-private instantiation
     float t[FIR_VAR_COUNT][FIR_CAL_ROUNDS];
@@ -657,9 +647,58 @@ static int fir_pick_variant(Fir *f, FirFftArgs &a, hipStream_t s, int *variant)
     f->cal_runs++;
     {
         std::lock_guard<std::mutex> lk(g_fir_var_mutex);
-        g_fir_var_cache[key] = best;
+        g_fir_var_cache[fir_var_key(f, a)] = best;
     }
-    *variant = best;
+    *chosen = best;
+    return SFE_OK;
+}
+
+// the launch description of one bulk call over the transform kernel (partition 0)
+static void fir_fill_args(const Fir *f, FirFftArgs &a, const void *d_in, void *d_out, size_t n, size_t in_stride,
+                          size_t out_stride)
+{
+    a.in = d_in;
+    a.out = d_out;
+    a.hist = f->d_hist[f->cur];
+    a.tw1 = f->d_tw1;
+    a.tw2 = f->d_tw2;
+    a.n = (long long)n;
+    a.in_stride = (long long)in_stride;
+    a.out_stride = (long long)out_stride;
+    a.hl = f->ovl;
+    a.advance = FFT_N - f->ovl;
+    a.hist_len = f->hl;
+    a.nblk = ((long long)n + a.advance - 1) / a.advance;
+    a.ticket = f->d_ticket;
+    a.total = 0;
+    a.tgroups = 0;
+    a.hs_stride = f->per_channel ? (long long)f->parts * 16 * 256 : 0;
+    a.variant = FIR_VAR_AUTO;
+    a.hs = f->d_hs;
+    a.shift = 0;
+    a.hist_out = nullptr;
+}
+
+// Behind a call's launches: the state the NEXT call starts from.  `fused`: the main launch already wrote
+// it into d_hist[cur ^ 1].  A handle one of whose calls sits in a hipGraph keeps its state in d_hist[cur]
+// for good -- the graph names that buffer -- so an eager call on such a handle copies the new state back
+// instead of flipping (a replay after an eager call used to read the stale buffer).
+static int fir_carry_state(Fir *f, const void *d_in, size_t n, size_t in_stride, bool fused, bool capturing, hipStream_t s)
+{
+    const int width = f->data_complex ? 2 : 1;
+    if (capturing) {
+        // in place, behind everything that read the old history: with n >= hl the kernel reads `in` only
+        f->captured = true;
+        return launch_history_update(d_in, (long long)n, (long long)in_stride, f->d_hist[f->cur], f->d_hist[f->cur], f->hl,
+                                     width, f->n_channels, s, f->in_u8);
+    }
+    if (!fused) {
+        int rc = launch_history_update(d_in, (long long)n, (long long)in_stride, f->d_hist[f->cur], f->d_hist[f->cur ^ 1],
+                                       f->hl, width, f->n_channels, s, f->in_u8);
+        if (rc != SFE_OK) return rc;
+    }
+    if (f->captured) SFE_HIP(hipMemcpyAsync(f->d_hist[f->cur], f->d_hist[f->cur ^ 1], f->hist_bytes(), hipMemcpyDeviceToDevice, s));
+    else f->cur ^= 1;
     return SFE_OK;
 }
 
@@ -667,6 +706,7 @@ static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_st
                    size_t out_stride, hipStream_t s)
 {
     if (n == 0) return SFE_OK;
+    f->started = true;
     int algo = f->algo;
     if (algo == SFE_FIR_ALGO_AUTO) algo = f->fft_ok ? SFE_FIR_ALGO_FFT : SFE_FIR_ALGO_DIRECT;
     int rc;
@@ -683,33 +723,11 @@ static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_st
             return SFE_EINVAL;
         }
         FirFftArgs a;
-        a.in = d_in;
-        a.out = d_out;
-        a.hist = f->d_hist[f->cur];
+        fir_fill_args(f, a, d_in, d_out, n, in_stride, out_stride);
         hist_fused = n >= (size_t)f->hl && !capturing;   // else the old history still contributes (captured: in place, below)
-        a.tw1 = f->d_tw1;
-        a.tw2 = f->d_tw2;
-        a.n = (long long)n;
-        a.in_stride = (long long)in_stride;
-        a.out_stride = (long long)out_stride;
-        a.hl = f->ovl;
-        a.advance = FFT_N - f->ovl;
-        a.hist_len = f->hl;
-        a.nblk = ((long long)n + a.advance - 1) / a.advance;
-        a.ticket = f->d_ticket;
-        a.total = 0;
-        a.tgroups = 0;
-        a.hs_stride = f->per_channel ? (long long)f->parts * 16 * 256 : 0;
-        a.variant = FIR_VAR_AUTO;
-        a.hs = f->d_hs;
-        a.shift = 0;
-        a.hist_out = hist_fused ? f->d_hist[f->cur ^ 1] : nullptr;
-        // the launches of the measurement ARE this call's (same output every time); the one below repeats it once more
-        int variant = FIR_VAR_AUTO;
-        rc = fir_pick_variant(f, a, s, &variant);
-        if (rc != SFE_OK) return rc;
-        a.variant = variant;
-        f->last_variant = variant;
+        a.variant = fir_pick_variant(f, a);
+        f->last_variant = a.variant;
+        rc = SFE_OK;
         // one launch per tap partition: partition p filters the stream delayed by p*ovl samples and
         // (p > 0) adds to what the earlier ones wrote
         for (int p = 0; p < f->parts && rc == SFE_OK; p++) {
@@ -759,18 +777,7 @@ static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_st
         }
     }
     if (rc != SFE_OK) return rc;
-    if (capturing) {
-        // in place, behind everything that read the old history: with n >= hl the kernel reads `in` only
-        return launch_history_update(d_in, (long long)n, (long long)in_stride, f->d_hist[f->cur],
-                                     f->d_hist[f->cur], f->hl, f->data_complex ? 2 : 1, f->n_channels, s, f->in_u8);
-    }
-    if (!hist_fused) {
-        rc = launch_history_update(d_in, (long long)n, (long long)in_stride, f->d_hist[f->cur],
-                                   f->d_hist[f->cur ^ 1], f->hl, f->data_complex ? 2 : 1, f->n_channels, s, f->in_u8);
-        if (rc != SFE_OK) return rc;
-    }
-    f->cur ^= 1;
-    return SFE_OK;
+    return fir_carry_state(f, d_in, n, in_stride, hist_fused, capturing, s);
 }
 
 // ------------------------------------------------------------------ resample / decimate
@@ -790,6 +797,7 @@ struct Rs {
     unsigned *d_ticket = nullptr;          // work counters of the transform-domain kernel
     void *d_hist[2] = {nullptr, nullptr};
     int cur = 0;
+    bool captured = false;                 // a call of this handle sits in a hipGraph that names d_hist[cur] (see fir_carry_state)
     sfe_rs_timestate ts = {0, 0.0f, 0};
     // class-compatible host path staging (one channel)
     void *d_in = nullptr, *d_out = nullptr;
@@ -1288,7 +1296,8 @@ int sfe_dsp_fir_load_history(sfe_fir_t h, const void *d_prev, size_t n_prev, siz
         int rc = launch_history_update(d_prev, (long long)n_prev, (long long)stride, f->d_hist[f->cur], f->d_hist[f->cur ^ 1],
                                        f->hl, f->data_complex ? 2 : 1, f->n_channels, s, 0);
         if (rc != SFE_OK) return rc;
-        f->cur ^= 1;
+        if (f->captured) SFE_HIP(hipMemcpyAsync(f->d_hist[f->cur], f->d_hist[f->cur ^ 1], f->hist_bytes(), hipMemcpyDeviceToDevice, s));
+        else f->cur ^= 1;
     }
     return SFE_OK;
 }
@@ -1319,28 +1328,55 @@ static int fir_replan_single(Fir *f)
     const int need = f->n_taps > 1 ? f->n_taps - 1 : 1;
     const int hl1 = ((need + 255) / 256) * 256;
     if (hl1 >= FFT_N) return SFE_ESTATE;
+    if (f->started || f->captured) {
+        // the re-plan zeroes the carried state and frees buffers a captured graph names
+        set_error("fir_set_output_format: this filter must be re-planned as one launch for 10-bit output, which "
+                  "restarts the stream: set the format before the first process call (or after sfe_dsp_fir_reset)");
+        return SFE_ESTATE;
+    }
     SFE_HIP(hipDeviceSynchronize());
-    if (f->d_hs) (void)hipFree(f->d_hs);
-    if (f->d_tw1) (void)hipFree(f->d_tw1);
-    if (f->d_tw2) (void)hipFree(f->d_tw2);
-    if (f->d_ticket) (void)hipFree(f->d_ticket);
+    // build the new plan beside the old one and swap only when all of it exists: a failure leaves the handle as it was
+    struct Saved {
+        v2f *hs, *tw1, *tw2;
+        unsigned *ticket;
+        void *hist[2];
+        int parts, ovl, hl, cur;
+        bool fft_ok;
+    } old = {f->d_hs, f->d_tw1, f->d_tw2, f->d_ticket, {f->d_hist[0], f->d_hist[1]}, f->parts, f->ovl, f->hl, f->cur, f->fft_ok};
     f->d_hs = f->d_tw1 = f->d_tw2 = nullptr;
     f->d_ticket = nullptr;
-    for (int i = 0; i < 2; i++) {
-        if (f->d_hist[i]) (void)hipFree(f->d_hist[i]);
-        f->d_hist[i] = nullptr;
-    }
+    f->d_hist[0] = f->d_hist[1] = nullptr;
     f->parts = 1;
     f->ovl = hl1;
     f->hl = hl1;
     f->cur = 0;
     int rc = fir_build_tables(f, f->h_taps_all.data());
-    if (rc != SFE_OK) return rc;
-    for (int i = 0; i < 2; i++) {
-        SFE_HIP(hipMalloc(&f->d_hist[i], f->hist_bytes()));
-        SFE_HIP(hipMemset(f->d_hist[i], 0, f->hist_bytes()));
+    for (int i = 0; i < 2 && rc == SFE_OK; i++) {
+        hipError_t e = hipMalloc(&f->d_hist[i], f->hist_bytes());
+        if (e == hipSuccess) e = hipMemset(f->d_hist[i], 0, f->hist_bytes());
+        if (e != hipSuccess) rc = hip_fail(e, "fir_replan_single: history");
     }
-    return SFE_OK;
+    if (rc == SFE_OK) {
+        void *drop[6] = {old.hs, old.tw1, old.tw2, old.ticket, old.hist[0], old.hist[1]};
+        for (void *q : drop)
+            if (q) (void)hipFree(q);
+        return SFE_OK;
+    }
+    void *drop[6] = {f->d_hs, f->d_tw1, f->d_tw2, f->d_ticket, f->d_hist[0], f->d_hist[1]};
+    for (void *q : drop)
+        if (q) (void)hipFree(q);
+    f->d_hs = old.hs;
+    f->d_tw1 = old.tw1;
+    f->d_tw2 = old.tw2;
+    f->d_ticket = old.ticket;
+    f->d_hist[0] = old.hist[0];
+    f->d_hist[1] = old.hist[1];
+    f->parts = old.parts;
+    f->ovl = old.ovl;
+    f->hl = old.hl;
+    f->cur = old.cur;
+    f->fft_ok = old.fft_ok;
+    return rc;
 }
 
 int sfe_dsp_fir_set_output_format(sfe_fir_t h, int fmt)
@@ -1397,6 +1433,34 @@ int sfe_dsp_fir_get_variant(sfe_fir_t h, int *last_variant, int *calibrations, f
     return SFE_OK;
 }
 
+int sfe_dsp_fir_calibrate(sfe_fir_t h, const void *d_in, void *d_out, size_t n, size_t in_stride,
+                          size_t out_stride, sfe_stream_t stream, int *chosen)
+{
+    Fir *f = as_fir(h);
+    if (chosen) *chosen = SFE_FIR_VARIANT_REGISTER_LOADS;
+    if (!f || !n || !d_in || !d_out) {
+        set_error("fir_calibrate: null handle or buffer");
+        return SFE_EINVAL;
+    }
+    if (f->n_channels > 1 && (in_stride < n || out_stride < n)) {
+        set_error("fir_calibrate: channel stride smaller than n");
+        return SFE_EINVAL;
+    }
+    if (!f->fft_ok || f->algo == SFE_FIR_ALGO_DIRECT) return SFE_OK;    // the direct kernel has one form
+    SFE_ON_DEVICE(f->device);
+    hipStream_t s = (hipStream_t)stream;
+    if (stream_is_capturing(s)) {
+        set_error("fir_calibrate: a measurement cannot be captured into a hipGraph");
+        return SFE_ESTATE;
+    }
+    FirFftArgs a;
+    fir_fill_args(f, a, d_in, d_out, n, in_stride, out_stride);      // hist_out stays null: the stream does not advance
+    int best = FIR_VAR_REG;
+    int rc = fir_calibrate(f, a, s, &best);
+    if (rc == SFE_OK && chosen) *chosen = best;
+    return rc;
+}
+
 int sfe_dsp_fir_forget_calibrations(void)
 {
     std::lock_guard<std::mutex> lk(g_fir_var_mutex);
@@ -1425,6 +1489,7 @@ int sfe_dsp_fir_reset(sfe_fir_t h)
     SFE_HIP(hipDeviceSynchronize());
     for (int i = 0; i < 2; i++) SFE_HIP(hipMemset(f->d_hist[i], 0, f->hist_bytes()));
     if (f->d_ticket) SFE_HIP(hipMemset(f->d_ticket, 0, FIR_TICKET_GROUPS_MAX * 128));
+    f->started = false;         // `captured` stays: a graph made before the reset still names d_hist[cur]
     return SFE_OK;
 }
 
@@ -1627,7 +1692,10 @@ int sfe_dsp_rs_process(sfe_rs_t h, const float *in, int n_in, float *out, int ou
     rc = launch_history_update(r->d_in, n_in, n_in, r->d_hist[r->cur], r->d_hist[r->cur ^ 1], r->hl,
                                r->data_complex ? 2 : 1, 1, r->stream);
     if (rc != SFE_OK) return rc;
-    r->cur ^= 1;
+    if (r->captured)
+        SFE_HIP(hipMemcpyAsync(r->d_hist[r->cur], r->d_hist[r->cur ^ 1], (size_t)r->hl * r->esz(), hipMemcpyDeviceToDevice, r->stream));
+    else
+        r->cur ^= 1;
     if (n > 0) SFE_HIP(hipMemcpyAsync(r->h_stage, r->d_out, (size_t)n * r->esz(), hipMemcpyDeviceToHost, r->stream));
     SFE_HIP(hipStreamSynchronize(r->stream));
     if (n > 0) memcpy(out, r->h_stage, (size_t)n * r->esz());
@@ -1964,15 +2032,23 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         r->ts = st;
         *n_out = K;
     }
-    if (capturing)          // in place behind the main launch: with n_in >= hl the kernel reads `in` only; the time state did not move
+    if (capturing) {        // in place behind the main launch: with n_in >= hl the kernel reads `in` only; the time state did not move
+        r->captured = true;
         return launch_history_update(d_in, (long long)n_in, (long long)in_stride, r->d_hist[r->cur],
                                      r->d_hist[r->cur], r->hl, r->data_complex ? 2 : 1, r->n_channels, s, r->in_u8);
+    }
     if (!hist_fused) {
         rc = launch_history_update(d_in, (long long)n_in, (long long)in_stride, r->d_hist[r->cur],
                                    r->d_hist[r->cur ^ 1], r->hl, r->data_complex ? 2 : 1, r->n_channels, s, r->in_u8);
         if (rc != SFE_OK) return rc;
     }
-    r->cur ^= 1;
+    // a handle one of whose calls sits in a hipGraph keeps its history in d_hist[cur], the buffer the graph
+    // names: eager calls copy the new history back instead of flipping (fir_carry_state has the reasoning)
+    if (r->captured)
+        SFE_HIP(hipMemcpyAsync(r->d_hist[r->cur], r->d_hist[r->cur ^ 1], (size_t)r->n_channels * r->hl * r->esz(),
+                               hipMemcpyDeviceToDevice, s));
+    else
+        r->cur ^= 1;
     return SFE_OK;
 }
 
@@ -2001,7 +2077,8 @@ int sfe_dsp_rs_load_history(sfe_rs_t h, const void *d_prev, size_t n_prev, size_
         int rc = launch_history_update(d_prev, (long long)n_prev, (long long)stride, r->d_hist[r->cur], r->d_hist[r->cur ^ 1],
                                        r->hl, r->data_complex ? 2 : 1, r->n_channels, s, 0);
         if (rc != SFE_OK) return rc;
-        r->cur ^= 1;
+        if (r->captured) SFE_HIP(hipMemcpyAsync(r->d_hist[r->cur], r->d_hist[r->cur ^ 1], hb, hipMemcpyDeviceToDevice, s));
+        else r->cur ^= 1;
     }
     return SFE_OK;
 }
@@ -2079,7 +2156,11 @@ int sfe_dsp_rs_set_algo(sfe_rs_t h, int algo)
     if (!r || algo < SFE_RS_ALGO_AUTO || algo > SFE_RS_ALGO_MFMA) return SFE_EINVAL;
     r->fft_mode = algo == SFE_RS_ALGO_FFT ? 1 : (algo == SFE_RS_ALGO_AUTO ? 0 : -1);
     r->use_mfma = algo == SFE_RS_ALGO_MFMA;
-    // plans are cached per (step, pos0) together with the choice that made them
+    // plans are cached per (step, pos0) together with the choice that made them; clearing frees
+    // device tables a launch in flight may still read, so wait for the handle's device first, in
+    // ITS context (the current device of a multi-GPU caller may be another one)
+    SFE_ON_DEVICE(r->device);
+    SFE_HIP(hipDeviceSynchronize());
     r->fft_plans.clear();
     return SFE_OK;
 }

@@ -31,6 +31,23 @@ int hip_fail(hipError_t e, const char *what);
 // from it; 256 if the attribute cannot be read.
 int device_cu_count();
 
+// Every entry point that touches a handle runs on the handle's device and puts the caller's
+// current device back afterwards (the library must not change the caller's HIP context state).
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) ok = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
 #define SFE_HIP(call)                                         \
     do {                                                      \
         hipError_t e__ = (call);                              \

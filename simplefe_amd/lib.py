@@ -58,6 +58,7 @@ SIGNATURES = {
     "sfe_dsp_fir_set_variant": (i32, [vp, i32]),
     "sfe_dsp_fir_get_variant": (i32, [vp, C.POINTER(i32), C.POINTER(i32), fp]),
     "sfe_dsp_fir_forget_calibrations": (i32, []),
+    "sfe_dsp_fir_calibrate": (i32, [vp, vp, vp, sz, sz, sz, vp, C.POINTER(i32)]),
     "sfe_dsp_rs_set_algo": (i32, [vp, i32]),
     "sfe_dsp_fir_pipe_create": (i32, [vp, sz, C.POINTER(vp)]),
     "sfe_dsp_rs_pipe_create": (i32, [vp, sz, f32, C.POINTER(vp)]),
@@ -87,6 +88,20 @@ SIGNATURES = {
     "sfe_dsp_rs_reset": (i32, [vp]),
     "sfe_dsp_rs_destroy": (i32, [vp]),
     "sfe_dsp_rs_plan": (i32, [C.POINTER(TimeState), i32, i32, i32, f32, vp, vp, i32, C.POINTER(i32)]),
+    "sfe_dsp_fir_group_create": (i32, [vp, i32, i32, i32, i32, i32, C.POINTER(i32), i32, C.POINTER(vp)]),
+    "sfe_dsp_fir_group_shards": (i32, [vp, C.POINTER(i32)]),
+    "sfe_dsp_fir_group_shard": (i32, [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(vp), C.POINTER(vp)]),
+    "sfe_dsp_fir_group_process_stream": (i32, [vp, C.POINTER(vp), C.POINTER(vp), sz, sz, sz]),
+    "sfe_dsp_fir_group_sync": (i32, [vp]),
+    "sfe_dsp_fir_group_reset": (i32, [vp]),
+    "sfe_dsp_fir_group_destroy": (i32, [vp]),
+    "sfe_dsp_rs_group_create": (i32, [vp, i32, i32, i32, i32, i32, C.POINTER(i32), i32, i32, C.POINTER(vp)]),
+    "sfe_dsp_rs_group_shards": (i32, [vp, C.POINTER(i32)]),
+    "sfe_dsp_rs_group_shard": (i32, [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(vp), C.POINTER(vp)]),
+    "sfe_dsp_rs_group_process_stream": (i32, [vp, C.POINTER(vp), sz, sz, C.POINTER(vp), sz, sz, f32, C.POINTER(sz)]),
+    "sfe_dsp_rs_group_sync": (i32, [vp]),
+    "sfe_dsp_rs_group_reset": (i32, [vp]),
+    "sfe_dsp_rs_group_destroy": (i32, [vp]),
     "sfe_dsp_rx_u8_to_f32": (i32, [vp, vp, sz, vp]),
     "sfe_dsp_tx_f32_to_10bit": (i32, [vp, vp, sz, vp]),
 }

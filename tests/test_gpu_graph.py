@@ -117,6 +117,80 @@ def test_fir_call_captured_once_replays_the_next_chunks(api, L, n_taps, nch):
     assert np.array_equal(g_out.to_numpy(), d_out.to_numpy())
 
 
+def test_graph_replays_and_eager_calls_interleave_on_one_handle(api, L):
+    """a captured call names the history buffer of the moment; an eager call used to move
+    the handle to the other buffer, after which a replay read (and wrote) stale state.  Now a handle
+    that has been captured keeps its state where the graph expects it: replays, eager calls, a call
+    shorter than the history and load_history interleave and equal the all-eager stream bit for bit."""
+    hip = Hip()
+    taps = synth.taps_cfg2()
+    n = 3840 * 5 + 100
+    plan = ["e", "g", "g", "e", "g", "s", "g", "e", "e", "g"]           # eager / graph replay / short eager call (100 < hl)
+    lens = [100 if k == "s" else n for k in plan]
+    x = synth.synth_cf32(sum(lens), ch=61)
+    fe = api.Fir(taps, data_complex=True)
+    want, off = [], 0
+    d_in, d_out = api.DeviceArray(2 * n), api.DeviceArray(2 * n)
+    for m in lens:
+        _h2d(api, L, d_in, np.ascontiguousarray(x[2 * off: 2 * (off + m)]), None)
+        fe.process_stream(d_in, d_out, m)
+        want.append(d_out.to_numpy(2 * m))
+        off += m
+    fg = api.Fir(taps, data_complex=True)
+    g_in, g_out = api.DeviceArray(2 * n), api.DeviceArray(2 * n)
+    s = g = ex = None
+    off = 0
+    for i, (kind, m) in enumerate(zip(plan, lens)):
+        chunk = np.ascontiguousarray(x[2 * off: 2 * (off + m)])
+        if kind == "g":
+            if ex is None:
+                s, g, ex = hip.capture(lambda st: fg.process_stream(g_in, g_out, n, stream=st))
+            _h2d(api, L, g_in, chunk, s.value)
+            hip.launch(ex, s)
+            hip.sync(s)
+        else:
+            _h2d(api, L, g_in, chunk, None)
+            fg.process_stream(g_in, g_out, m)
+            api.sync()
+        assert np.array_equal(g_out.to_numpy(2 * m), want[i]), (i, kind)
+        off += m
+    hip.free(s, g, ex)
+
+    # the same for a resampler handle (integer-valued step)
+    U, S = 3, 5
+    rate = float(np.float32(S) / np.float32(U))
+    n = S * 231 * 40
+    cap = n * U // S + 8
+    plan = ["e", "g", "e", "g", "g", "e", "g"]
+    xr = synth.synth_cf32(n * len(plan), ch=62)
+    re_ = api.Rs(synth.taps_cfg3(), U, 4096, mode=L.RS_RESAMPLE, data_complex=True)
+    d_in, d_out = api.DeviceArray(2 * n), api.DeviceArray(2 * cap)
+    want = []
+    for i in range(len(plan)):
+        _h2d(api, L, d_in, np.ascontiguousarray(xr[2 * n * i: 2 * n * (i + 1)]), None)
+        k = re_.process_stream(d_in, n, d_out, cap, rate)
+        want.append(d_out.to_numpy(2 * k))
+    rg = api.Rs(synth.taps_cfg3(), U, 4096, mode=L.RS_RESAMPLE, data_complex=True)
+    g_in, g_out = api.DeviceArray(2 * n), api.DeviceArray(2 * cap)
+    s = g = ex = None
+    ks = []
+    for i, kind in enumerate(plan):
+        chunk = np.ascontiguousarray(xr[2 * n * i: 2 * n * (i + 1)])
+        if kind == "g":
+            if ex is None:
+                s, g, ex = hip.capture(lambda st: ks.append(rg.process_stream(g_in, n, g_out, cap, rate, stream=st)))
+            _h2d(api, L, g_in, chunk, s.value)
+            hip.launch(ex, s)
+            hip.sync(s)
+            k = ks[0]
+        else:
+            _h2d(api, L, g_in, chunk, None)
+            k = rg.process_stream(g_in, n, g_out, cap, rate)
+            api.sync()
+        assert np.array_equal(g_out.to_numpy(2 * k), want[i]), (i, kind)
+    hip.free(s, g, ex)
+
+
 @pytest.mark.parametrize("which,U,S,n_taps,exact", [("resample", 3, 5, 381, False), ("resample", 3, 5, 381, True),
                                                     ("decimate", 1, 8, 64, False), ("decimate", 1, 8, 64, True)])
 def test_rs_call_captured_once_replays_the_next_chunks(api, L, which, U, S, n_taps, exact):

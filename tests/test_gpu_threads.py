@@ -57,7 +57,7 @@ def test_handles_driven_from_concurrent_host_threads_equal_the_same_handles_alon
     for j in jobs:
         _run(api, j, None, 3, alone, errs)
     assert not errs, errs
-    LL.sfe_dsp_fir_forget_calibrations()    # the two FIR threads now race to measure the same shape
+    LL.sfe_dsp_fir_forget_calibrations()
     together = {}
     streams = [torch.cuda.Stream() for _ in jobs]
     threads = [threading.Thread(target=_run, args=(api, j, s.cuda_stream, 3, together, errs)) for j, s in zip(jobs, streams)]
