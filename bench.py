@@ -82,6 +82,8 @@ def parse():
     ap.add_argument("--no-others", action="store_true", help="skip the other_configs legs")
     ap.add_argument("--no-calibrate", action="store_true",
                     help="do not call sfe_dsp_fir_calibrate before the headline leg (run the default variant)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="one process drives all --gpus devices through sfe_dsp_fir_group_* (no torch.distributed)")
     ap.add_argument("--other-steps", type=int, default=20)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--precondition", type=float, default=0.15, help="seconds of untimed launches before any warm-up")
@@ -463,6 +465,99 @@ def make_rs_leg(ctx, which, log2n, in_fmt="f32", short_proto=False):
     return leg
 
 
+def group_leg(ctx, taps, total_channels, n_ch, devices, steps, warmup):
+    """ONE process, len(devices) devices: the channel partition made inside the library
+    (sfe_dsp_fir_group_*, include/sfe_dsp.h) instead of one rank per GPU.  Launches go to every
+    device before anything waits; the time is the wall clock around `steps` group calls and one
+    sync.  Every shard's first and last channel is checked against the oracle (first and last
+    window), and the float64 checksum over all outputs is what the rank-per-GPU form all-reduces."""
+    torch, api, synth, L = ctx["torch"], ctx["api"], ctx["synth"], ctx["L"]
+    from oracle import binding as orc
+    grp = api.FirGroup(taps, total_channels, devices)
+    sh = grp.shards()
+    xs, ys = [], []
+    for d, f, c, _, _ in sh:
+        with torch.cuda.device(d):
+            x = torch.empty(c * n_ch * 2, dtype=torch.float32, device="cuda:%d" % d)
+            for k in range(c):
+                api.check(L.sfe_dsp_synth_fill(x.data_ptr() + k * n_ch * 8, 2 * n_ch, synth.SEED, f + k, 0, None))
+            torch.cuda.synchronize(d)
+            xs.append(x)
+            ys.append(torch.empty_like(x))
+    pin, pout = [x.data_ptr() for x in xs], [y.data_ptr() for y in ys]
+    for _ in range(max(2, warmup)):
+        grp.process_stream(pin, pout, n_ch)
+    grp.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        grp.process_stream(pin, pout, n_ch)
+    grp.sync()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    # parity: history = the tail of the same buffer (every call re-reads the same input)
+    W, hlen, worst, count = 1 << 13, len(taps) - 1, 0.0, 0
+    blk = lambda v: orc.Blkconv(np.ascontiguousarray(taps, dtype=np.float32), 4096).stream(np.ascontiguousarray(v))
+    csum = [0.0, 0.0, 0.0, 0.0]
+    for (d, f, c, _, _), x, y in zip(sh, xs, ys):
+        for k in sorted({0, c - 1}):
+            xc, yc = x[2 * n_ch * k: 2 * n_ch * (k + 1)], y[2 * n_ch * k: 2 * n_ch * (k + 1)]
+            for s0 in (0, n_ch - W):
+                seg = (np.concatenate([xc[2 * (n_ch - hlen):].cpu().numpy(), xc[: 2 * W].cpu().numpy()]) if s0 == 0
+                       else xc[2 * (s0 - hlen): 2 * (s0 + W)].cpu().numpy())
+                got = yc[2 * s0: 2 * (s0 + W)].cpu().numpy()
+                worst = max(worst, synth.rel_rms(got[0::2], blk(seg[0::2])[hlen:]), synth.rel_rms(got[1::2], blk(seg[1::2])[hlen:]))
+                count += 1
+        for k in range(c):
+            v = y[2 * n_ch * k: 2 * n_ch * (k + 1)]
+            for off in range(0, 2 * n_ch, 1 << 27):
+                w = v[off: off + (1 << 27)].view(-1, 2).to(torch.float64)
+                csum[1] += float(w[:, 0].sum().item())
+                csum[2] += float(w[:, 1].sum().item())
+                csum[3] += float((w * w).sum().item())
+        csum[0] += float(c * n_ch)
+    grp.close()
+    job = float(total_channels) * n_ch
+    return {"ms": ms, "value": job / (ms * 1e-3) / 1e6, "unit": "MS/s",
+            "frac": 16.0 * job / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * len(set(devices))),
+            "devices": list(devices), "shards": [[d, f, c] for d, f, c, _, _ in sh],
+            "parity": {"rel_rms_max": worst, "windows": count, "window_len": W, "tol": TOL, "ok": bool(worst <= TOL)},
+            "checksum": {"samples": csum[0], "sum_re": csum[1], "sum_im": csum[2], "sum_abs2": csum[3]},
+            "timed": "wall clock around %d sfe_dsp_fir_group_process_stream calls + one sfe_dsp_fir_group_sync" % steps}
+
+
+def main_single_process(args):
+    """`python bench.py --gpus N --single-process`: BASELINE configs[4] (64 channels x 2^24) driven from ONE
+    process through sfe_dsp_fir_group_* over N devices -- the form a C++ flowgraph would use.  Same
+    contract line; SFE_BENCH_ONE_DEVICE=1 rehearses it with N blocks on device 0."""
+    import torch
+    from simplefe_amd import api, lib, shard, synth
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libsfe_dsp has no CPU fallback")
+    one_dev = bool(os.environ.get("SFE_BENCH_ONE_DEVICE"))
+    if torch.cuda.device_count() < args.gpus and not one_dev:
+        raise SystemExit(f"--gpus {args.gpus} but this node shows {torch.cuda.device_count()} GPU(s)")
+    devices = [0] * args.gpus if one_dev else list(range(args.gpus))
+    ctx = {"torch": torch, "api": api, "lib": lib, "synth": synth, "shard": shard, "L": lib.load()}
+    total_channels = args.channels or 64
+    log2n = args.log2n or 30
+    n_ch = (1 << log2n) // total_channels
+    g = group_leg(ctx, synth.taps_cfg2(), total_channels, n_ch, devices, args.steps, args.warmup)
+    out = {"metric": "complex-float32 MS/s through 256-tap blkconv FIR; % of HBM roofline", "value": g["value"], "unit": "MS/s",
+           "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": g["ms"], "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "%d independent cf32 channels x %s samples, 256-tap FIR (blkconv law), ONE process driving %d device(s) "
+                                  "through sfe_dsp_fir_group_*, device-resident in/out" % (total_channels, _p2(n_ch), args.gpus),
+                      "channels_total": total_channels, "samples_per_channel": n_ch, "devices": g["devices"], "shards": g["shards"],
+                      "sharding": "contiguous channel blocks per device inside the library, no data-path exchange"},
+           "roofline": {"bound": "hbm", "achieved": 16.0 * total_channels * n_ch / (g["ms"] * 1e-3) / 1e9,
+                        "peak": HBM_PEAK_GBS * len(set(devices)), "unit": "GB/s", "frac": g["frac"], "traffic": None,
+                        "kernel": "fir_fft4096_kernel", "kernel_ms": g["ms"],
+                        "note": "kernel_ms = wall time per group call (all devices in flight together); " + g["timed"]},
+           "parity": g["parity"], "checksum": g["checksum"]}
+    print(json.dumps(out), flush=True)
+    if not g["parity"]["ok"]:
+        raise SystemExit(3)
+
+
 def time_leg(ctx, leg, steps, warmup):
     """W untimed steps, then exactly `steps` timed ones between barriers; returns
     (wall seconds max over ranks, the HIP-event ms of every timed step on the launch stream)."""
@@ -584,6 +679,10 @@ def split_stream_check(ctx, taps):
 
 def main():
     args = parse()
+    if args.single_process:
+        if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+            raise SystemExit("--single-process is one process by definition: start it bare, not under torch.distributed.run")
+        return main_single_process(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)                 # does not return
     from simplefe_amd import shard
@@ -755,6 +854,24 @@ def main():
         out["other_configs"] = other_rows + other_errors
     if world > 1 and head.kind == "fir" and not np.iscomplexobj(head.taps):
         out["split_stream"] = split_stream_check(ctx, head.taps)
+    if sharded and not args.no_others and args.input == "f32" and args.output == "f32" and args.algo == "auto":
+        # The same fixed job driven from ONE process through sfe_dsp_fir_group_* (the form a C++ flowgraph
+        # uses), outside every timed region: rank 0 drives all N devices while the other ranks wait on the
+        # HOST (a gloo group: an RCCL barrier would keep a kernel spinning on the very GPUs being timed).
+        host = dist.new_group(backend="gloo")
+        torch.cuda.synchronize()
+        dist.barrier(group=host)
+        if rank == 0:
+            try:
+                devs = [0] * world if os.environ.get("SFE_BENCH_ONE_DEVICE") else list(range(world))
+                g = group_leg(ctx, head.taps, total_channels, head.n, devs, args.other_steps, 3)
+                g["workload"] = "the same job, ONE process driving %d device(s) through sfe_dsp_fir_group_* (no torch.distributed)" % world
+                g["checksum_equals_ranks"] = bool(all(abs(a - b) <= 1e-9 * max(1.0, abs(b)) for a, b in
+                                                      zip([g["checksum"][k] for k in ("samples", "sum_re", "sum_im", "sum_abs2")], csum)))
+                out["single_process_group"] = g
+            except Exception as e:          # reported, never allowed to take the headline with it
+                out["single_process_group"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        dist.barrier(group=host)
     if rank == 0 and world == 1 and not args.no_cpu:
         if head.kind == "fir":
             out["cpu_baseline"] = cpu_baseline_fir(np.real(head.taps).astype(np.float32), args.cpu_seconds)

@@ -54,6 +54,33 @@ def test_bench_gpus2_from_a_bare_shell_starts_two_ranks_and_checks_both():
         assert abs(a - b) <= 1e-9 * max(1.0, abs(a)), (k, a, b)
 
 
+def test_bench_gpus4_rehearsal_and_the_single_process_group_form():
+    """Four ranks on the one device (the card allows six processes; eight ranks are rehearsed over gloo on
+    the CPU, tests/test_shard_gloo.py): 64 channels as 16 + 16 + 16 + 16, one stream cut into four spans,
+    rank 0's calibrated variant run by every rank, and -- outside the timed region -- the SAME job driven by
+    rank 0 alone through sfe_dsp_fir_group_* over four blocks: same checksum as the four ranks' all-reduce."""
+    r4, j4 = _bench("--gpus", "4", "--log2n", "24", "--steps", "3", "--warmup", "1", "--other-steps", "3", "--no-cpu",
+                    env_extra={"SFE_BENCH_ONE_DEVICE": "1"}, timeout=900)
+    assert r4.returncode == 0, r4.stdout + r4.stderr
+    assert j4["n_gpus"] == 4 and j4["scaling"] == "strong" and j4["config"]["channels_per_gpu"] == 16
+    assert j4["parity"]["ok"] and j4["parity"]["ranks_checked"] == 4 and j4["parity"]["windows"] == 128
+    assert j4["roofline"]["variant"]["chosen_by"].endswith("broadcast to all ranks")
+    ss = j4["split_stream"]
+    assert ss["ok"] and ss["spans"] == 4 and ss["exchange"].startswith("point-to-point"), ss
+    g = j4["single_process_group"]
+    assert "error" not in g, g
+    assert g["parity"]["ok"] and g["checksum_equals_ranks"] and g["devices"] == [0, 0, 0, 0]
+    assert [c for _, _, c in g["shards"]] == [16, 16, 16, 16]
+    # and the bare single-process form of the line
+    r1, j1 = _bench("--gpus", "8", "--single-process", "--log2n", "24", "--steps", "3", "--warmup", "1",
+                    env_extra={"SFE_BENCH_ONE_DEVICE": "1"})
+    assert r1.returncode == 0, r1.stdout + r1.stderr
+    assert j1["n_gpus"] == 8 and j1["parity"]["ok"] and len(j1["config"]["shards"]) == 8
+    for k in ("sum_re", "sum_im", "sum_abs2"):
+        a, b = j1["checksum"][k], j4["checksum"][k]
+        assert abs(a - b) <= 1e-9 * max(1.0, abs(a)), (k, a, b)
+
+
 def test_bench_gpus2_default_shape_carries_the_weak_row():
     """No --log2n/--channels at N > 1: the 64 x 2^24 job as the headline (32 channels per rank here)
     and the round-2 weak shape (8 channels x 2^25 per rank) as an other_configs row, both checked."""

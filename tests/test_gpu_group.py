@@ -34,7 +34,7 @@ def _streams(api, nch, n, first_seed=0):
 @pytest.mark.parametrize("devices", [[0, 0], [0] * 8, [0, 0, 0]])
 @pytest.mark.parametrize("per_channel", [False, True])
 def test_fir_group_equals_one_handle_over_all_channels(api, L, devices, per_channel):
-    nch, n, calls = 64, 3840 * 9 + 123, 3
+    nch, n, calls = 64, 3840 * 9 + 124, 3          # even: channel rows stay 16-byte aligned for synth_fill
     taps = synth.taps_per_channel(nch) if per_channel else synth.taps_cfg2()
     one = api.Fir(taps, per_channel=True) if per_channel else api.Fir(taps, data_complex=True, n_channels=nch)
     grp = api.FirGroup(taps, nch, devices, per_channel=per_channel)

@@ -1,4 +1,6 @@
-"""The N > 1 path on CPU: two gloo ranks, channel-block sharding, MAX/SUM control collectives.
+"""The N > 1 path on CPU: two and EIGHT gloo ranks (the driver's N = 8 shape; the GPU box allows at most
+six processes on its card, so eight ranks are rehearsed here), channel-block sharding, MAX/SUM control
+collectives, rank 0's choice handed to every rank, the host-side (gloo) barrier group.
 The per-channel "filter" here is the oracle (this is a test); on GPUs bench.py runs the same
 sharding logic with libsfe_dsp kernels and RCCL."""
 import os
@@ -7,6 +9,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -14,12 +17,21 @@ WORKER = r"""
 import os, sys, time
 sys.path.insert(0, %(root)r)
 import numpy as np
+import pytest
 import torch
 from simplefe_amd import shard, synth
 from oracle import binding as orc
 rank, local_rank, world = shard.init_process_group(torch.device("cpu"))
-NCH, N = 6, 4000
+NCH, N = int(os.environ.get("SFE_TEST_NCH", "6")), 4000
 first, count = shard.channel_block(NCH, world, rank)
+# bench.py at N > 1: rank 0 measures the kernel variant, every rank runs what rank 0 chose
+chosen = 2 if rank == 0 else 0
+chosen = int(round(shard.sum_over_ranks([float(chosen) if rank == 0 else 0.0])[0]))
+assert chosen == 2
+# ... and the host-side barrier group the single-process leg waits on
+import torch.distributed as dist
+host = dist.new_group(backend="gloo")
+dist.barrier(group=host)
 taps = synth.taps_cfg2()
 t0 = time.perf_counter()
 acc = [0.0, 0.0, 0.0]
@@ -58,23 +70,25 @@ def test_channel_block_partition():
             assert max(k for _, k in blocks) - min(k for _, k in blocks) <= 1
 
 
-def test_two_rank_gloo_sharding_matches_single_process(tmp_path):
+
+@pytest.mark.parametrize("ranks,nch", [(2, 6), (8, 19)])
+def test_gloo_channel_sharding_matches_single_process(tmp_path, ranks, nch):
     from oracle import binding as orc
     from simplefe_amd import synth
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", SFE_TEST_NCH=str(nch))
     out = subprocess.run(
-        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
         capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()
     world, s1, s2, cnt = int(line[1]), float(line[2]), float(line[3]), int(line[4])
-    assert world == 2 and cnt == 6 * 2 * 4000
+    assert world == ranks and cnt == nch * 2 * 4000
     taps = synth.taps_cfg2()
     e1 = e2 = 0.0
-    for c in range(6):
+    for c in range(nch):
         x = synth.synth_cf32(4000, ch=c)
         for part in (0, 1):
             y = orc.Blkconv(taps, 1024).stream(np.ascontiguousarray(x[part::2])).astype(np.float64)
@@ -88,6 +102,7 @@ SPLIT_WORKER = r"""
 import os, sys
 sys.path.insert(0, %(root)r)
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 from simplefe_amd import shard, synth
@@ -124,8 +139,9 @@ def test_span_block_partition():
                     pos += c
 
 
-def test_two_rank_gloo_single_stream_split_with_halo_exchange(tmp_path):
-    """SURVEY 8(e) row 3 rehearsed on CPU: one stream, two ranks, cut on a transform boundary, the
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_gloo_single_stream_split_with_halo_exchange(tmp_path, ranks):
+    """SURVEY 8(e) row 3 rehearsed on CPU: one stream, two / eight ranks, cut on transform boundaries, the
     255-sample halo sent point-to-point to the right neighbour; the stitched result equals the
     uncut stream's (the oracle stands in for the kernel here -- on GPUs the same shard.* calls
     feed sfe_dsp_fir_load_history, tests/test_gpu_split.py)."""
@@ -133,9 +149,9 @@ def test_two_rank_gloo_single_stream_split_with_halo_exchange(tmp_path):
     script.write_text(SPLIT_WORKER % {"root": ROOT})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     out = subprocess.run(
-        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
         capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()
-    assert int(line[1]) == 2 and int(line[2]) == 50000 and float(line[3]) <= 1e-6
+    assert int(line[1]) == ranks and int(line[2]) == 50000 and float(line[3]) <= 1e-6
