@@ -39,10 +39,13 @@ private:
     blkconv(const blkconv &);             // the reference's implicit copy would double-free
     blkconv &operator=(const blkconv &);
 
+    // the reference constructor has no device argument: the object lives on the calling thread's current
+    // device (sfe_dsp_set_device / hipSetDevice; 0 unless chosen).  No environment is read.
     static int device()
     {
-        const char *e = getenv("SFE_DSP_DEVICE");
-        return e ? atoi(e) : 0;
+        int d = 0;
+        (void)sfe_dsp_get_device(&d);       // no GPU: d stays 0 and the create call below reports SFE_ENODEV
+        return d;
     }
     static void guard(int rc, const char *where)
     {

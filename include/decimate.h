@@ -17,9 +17,10 @@ class decimate
 public:
     decimate(float *taps, int n_taps, int upsample, int blksize) : m_h(0)
     {
-        const char *e = getenv("SFE_DSP_DEVICE");
+        int dev = 0;                        // the calling thread's current device (sfe_dsp_set_device); no environment is read
+        (void)sfe_dsp_get_device(&dev);
         int rc = sfe_dsp_rs_create(taps, n_taps, upsample, blksize, /*data_complex*/ 0,
-                                   /*n_channels*/ 1, e ? atoi(e) : 0, SFE_RS_DECIMATE, &m_h);
+                                   /*n_channels*/ 1, dev, SFE_RS_DECIMATE, &m_h);
         if (rc != SFE_OK) {
             fprintf(stderr, "decimate::decimate: %s (code %d)\n", sfe_dsp_last_error(), rc);
             abort();

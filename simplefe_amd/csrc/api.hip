@@ -935,6 +935,20 @@ int sfe_dsp_device_count(int *count)
 
 int sfe_dsp_set_device(int device) { return use_device(device); }
 
+int sfe_dsp_get_device(int *device)
+{
+    if (!device) return SFE_EINVAL;
+    *device = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        set_error("no HIP device available: libsfe_dsp has no CPU fallback");
+        return SFE_ENODEV;
+    }
+    SFE_HIP(hipGetDevice(device));
+    return SFE_OK;
+}
+
 int sfe_dsp_sync(sfe_stream_t stream)
 {
     SFE_HIP(hipStreamSynchronize((hipStream_t)stream));

@@ -32,6 +32,7 @@ SIGNATURES = {
     "sfe_dsp_last_error": (C.c_char_p, []),
     "sfe_dsp_device_count": (i32, [C.POINTER(i32)]),
     "sfe_dsp_set_device": (i32, [i32]),
+    "sfe_dsp_get_device": (i32, [C.POINTER(i32)]),
     "sfe_dsp_sync": (i32, [vp]),
     "sfe_dsp_malloc": (i32, [C.POINTER(vp), sz]),
     "sfe_dsp_free": (i32, [vp]),
