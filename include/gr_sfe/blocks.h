@@ -23,6 +23,8 @@
 #ifndef GR_SFE_BLOCKS_H_
 #define GR_SFE_BLOCKS_H_
 
+#include <string.h>
+
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -148,6 +150,101 @@ typename fir_xxf_sync<CPLX>::sptr fir_xxf_sync<CPLX>::make(const std::vector<flo
 }
 typedef fir_xxf_sync<true> fir_ccf_sync;
 typedef fir_xxf_sync<false> fir_fff_sync;
+
+// --------------------------------------- a bank of FIR streams over several GPUs, one round trip per call
+// n_channels independent gr_complex streams through one filter, ONE INPUT AND ONE OUTPUT PORT PER CHANNEL --
+// what n_channels reference objects are (libdsp/blkconv.h:35-62) -- with the channels cut into contiguous
+// blocks over `devices` inside the library (sfe_dsp_fir_group_*, sfe_dsp.h): every device gets its copy-in,
+// its launch and its copy-out on a stream of its own before the call waits for any of them.
+// devices = {0} is the one-GPU bank; {0, 1, ..., 7} spreads 64 channels eight to a GPU.
+class fir_bank_ccf_sync : virtual public gr::sync_block
+{
+public:
+    typedef sptr_of<fir_bank_ccf_sync>::type sptr;
+    // max_items: the largest work() call served in one piece (longer calls are processed in pieces)
+    static sptr make(const std::vector<float> &taps, int n_channels, const std::vector<int> &devices, int max_items = 65536);
+};
+
+class fir_bank_ccf_sync_impl : public fir_bank_ccf_sync
+{
+public:
+    fir_bank_ccf_sync_impl(const std::vector<float> &taps, int n_channels, const std::vector<int> &devices, int max_items)
+        : gr::sync_block("sfe_fir_bank_ccf_sync", gr::io_signature::make(n_channels, n_channels, sizeof(gr_complex)),
+                         gr::io_signature::make(n_channels, n_channels, sizeof(gr_complex))),
+          d_g(0), d_max(max_items > 0 ? max_items : 65536)
+    {
+        check(sfe_dsp_fir_group_create(taps.data(), (int)taps.size(), 0, 1, 0, n_channels, devices.data(), (int)devices.size(), &d_g),
+              "fir_bank_ccf_sync");
+        int n = 0, home = 0;
+        check(sfe_dsp_fir_group_shards(d_g, &n), "fir_bank_ccf_sync");
+        sfe_dsp_get_device(&home);
+        d_sh.resize(n);
+        d_in.assign(n, (void *)0);
+        d_out.assign(n, (void *)0);
+        for (int k = 0; k < n; k++) {
+            part &s = d_sh[k];
+            check(sfe_dsp_fir_group_shard(d_g, k, &s.device, &s.first, &s.count, 0, &s.stream), "fir_bank_ccf_sync");
+            const size_t bytes = (size_t)s.count * d_max * sizeof(gr_complex);
+            check(sfe_dsp_set_device(s.device), "fir_bank_ccf_sync");
+            check(sfe_dsp_malloc(&d_in[k], bytes), "fir_bank_ccf_sync");
+            check(sfe_dsp_malloc(&d_out[k], bytes), "fir_bank_ccf_sync");
+            check(sfe_dsp_host_alloc(&s.h_in, bytes), "fir_bank_ccf_sync");
+            check(sfe_dsp_host_alloc(&s.h_out, bytes), "fir_bank_ccf_sync");
+        }
+        sfe_dsp_set_device(home);
+    }
+    ~fir_bank_ccf_sync_impl()
+    {
+        if (d_g) sfe_dsp_fir_group_sync(d_g);
+        for (size_t k = 0; k < d_sh.size(); k++) {
+            if (d_in[k]) sfe_dsp_free(d_in[k]);
+            if (d_out[k]) sfe_dsp_free(d_out[k]);
+            if (d_sh[k].h_in) sfe_dsp_host_free(d_sh[k].h_in);
+            if (d_sh[k].h_out) sfe_dsp_host_free(d_sh[k].h_out);
+        }
+        sfe_dsp_fir_group_destroy(d_g);
+    }
+
+    int work(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &output_items)
+    {
+        for (int off = 0; off < noutput_items;) {
+            const size_t m = (size_t)(noutput_items - off < d_max ? noutput_items - off : d_max), row = m * sizeof(gr_complex);
+            for (size_t k = 0; k < d_sh.size(); k++) {             // copy-in of every block, each on its block's stream
+                part &s = d_sh[k];
+                for (int c = 0; c < s.count; c++)
+                    memcpy((char *)s.h_in + c * row, (const gr_complex *)input_items[s.first + c] + off, row);
+                check(sfe_dsp_memcpy_h2d(d_in[k], s.h_in, s.count * row, s.stream), "fir_bank_ccf_sync::work");
+            }
+            check(sfe_dsp_fir_group_process_stream(d_g, (const void *const *)d_in.data(), d_out.data(), m, m, m), "fir_bank_ccf_sync::work");
+            for (size_t k = 0; k < d_sh.size(); k++)
+                check(sfe_dsp_memcpy_d2h(d_sh[k].h_out, d_out[k], d_sh[k].count * row, d_sh[k].stream), "fir_bank_ccf_sync::work");
+            check(sfe_dsp_fir_group_sync(d_g), "fir_bank_ccf_sync::work");
+            for (size_t k = 0; k < d_sh.size(); k++)
+                for (int c = 0; c < d_sh[k].count; c++)
+                    memcpy((gr_complex *)output_items[d_sh[k].first + c] + off, (const char *)d_sh[k].h_out + c * row, row);
+            off += (int)m;
+        }
+        return noutput_items;
+    }
+
+private:
+    struct part {
+        int device, first, count;
+        sfe_stream_t stream;
+        void *h_in, *h_out;
+        part() : device(0), first(0), count(0), stream(0), h_in(0), h_out(0) {}
+    };
+    sfe_fir_group_t d_g;
+    int d_max;
+    std::vector<part> d_sh;
+    std::vector<void *> d_in, d_out;
+};
+
+inline fir_bank_ccf_sync::sptr fir_bank_ccf_sync::make(const std::vector<float> &taps, int n_channels, const std::vector<int> &devices,
+                                                       int max_items)
+{
+    return fir_bank_ccf_sync::sptr(new fir_bank_ccf_sync_impl(taps, n_channels, devices, max_items));
+}
 
 // ------------------------------------------------------- decimation / rational resampling, batched
 // One pipe-backed block serves both classes: `decimate` at integer rate D with upsample 1

@@ -58,7 +58,7 @@ int sfe_dsp_device_count(int *count);
 /* The calling thread's current device (HIP's notion: hipSetDevice / hipGetDevice).  Handles name
  * their device at create and switch to it on every call, so these two matter only to what has no
  * device argument: sfe_dsp_malloc and friends, and the drop-in classes blkconv / resample /
- * decimate (include/*.h), whose reference constructors have no such argument -- an object lives on
+ * decimate (the class headers under include/), whose reference constructors have no such argument -- an object lives on
  * the device that is current when it is constructed (0 unless the caller chose another).
  * get_device: SFE_ENODEV without a GPU. */
 int sfe_dsp_set_device(int device);

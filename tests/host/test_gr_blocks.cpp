@@ -1,6 +1,7 @@
 // Drives include/gr_sfe/blocks.h the way the GNU Radio scheduler drives a block: repeated
 // work()/general_work() calls with scheduler-sized item counts.  Needs a GPU to run.
 //   test_gr_blocks <fir|fir_sync|fir_f|decimate|resample|decimate_f|resample_f> <taps.f32> <x> <y> [decim] [interp]
+//   test_gr_blocks bank <taps.f32> <x> <y> <n_channels> <blocks>   fir_bank_ccf_sync: one port per channel, channel blocks on device 0
 //   test_gr_blocks rate <taps.f32> <x> <y>     4096-item calls through fir_ccf (batched) and fir_ccf_sync;
 //                                              prints "<items/s batched> <items/s sync>"; y = batched output
 // (_f: float items, otherwise gr_complex items)
@@ -158,6 +159,32 @@ int main(int argc, char **argv)
         fwrite(yb.data(), 1, yb.size(), f);
         fclose(f);
         printf("%zu\n", yb.size());
+        return 0;
+    }
+    if (!strcmp(argv[1], "bank")) {
+        // test_gr_blocks bank <taps> <x: n_channels rows of n gr_complex> <y> <n_channels> <blocks>: every block on device 0
+        std::vector<float> taps = slurp(argv[2]), x = slurp(argv[3]);
+        const int nch = atoi(argv[5]), nblk = atoi(argv[6]);
+        const int n = (int)(x.size() / 2 / nch);
+        std::vector<float> y(x.size());
+        gr::sfe::fir_bank_ccf_sync::sptr b = gr::sfe::fir_bank_ccf_sync::make(taps, nch, std::vector<int>(nblk, 0), 5000);
+        int si = 0;
+        for (int off = 0; off < n;) {
+            int m = sizes[si++ % 5];
+            if (m > n - off) m = n - off;
+            gr_vector_const_void_star in(nch);
+            gr_vector_void_star out(nch);
+            for (int c = 0; c < nch; c++) {
+                in[c] = x.data() + 2 * ((size_t)c * n + off);
+                out[c] = y.data() + 2 * ((size_t)c * n + off);
+            }
+            if (b->work(m, in, out) != m) return 1;
+            off += m;
+        }
+        FILE *f = fopen(argv[4], "wb");
+        fwrite(y.data(), 4, y.size(), f);
+        fclose(f);
+        printf("%d\n", n);
         return 0;
     }
     std::vector<float> taps = slurp(argv[2]), x = slurp(argv[3]);

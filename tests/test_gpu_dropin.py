@@ -115,6 +115,22 @@ def _run_gr(gr_exe, tmp_path, kind, taps, x_il, *extra):
     return np.fromfile(tmp_path / "y.f32", dtype=np.float32)
 
 
+def test_gr_fir_bank_over_device_blocks(gr_exe, tmp_path):
+    """fir_bank_ccf_sync: 6 channels on 6 ports, cut into 1, 2 and 4 blocks (all on device 0 here; on an
+    8-GPU node the same list names 8 devices), scheduler-sized work() calls incl. one longer than the block's
+    staging: every port's stream is its own convolution, and the cut changes no bit."""
+    from simplefe_amd import synth
+    taps = synth.taps_cfg2()
+    nch, n = 6, 30000
+    x = np.stack([synth.synth_cf32(n, ch=20 + c) for c in range(nch)])
+    outs = [_run_gr(gr_exe, tmp_path, "bank", taps, x, nch, nblk).reshape(nch, 2 * n) for nblk in (1, 2, 4)]
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    for c in range(nch):
+        for part in (0, 1):
+            ref = np.convolve(x[c, part::2].astype(np.float64), taps.astype(np.float64))[:n]
+            assert synth.rel_rms(outs[0][c, part::2], ref) <= 1e-5, c
+
+
 def test_gr_fir_blocks_batched_and_sync(gr_exe, tmp_path):
     """general_work() / work() called with scheduler-sized item counts (4096, 1000, 8191, 37, 16384):
     the batched block (fir_ccf: pinned batches of 8192 items, four in flight) and the one-round-trip
