@@ -206,8 +206,8 @@ static const PolyFftPlan *get_fft_plan(FftPlanCache &cache, const std::vector<fl
     pl.e_max = f.e_max;
     // Selection (measured over a grid of shapes at 2^26 samples, scripts/calibrate_rs_fft.py):
     //  - the overlap must leave a useful block: Li <= 192 (V = 257 - Li >= 65 of 256 points);
-    //  - shapes the tiled direct kernel has no instantiation for fall to the generic kernel, which is
-    //    3-11x slower than this one: take the transform whenever it exists;
+    //  - shapes neither tiled kernel takes fall to the generic kernel, which is 3-11x slower than this
+    //    one: take the transform whenever it exists;
     //  - otherwise the transform wins once the direct form costs more than ~230 flop per (complex)
     //    input sample, scaled by how much of each 256-point block is overlap, and 1.4x later for
     //    UP = 4 (one segment per pass fills only 9 of the 16 lane groups).
@@ -215,7 +215,10 @@ static const PolyFftPlan *get_fft_plan(FftPlanCache &cache, const std::vector<fl
     const int V = 257 - pl.Li;
     const int Lp2 = ((f.Lp + 2 * f.SP - 1) / (2 * f.SP)) * (2 * f.SP);
     const bool tiled_ok = poly_tiled_supported(f.SP, f.UP, Lp2);
-    const double threshold = 230.0 * 231.0 / (V > 0 ? V : 1) * (f.UP >= 4 ? 1.4 : 1.0);
+    // (round 4: shapes without a compile-time tiled instantiation now run poly_rt_kernel, whose loops are not
+    // unrolled over SP and UP: the transform takes over at half the arithmetic)
+    const double threshold = 230.0 * 231.0 / (V > 0 ? V : 1) * (f.UP >= 4 ? 1.4 : 1.0) *
+                             (poly_tiled_is_compiled(f.SP, f.UP, Lp2) ? 1.0 : 0.5);
     const bool forced = fft_mode > 0;
     if (!pl.R || pl.Li > 192 || fft_mode < 0 || (!forced && tiled_ok && direct_flops < threshold)) {
         cache.plans[key] = pl;
@@ -795,6 +798,9 @@ struct Rs {
     MfmaCache mfma_plans;
     FftPlanCache fft_plans;
     unsigned *d_ticket = nullptr;          // work counters of the transform-domain kernel
+    struct Fir *gen_tables = nullptr;      // general rate in the transform domain (poly_gen.hip): the U phases' spectra and the
+                                           // twiddle bases, built by the FIR's own table builder (one "channel" per phase)
+    bool gen_tried = false;
     void *d_hist[2] = {nullptr, nullptr};
     int cur = 0;
     bool captured = false;                 // a call of this handle sits in a hipGraph that names d_hist[cur] (see fir_carry_state)
@@ -854,6 +860,7 @@ static void rs_free(Rs *r)
     r->mfma_plans.clear();
     r->fft_plans.clear();
     if (r->d_ticket) (void)hipFree(r->d_ticket);
+    if (r->gen_tables) fir_free(r->gen_tables);
     for (int i = 0; i < 2; i++)
         if (r->d_hist[i]) (void)hipFree(r->d_hist[i]);
     if (r->d_in) (void)hipFree(r->d_in);
@@ -2015,7 +2022,57 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         r->plan_stream = s;
         sa.segs = r->d_segs;
         sa.chunks = static_cast<const SegChunk *>(r->d_chunks);
-        rc = launch_poly_seg(sa, r->data_complex, r->exact_stream, r->n_channels, s);
+        // Bulk calls of complex streams at rate >= 1 in fused arithmetic: the transform-domain kernel (poly_gen.hip) --
+        // all U phases of every input by one forward and U inverse 4096-point transforms, outputs picked and blended from
+        // LDS by the same runs.  sfe_dsp_rs_set_algo(SFE_RS_ALGO_DIRECT) and the exact mode keep poly_seg_kernel.
+        rc = SFE_ESTATE;
+        if (!r->exact_stream && r->data_complex && !r->in_u8 && r->fft_mode >= 0 && stepf >= (float)r->U &&
+            (r->fft_mode > 0 || (n_in >= ((size_t)1 << 16) && r->plen >= 12))) {
+            if (!r->gen_tried) {
+                // spectra of the U phase filters (taps[i U + j], i < plen; one zero behind so that the overlap the FIR
+                // planner picks covers plen samples, not plen - 1) through fir_build_tables: one "channel" per phase
+                r->gen_tried = true;
+                std::vector<float> rows((size_t)r->U * (r->plen + 1), 0.0f);
+                for (int j = 0; j < r->U; j++)
+                    for (int i = 0; i < r->plen; i++) rows[(size_t)j * (r->plen + 1) + i] = r->h_taps_pm[(size_t)j * r->plen + i];
+                sfe_fir_t gh = nullptr;
+                if (fir_create_impl(rows.data(), r->plen + 1, 0, 1, r->U, 0, r->device, 1, &gh) == SFE_OK) {
+                    r->gen_tables = static_cast<Fir *>(gh);
+                    if (r->gen_tables->parts != 1) {
+                        fir_free(r->gen_tables);
+                        r->gen_tables = nullptr;
+                    }
+                }
+            }
+            if (r->gen_tables) {
+                PolyGenArgs ga;
+                memset(&ga, 0, sizeof(ga));
+                ga.in = d_in;
+                ga.out = d_out;
+                ga.hist = r->d_hist[r->cur];
+                ga.hs = r->gen_tables->d_hs;
+                ga.tw1 = r->gen_tables->d_tw1;
+                ga.tw2 = r->gen_tables->d_tw2;
+                ga.segs = r->d_segs;
+                ga.chunks = static_cast<const SegChunk *>(r->d_chunks);
+                ga.n_in = (long long)n_in;
+                ga.in_stride = (long long)in_stride;
+                ga.out_stride = (long long)out_stride;
+                ga.hl = r->hl;
+                ga.U = r->U;
+                ga.plen = r->plen;
+                ga.ovl = r->gen_tables->ovl;
+                ga.blksize = r->blksize;
+                ga.n_chunks = (int)chunks.size();
+                int max_runs = 0;
+                for (size_t i = 0; i < chunks.size(); i++) {
+                    const int two = chunks[i].n_seg + (i + 1 < chunks.size() ? chunks[i + 1].n_seg : 0);
+                    max_runs = two > max_runs ? two : max_runs;
+                }
+                rc = launch_poly_gen(ga, max_runs, stepf, r->n_channels, s);
+            }
+        }
+        if (rc == SFE_ESTATE) rc = launch_poly_seg(sa, r->data_complex, r->exact_stream, r->n_channels, s);
         if (rc == SFE_ESTATE) {
             // a call's input does not fit an LDS tile (huge blksize): expand on the host and use
             // the per-output schedule kernel

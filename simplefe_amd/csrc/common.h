@@ -145,12 +145,16 @@ struct PolyTiledArgs {
     const float *G;
     long long   n_in, in_stride, out_stride, n_out;
     int         hl, Lp, e_max;
+    // poly_rt_kernel (any SP, UP as launch arguments; set by the launcher)
+    int         SP = 0, UP = 0, tm = 0, rowlen = 0;
+    unsigned    sp_inv = 0;           // ceil(2^32 / SP): floor(s / SP) = mulhi(s, sp_inv) for the s a tile meets
 };
 // returns SFE_OK, or SFE_ESTATE when (SP, UP, Lp) has no tiled instantiation (caller falls
 // back to launch_poly_int)
 int launch_poly_tiled(const PolyTiledPlan &plan, const PolyTiledArgs &a, int data_complex, int exact,
                       int in_u8, int n_channels, hipStream_t s);
-bool poly_tiled_supported(int SP, int UP, int Lp);
+bool poly_tiled_supported(int SP, int UP, int Lp);     // a compile-time instantiation, or the runtime-shape kernel
+bool poly_tiled_is_compiled(int SP, int UP, int Lp);    // a compile-time instantiation of poly_tiled_kernel
 
 // f32-MFMA form of the same integer-step law (fused multiply-add numerics only).  Outputs are
 // taken in groups of RG = UP*DM consecutive outputs (DM consecutive m, RG <= 16) that read a
@@ -233,6 +237,23 @@ struct PolySegArgs {
 };
 // returns SFE_ESTATE when a call's tile does not fit in LDS (caller falls back to launch_poly_sched)
 int launch_poly_seg(const PolySegArgs &a, int data_complex, int exact, int n_channels, hipStream_t s);
+
+// The same law in the transform domain (poly_gen.hip): one forward 4096-point transform of an input block, U
+// spectrum products and inverse transforms (all U phase samples of every input, libdsp/resample.cxx:100-114), the
+// outputs picked and blended from LDS by the same runs.  Complex float32, fused numerics, rate >= 1.
+struct PolyGenArgs {
+    const void *in;
+    void       *out;
+    const void *hist;
+    const v2f  *hs;             // [U][16][256]: the phases' spectra / 4096 in the FIR kernel's thread order
+    const v2f  *tw1, *tw2;      // the FIR kernel's twiddle bases
+    const void *segs;           // TlSeg[]
+    const SegChunk *chunks;
+    long long   n_in, in_stride, out_stride;
+    int         hl, U, plen, ovl, blksize, n_chunks;
+};
+// SFE_ESTATE: outside what the kernel takes (caller: launch_poly_seg)
+int launch_poly_gen(const PolyGenArgs &a, int max_runs_two_calls, float step, int n_channels, hipStream_t s);
 
 // new_hist[i] = virtual[n_in - hl + i], virtual = old_hist ++ in  (per channel)
 int launch_history_update(const void *in, long long n_in, long long in_stride,

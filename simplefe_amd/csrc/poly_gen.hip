@@ -1,0 +1,297 @@
+// poly_gen.hip -- the general (non-integer-step) rate in the transform domain.
+//
+// The reference's `resample` computes ALL U polyphase outputs of every input sample
+// (libdsp/resample.cxx:100-114: m_out[j][n] = sum_i taps[i U + j] x[n - i]) and then, for every output
+// instant t of the float32 time law, picks two neighbouring ones and blends them (:125-148):
+//     y = s(p) (1 - mu) + mu s(p + 1),   p = floor(t), mu = t - p,   s(n U + j) = m_out[j][n].
+// `mu` only enters that final blend; the two values it blends are phase samples -- U plain FIR filters
+// of the SAME input -- and a transform yields those: ONE forward 4096-point transform of the input block,
+// U spectrum products with the phases' spectra, U inverse transforms.  That is (1 + U) transforms per
+// 4096 - ovl samples where the direct form (polyphase.hip: poly_seg_kernel) spends two dot products
+// of plen taps per OUTPUT read at per-lane conflicting LDS addresses: 381 taps in 3 phases at rate 1.77 --
+// ~570 flop per input sample direct, ~250 here.
+//
+// One workgroup = one block of the stream, the FIR kernel's transform (fir_fft.hip: N = 16 x 16 x 16, thread t
+// owns 16 complex values, padded exchange buffer, the same twiddle tables and the same spectrum layout):
+//   block b transforms x[b A - ovl .. b A - ovl + 4096), A = 4096 - ovl, ovl >= plen a multiple of 256, and
+//   OWNS the outputs whose first phase sample is s(p) with floor(p / U) in [b A - 1, (b + 1) A - 1): both
+//   s(p) and s(p + 1) then lie in what the block's inverse transforms produce validly.
+//   0. the runs (timelaw.h: t_i = t0 + i d, exact in double) of the one or two reference calls the block
+//      overlaps are copied to LDS; every thread finds the block's first and last output by the same
+//      uniform search and expands ITS outputs k = k0 + tid + 256 q into (position, mu), kept in registers
+//   1. forward transform -> this thread's 16 bins X, kept in registers
+//   2. for each phase j: X H_j -> inverse transform -> S_j[n] into the exchange buffer -> every thread
+//      adds its outputs' share: (1 - mu) S_j[n] where the output's first sample has phase j, mu S_j[n'] where
+//      its second one has (the next phase of the same input sample, or phase 0 of the next one)
+//   3. the outputs are stored, lanes = consecutive outputs
+// (pos, mu) are the reference's own sequence, bit for bit (the runs reproduce the float32 recurrence);
+// the arithmetic is fused and transform-domain: rel-RMS ~3e-7 against the oracle, the exact mode stays on
+// poly_seg_kernel.  Complex float32 streams, rate >= 1 (at most one output per owned input sample).
+#include <stdint.h>
+
+#include "common.h"
+#include "fft16.h"
+
+namespace sfe {
+namespace {
+
+struct RunLds {            // TlSeg (timelaw.h) as three 8-byte words
+    double t0;
+    float d;
+    int k0;
+    int count, pad;
+};
+static_assert(sizeof(RunLds) == 24, "TlSeg layout");
+
+constexpr int GEN_MAX_RUNS = 1024;       // runs of the (at most two) calls a block overlaps, in LDS: 24 KiB of the 34 KiB buffer
+
+// KPT: outputs per thread (the block owns at most 256 KPT outputs; the launcher picks it from the rate)
+template <int KPT>
+__global__ __launch_bounds__(256) void poly_gen4096_kernel(PolyGenArgs a)
+{
+    __shared__ v2f lds[FFT_ROWS * LDS_K2_STRIDE];
+    const unsigned t = threadIdx.x, lo = t & 15u, hi = t >> 4;
+    const int ch = blockIdx.y;
+    const long long blk = blockIdx.x;
+    const v2f *in = static_cast<const v2f *>(a.in) + (size_t)ch * a.in_stride;
+    const v2f *hist = static_cast<const v2f *>(a.hist) + (size_t)ch * a.hl;
+    v2f *out = static_cast<v2f *>(a.out) + (size_t)ch * a.out_stride;
+    const int A = FFT_N - a.ovl, U = a.U;
+
+    // ---- the block's 16 rows (thread t: samples base + t + 256 r): requested first, they land under step 0
+    v2f nx[16];
+    const long long base = blk * A - a.ovl;
+    if (base >= 0 && base + FFT_N <= a.n_in) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) nx[r] = __builtin_nontemporal_load(in + base + 256 * r + t);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const long long i = base + 256 * r + (long long)t;
+            if (i >= 0) nx[r] = i < a.n_in ? in[i] : (v2f){0.0f, 0.0f};
+            else nx[r] = i >= -(long long)a.hl ? hist[a.hl + i] : (v2f){0.0f, 0.0f};
+        }
+    }
+
+    // ---- 0. which outputs are this block's, and where each of this thread's sits
+    // positions on the upsampled grid, absolute (relative to the launch's first input sample):
+    // P = in_off U + floor(t); the block owns Plo <= P < Phi.  Call c emitted the outputs with
+    // c B U - 1 <= P < (c + 1) B U - 1 (its leftover output sits at relative position -1).
+    const long long Plo = (long long)U * (blk * A - 1), Phi = Plo + (long long)U * A;
+    const long long BU = (long long)a.blksize * U;
+    long long c0 = (Plo + 1) / BU, c1 = (Phi) / BU;              // Plo + 1 >= 0 except for block 0 (Plo = -U): floor of a negative
+    if (Plo + 1 < 0) c0 = 0;
+    if (c1 >= a.n_chunks) c1 = a.n_chunks - 1;
+    if (c0 > c1) c0 = c1;
+    const SegChunk ca = a.chunks[c0], cb = a.chunks[c1];
+    RunLds *runs = reinterpret_cast<RunLds *>(lds);
+    const int na = ca.n_seg, nb = c1 > c0 ? cb.n_seg : 0;         // host guarantees na + nb <= GEN_MAX_RUNS
+    {
+        const unsigned long long *ga = reinterpret_cast<const unsigned long long *>(static_cast<const RunLds *>(a.segs) + ca.seg_first);
+        const unsigned long long *gb = reinterpret_cast<const unsigned long long *>(static_cast<const RunLds *>(a.segs) + cb.seg_first);
+        unsigned long long *ws = reinterpret_cast<unsigned long long *>(lds);
+        for (int i = (int)t; i < 3 * na; i += 256) ws[i] = ga[i];
+        for (int i = (int)t; i < 3 * nb; i += 256) ws[3 * na + i] = gb[i];
+    }
+    lds_barrier();
+    // outputs of a call whose relative position is < bound (uniform: every thread runs the same search)
+    auto count_below = [&](const RunLds *rs, int n_seg, int n_out, long long bound) -> int {
+        if (n_seg == 0 || bound <= -1) return 0;
+        const double bd = (double)bound;
+        int l = 0, h = n_seg;                    // first run whose t0 >= bound
+        while (l < h) {
+            const int m = (l + h) >> 1;
+            if (rs[m].t0 < bd) l = m + 1; else h = m;
+        }
+        if (l == 0) return 0;
+        const RunLds g = rs[l - 1];
+        long long i = g.count;
+        if (g.count > 1 && g.d > 0.0f) {
+            i = (long long)ceil((bd - g.t0) / (double)g.d);       // first i with t0 + i d >= bound, up to rounding:
+            if (i < 0) i = 0;
+            if (i > g.count) i = g.count;
+            while (i < g.count && g.t0 + (double)i * (double)g.d < bd) i++;
+            while (i > 0 && g.t0 + (double)(i - 1) * (double)g.d >= bd) i--;
+        }
+        const int k = g.k0 + (int)i;
+        return k < n_out ? k : n_out;
+    };
+    const RunLds *ra = runs, *rb = runs + na;
+    const long long offa = ca.in_off * U, offb = cb.in_off * U;
+    const int ka_lo = count_below(ra, na, ca.n_out, Plo - offa), ka_hi = count_below(ra, na, ca.n_out, Phi - offa);
+    int kb_lo = 0, kb_hi = 0;
+    if (c1 > c0) {
+        kb_lo = count_below(rb, nb, cb.n_out, Plo - offb);
+        kb_hi = count_below(rb, nb, cb.n_out, Phi - offb);
+    }
+    const int Ta = ka_hi - ka_lo, T = Ta + (kb_hi - kb_lo);        // T <= 256 KPT (launcher)
+    const long long k_first = Ta > 0 || c1 == c0 ? ca.k_first + ka_lo : cb.k_first + kb_lo;   // the block's outputs are consecutive
+
+    unsigned posl[KPT];       // position inside the block, P - Plo (< U A); 0xFFFFFFFF: no output
+    float mu[KPT];
+#pragma unroll
+    for (int q = 0; q < KPT; q++) {
+        const int idx = (int)t + 256 * q;
+        posl[q] = 0xFFFFFFFFu;
+        mu[q] = 0.0f;
+        if (idx < T) {
+            const bool second = idx >= Ta;
+            const RunLds *rs = second ? rb : ra;
+            const int ns = second ? nb : na;
+            const int kk = second ? kb_lo + (idx - Ta) : ka_lo + idx;
+            int l = 0, h = ns;                   // first run with k0 + count > kk
+            while (l < h) {
+                const int m = (l + h) >> 1;
+                if (rs[m].k0 + rs[m].count <= kk) l = m + 1; else h = m;
+            }
+            const RunLds g = rs[l];
+            const double tt = g.t0 + (double)(kk - g.k0) * (double)g.d;      // exact (timelaw.h)
+            const double fl = floor(tt);
+            mu[q] = (float)(tt - fl);
+            posl[q] = (unsigned)((second ? offb : offa) + (long long)fl - Plo);
+        }
+    }
+    lds_barrier();                               // the runs are dead: the buffer is the exchange buffer from here on
+
+    // ---- twiddle bases (fir_fft.hip: W^(e (4a + b)) = q[a] p[b])
+    v2f p1[4], q1[4], p2[4], q2[4];
+#pragma unroll
+    for (int k = 1; k < 4; k++) {
+        p1[k] = a.tw1[k * 256 + t];
+        q1[k] = a.tw1[(k + 3) * 256 + t];
+        p2[k] = a.tw2[k * 16 + lo];
+        q2[k] = a.tw2[(k + 3) * 16 + lo];
+    }
+    const unsigned base_b = hi * LDS_K2_STRIDE + lo, base_c = hi * LDS_K2_STRIDE + lo * LDS_K1_STRIDE;
+
+    // ---- 1. forward transform: F1 over n2, F2 over n1, F3 over n0 -> bin k of this thread in X[k]
+    dft16<-1>(nx);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        v2f x = nx[P16(k)];
+        if ((k >> 2) && (k & 3)) x = cmul2(x, q1[k >> 2], p1[k & 3]);
+        else if (k >> 2) x = cmul(x, q1[k >> 2]);
+        else if (k & 3) x = cmul(x, p1[k & 3]);
+        lds[t + (unsigned)k * LDS_K2_STRIDE] = x;
+    }
+    lds_barrier();
+    v2f v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = lds[base_b + 16u * r];
+    dft16<-1>(v);
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        v2f x = v[P16(k)];
+        if ((k >> 2) && (k & 3)) x = cmul2(x, q2[k >> 2], p2[k & 3]);
+        else if (k >> 2) x = cmul(x, q2[k >> 2]);
+        else if (k & 3) x = cmul(x, p2[k & 3]);
+        lds[base_b + (unsigned)LDS_K1_STRIDE * k] = x;
+    }
+    lds_barrier();
+    v2f X[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) X[r] = lds[base_c + r];
+    dft16<-1>(X);                                // bin k sits in X[P16(k)]
+
+    // ---- 2. phase by phase
+    v2f acc[KPT];
+#pragma unroll
+    for (int q = 0; q < KPT; q++) acc[q] = (v2f){0.0f, 0.0f};
+    const unsigned Uu = (unsigned)U, Minv = Uu > 1u ? 0xFFFFFFFFu / Uu + 1u : 0u;      // floor(x / U) = mulhi(x, Minv), x < U A
+    const unsigned e0 = (unsigned)a.ovl - 1u;    // transform element of the block's first owned input sample
+#pragma unroll 1
+    for (int j = 0; j < U; j++) {
+        lds_barrier();                           // (j > 0: every thread is done reading S_{j-1})
+        const v2f *hs = a.hs + (size_t)j * 16 * 256;
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[P16(k)] = cmul(X[P16(k)], hs[k * 256 + t]);
+        dft16_rev<+1>(v);
+#pragma unroll
+        for (int k = 0; k < 16; k++) lds[base_c + k] = v[k];
+        lds_barrier();
+        // I2: over k1
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            v2f x = lds[base_b + (unsigned)LDS_K1_STRIDE * r];
+            if ((r >> 2) && (r & 3)) x = cmul2_conj(x, q2[r >> 2], p2[r & 3]);
+            else if (r >> 2) x = cmul_conj(x, q2[r >> 2]);
+            else if (r & 3) x = cmul_conj(x, p2[r & 3]);
+            v[r] = x;
+        }
+        dft16<+1>(v);
+        lds_barrier();
+#pragma unroll
+        for (int k = 0; k < 16; k++) lds[base_b + 16u * k] = v[P16(k)];
+        lds_barrier();
+        // I3: over k2 -> S_j of transform elements t + 256 r, written back to the cells this thread read
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            v2f x = lds[t + (unsigned)r * LDS_K2_STRIDE];
+            if ((r >> 2) && (r & 3)) x = cmul2_conj(x, q1[r >> 2], p1[r & 3]);
+            else if (r >> 2) x = cmul_conj(x, q1[r >> 2]);
+            else if (r & 3) x = cmul_conj(x, p1[r & 3]);
+            v[r] = x;
+        }
+        dft16<+1>(v);
+#pragma unroll
+        for (int r = 0; r < 16; r++) lds[t + (unsigned)r * LDS_K2_STRIDE] = v[P16(r)];
+        lds_barrier();
+        // the outputs' shares of S_j: element e sits at cell 272 (e / 256) + e % 256
+        const unsigned ju = (unsigned)j;
+#pragma unroll
+        for (int q = 0; q < KPT; q++) {
+            const unsigned pl = posl[q];
+            if (pl == 0xFFFFFFFFu) continue;
+            const unsigned n = Uu > 1u ? __umulhi(pl, Minv) : pl, ph = pl - n * Uu;
+            const bool wrap = ph + 1u == Uu;                         // the second sample is phase 0 of the NEXT input sample
+            if (ph == ju) {
+                const unsigned e = e0 + n;
+                const v2f s0 = lds[(e >> 8) * LDS_K2_STRIDE + (e & 255u)];
+                const float om = 1.0f - mu[q];                      // resample.cxx:147
+                acc[q] = __builtin_elementwise_fma((v2f){om, om}, s0, acc[q]);
+            }
+            if ((wrap ? 0u : ph + 1u) == ju) {
+                const unsigned e = e0 + n + (wrap ? 1u : 0u);
+                const v2f s1 = lds[(e >> 8) * LDS_K2_STRIDE + (e & 255u)];
+                acc[q] = __builtin_elementwise_fma((v2f){mu[q], mu[q]}, s1, acc[q]);
+            }
+        }
+    }
+    // ---- 3. lanes = consecutive outputs
+#pragma unroll
+    for (int q = 0; q < KPT; q++)
+        if (posl[q] != 0xFFFFFFFFu) __builtin_nontemporal_store(acc[q], out + k_first + (long long)t + 256 * q);
+}
+
+}  // namespace
+
+int poly_gen_outputs_per_block(int U, int ovl, float step)
+{
+    // consecutive outputs are >= step (1 - 2^-22) apart on the upsampled grid
+    const double span = (double)U * (FFT_N - ovl);
+    return (int)(span / ((double)step * (1.0 - 1.0 / 4194304.0))) + 2;
+}
+
+// SFE_ESTATE: the shape is outside what this kernel takes (the caller uses poly_seg_kernel)
+int launch_poly_gen(const PolyGenArgs &a, int max_runs_two_calls, float step, int n_channels, hipStream_t s)
+{
+    if (a.n_chunks <= 0) return SFE_OK;
+    if (a.ovl < a.plen || a.ovl >= FFT_N || (a.ovl & 255) || a.blksize < FFT_N - a.ovl || max_runs_two_calls > GEN_MAX_RUNS)
+        return SFE_ESTATE;
+    const int per_block = poly_gen_outputs_per_block(a.U, a.ovl, step);
+    if (per_block > 256 * 16) return SFE_ESTATE;
+    const long long A = FFT_N - a.ovl;
+    const long long nblk = (a.n_in + A - 1) / A;
+    if (nblk > 0x7fffffffLL) return SFE_ESTATE;
+    dim3 grid((unsigned)nblk, (unsigned)n_channels), block(256);
+    const int kpt = (per_block + 255) / 256;
+    if (kpt <= 6) hipLaunchKernelGGL((poly_gen4096_kernel<6>), grid, block, 0, s, a);
+    else if (kpt <= 9) hipLaunchKernelGGL((poly_gen4096_kernel<9>), grid, block, 0, s, a);
+    else if (kpt <= 12) hipLaunchKernelGGL((poly_gen4096_kernel<12>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((poly_gen4096_kernel<16>), grid, block, 0, s, a);
+    SFE_HIP(hipGetLastError());
+    return SFE_OK;
+}
+
+}  // namespace sfe

@@ -351,6 +351,102 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
     }
 }
 
+// ------------------------------------------- integer-step law, tiled, ANY (SP, UP): launch arguments
+// poly_tiled_kernel exists for eleven compile-time (SP, UP) pairs, none with UP > SP (VERDICT r3 missing 4):
+// every interpolating ratio -- what `resample` accepts and `decimate` does not, libdsp/resample.cxx:91 against
+// libdsp/decimate.cxx:75-78 -- and decimations such as 6, 7, 16 fell to poly_int_kernel (one output per thread,
+// per-lane tap rows, samples read at stride `step`).  This kernel is the tiled form with SP and UP as
+// ARGUMENTS: the same zero-padded rows G[UP][Lp] (api.hip: fold_rows), the same LDS image -- the tile
+// de-interleaved by a runtime SP, X[p][c] = x[n_org + SP c + p], row pitch chosen by the launcher so that the
+// scatter spreads over the banks -- and per thread m = tid, tid + 256, ...: for a fixed tap the lanes of a wave
+// read consecutive cells of one row (conflict-free), every sample read feeds all UP phase sums, taps come
+// through the constant address space (scalar loads: they are wave-uniform).  Accumulation runs tap index
+// ascending from 0.0f (the reference's order, libdsp/decimate.cxx:134-137): EXACT is bit-identical to the
+// compiled reference, the default fuses multiply and add.  UPM = accumulators compiled in (>= UP).
+template <bool CPLX, bool EXACT, bool IN_U8, int UPM>
+__global__ __launch_bounds__(256) void poly_rt_kernel(PolyTiledArgs a)
+{
+    typedef typename Elem<CPLX>::T T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T *X = reinterpret_cast<T *>(smem);
+
+    const unsigned tid = threadIdx.x;
+    const int ch = blockIdx.y;
+    const T *in = static_cast<const T *>(a.in) + (IN_U8 ? 0 : (size_t)ch * a.in_stride);
+    const unsigned char *in8 = static_cast<const unsigned char *>(a.in) + (size_t)ch * a.in_stride * (CPLX ? 2 : 1);
+    const T *hist = static_cast<const T *>(a.hist) + (size_t)ch * a.hl;
+    T *out = static_cast<T *>(a.out) + (size_t)ch * a.out_stride;
+
+    if (!EXACT && a.hist_out && blockIdx.x == a.tiles) {        // the history workgroup (poly_tiled_kernel has the reasoning)
+        T *ho = static_cast<T *>(a.hist_out) + (size_t)ch * a.hl;
+#pragma unroll 1
+        for (unsigned i = tid; i < (unsigned)a.hl; i += 256u) {
+            if constexpr (IN_U8) ho[i] = vload_u8<CPLX>(in8, hist, a.n_in - a.hl + i, a.n_in, a.hl);
+            else ho[i] = in[a.n_in - a.hl + i];
+        }
+        return;
+    }
+    const unsigned SP = (unsigned)a.SP, RL = (unsigned)a.rowlen;
+    const int UP = a.UP, TMr = a.tm;
+    const long long m0 = (long long)blockIdx.x * TMr;
+    const long long n_org = (long long)SP * m0 + a.e_max - (a.Lp - 1);   // stream index of local sample 0
+    const unsigned n_tile = SP * (unsigned)TMr + (unsigned)a.Lp;
+    // local sample s -> cell (s % SP) * RL + s / SP, the division as a multiply (exact: s < 2^16, SP <= 64)
+    auto cell_of = [&](unsigned s) -> unsigned {
+        const unsigned q = __umulhi(s, a.sp_inv);
+        return (s - q * SP) * RL + q;
+    };
+    if constexpr (IN_U8) {
+        for (unsigned s = tid; s < n_tile; s += 256u) X[cell_of(s)] = vload_u8<CPLX>(in8, hist, n_org + s, a.n_in, a.hl);
+    } else if (n_org >= 0 && n_org + n_tile <= a.n_in) {
+        const T *src = in + n_org;                                        // uniform
+#pragma unroll 1
+        for (unsigned i0 = tid; i0 < n_tile; i0 += 256u * 8u) {           // eight requests per thread in flight at a time
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const unsigned i = i0 + 256u * u;
+                v[u] = i < n_tile ? __builtin_nontemporal_load(src + i) : Elem<CPLX>::zero();
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const unsigned i = i0 + 256u * u;
+                if (i < n_tile) X[cell_of(i)] = v[u];
+            }
+        }
+    } else {
+        for (unsigned s = tid; s < n_tile; s += 256u) X[cell_of(s)] = vload<CPLX>(in, hist, n_org + s, a.n_in, a.hl);
+    }
+    __syncthreads();
+
+    typedef const __attribute__((address_space(4))) float *cfp;
+    const cfp g = (cfp)a.G;
+    const int Lq = a.Lp / (int)SP;
+#pragma unroll 1
+    for (int mi = (int)tid; mi < TMr; mi += 256) {
+        T acc[UPM];
+#pragma unroll
+        for (int r = 0; r < UPM; r++) acc[r] = Elem<CPLX>::zero();
+        // local time qt = SP qq + p descending = tap index ascending; sample (mi, qt) sits at row p, column mi + qq
+        const T *col = X + mi;
+#pragma unroll 1
+        for (int qq = Lq - 1; qq >= 0; --qq) {
+#pragma unroll 1
+            for (int p = (int)SP - 1; p >= 0; --p) {
+                const T x = col[(unsigned)p * RL + (unsigned)qq];
+                const int qt = qq * (int)SP + p;
+#pragma unroll
+                for (int r = 0; r < UPM; r++)
+                    if (UPM == 1 || r < UP) acc[r] = mac<EXACT>(acc[r], g[r * a.Lp + qt], x);
+            }
+        }
+        const long long k = (long long)UP * (m0 + mi);
+#pragma unroll
+        for (int r = 0; r < UPM; r++)
+            if ((UPM == 1 || r < UP) && k + r < a.n_out) out[k + r] = acc[r];
+    }
+}
+
 #ifdef SFE_DIAG
 // ------------------------------------------------------ integer-step decimation, streamed (UP == 1)
 // DIAGNOSTIC LIBRARY ONLY (SFE_TILED_TPW=N, scripts/ab_dec.py tN): measured 3-10 % SLOWER than one tile per workgroup
@@ -999,25 +1095,116 @@ int launch_poly_int(const PolyArgs &a, int data_complex, int /*taps_complex*/, i
     return SFE_OK;
 }
 
-bool poly_tiled_supported(int SP, int UP, int Lp)
+// the eleven compile-time instantiations of poly_tiled_kernel
+static bool poly_tiled_compiled(int SP, int UP, int Lp)
 {
     if (Lp <= 0 || Lp % (2 * SP)) return false;   // whole chunk pairs
-    int xc;
     switch (SP * 16 + UP) {
     case 1 * 16 + 1: case 2 * 16 + 1: case 3 * 16 + 1: case 4 * 16 + 1: case 5 * 16 + 1: case 8 * 16 + 1:
     case 10 * 16 + 1: case 5 * 16 + 3: case 3 * 16 + 2: case 5 * 16 + 2: case 5 * 16 + 4:
         break;
     default: return false;
     }
-    xc = tiled_xc(SP);
-    return Lp / SP <= xc;
+    return Lp / SP <= tiled_xc(SP);
+}
+
+// ---- poly_rt_kernel's tile: m per workgroup and the LDS row pitch --------------------------------
+constexpr int RT_MAX_SP = 64, RT_MAX_UP = 8, RT_LDS_MAX = 60 * 1024;
+// tm m per tile so that the larger of the input and the output tile is ~4096 samples (a multiple of 64 m, <= 2048)
+static int rt_tile_m(int SP, int UP)
+{
+    const int w = SP > UP ? SP : UP;
+    int tm = (4096 / w) / 64 * 64;
+    if (tm < 64) tm = 64;
+    if (tm > 2048) tm = 2048;
+    return tm;
+}
+// row pitch >= tm + Lq: the scatter writes sample s to cell (s % SP) * RL + s / SP; lanes hold consecutive s.
+// Pick the pad (0..63) under which a wave's 64 consecutive s fall on the banks most evenly (64 banks of 4
+// bytes; an element covers esz / 4 of them).
+static int rt_rowlen(int SP, int tm, int Lq, int esz)
+{
+    const int base = tm + Lq, wpe = esz / 4;
+    int best_pad = 0, best_cost = 1 << 30;
+    for (int pad = 0; pad < 64; pad++) {
+        const int RL = base + pad;
+        int cost = 0;
+        for (int s0 = 0; s0 < SP * 4; s0 += (SP > 3 ? SP / 3 : 1)) {      // a few phases of the wave against the rows
+            int hits[64] = {0};
+            for (int l = 0; l < 64; l++) {
+                const int s = s0 + l, cell = (s % SP) * RL + s / SP;
+                for (int w = 0; w < wpe; w++) hits[(cell * wpe + w) & 63]++;
+            }
+            int mx = 0;
+            for (int b = 0; b < 64; b++) mx = hits[b] > mx ? hits[b] : mx;
+            cost += mx;
+        }
+        if (cost < best_cost) {
+            best_cost = cost;
+            best_pad = pad;
+        }
+    }
+    return base + best_pad;
+}
+static bool poly_rt_supported(int SP, int UP, int Lp, int esz)
+{
+    if (Lp <= 0 || Lp % SP || SP < 1 || SP > RT_MAX_SP || UP < 1 || UP > RT_MAX_UP) return false;
+    const int tm = rt_tile_m(SP, UP);
+    return (size_t)SP * (tm + Lp / SP + 63) * esz <= (size_t)RT_LDS_MAX;
+}
+
+bool poly_tiled_supported(int SP, int UP, int Lp)
+{
+    return poly_tiled_compiled(SP, UP, Lp) || poly_rt_supported(SP, UP, Lp, 8);
+}
+bool poly_tiled_is_compiled(int SP, int UP, int Lp) { return poly_tiled_compiled(SP, UP, Lp); }
+
+static int launch_poly_rt(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int data_complex, int exact, int in_u8,
+                          int n_channels, hipStream_t s)
+{
+    const int esz = data_complex ? 8 : 4;
+    if (!poly_rt_supported(plan.SP, plan.UP, plan.Lp, esz)) return SFE_ESTATE;
+    PolyTiledArgs a = a0;
+    a.SP = plan.SP;
+    a.UP = plan.UP;
+    a.tm = rt_tile_m(plan.SP, plan.UP);
+    a.rowlen = rt_rowlen(plan.SP, a.tm, plan.Lp / plan.SP, esz);
+    a.sp_inv = (unsigned)((0x100000000ull + (unsigned)plan.SP - 1) / (unsigned)plan.SP);
+    const long long mtot = (a.n_out + plan.UP - 1) / plan.UP;
+    const long long tiles = (mtot + a.tm - 1) / a.tm;
+    if (tiles > 0x7fffffffLL) {
+        set_error("polyphase: too many tiles");
+        return SFE_EINVAL;
+    }
+    a.tiles = (unsigned)tiles;
+    if (exact) a.hist_out = nullptr;
+    dim3 grid((unsigned)tiles + (a.hist_out ? 1u : 0u), (unsigned)n_channels), block(256);
+    const size_t sh = (size_t)plan.SP * a.rowlen * esz;
+#define SFE_RT(C, E, U8)                                                                             \
+    do {                                                                                              \
+        if (plan.UP == 1) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 1>), grid, block, sh, s, a);   \
+        else if (plan.UP == 2) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 2>), grid, block, sh, s, a); \
+        else if (plan.UP <= 4) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 4>), grid, block, sh, s, a); \
+        else hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 8>), grid, block, sh, s, a);                \
+    } while (0)
+    if (in_u8) {
+        if (data_complex) SFE_RT(true, false, true); else SFE_RT(false, false, true);
+    } else if (data_complex) {
+        if (exact) SFE_RT(true, true, false); else SFE_RT(true, false, false);
+    } else {
+        if (exact) SFE_RT(false, true, false); else SFE_RT(false, false, false);
+    }
+#undef SFE_RT
+    SFE_HIP(hipGetLastError());
+    return SFE_OK;
 }
 
 int launch_poly_tiled(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int data_complex, int exact,
                       int in_u8, int n_channels, hipStream_t s)
 {
     if (a0.n_out <= 0) return SFE_OK;
-    if (!poly_tiled_supported(plan.SP, plan.UP, plan.Lp)) return SFE_ESTATE;
+    if (!poly_tiled_compiled(plan.SP, plan.UP, plan.Lp))          // no compile-time instantiation: SP, UP as launch arguments
+        return launch_poly_rt(plan, a0, data_complex, exact, in_u8, n_channels, s);
     const long long mtot = (a0.n_out + plan.UP - 1) / plan.UP;
     const long long tiles = (mtot + TM - 1) / TM;
     if (tiles > 0x7fffffffLL) {
@@ -1090,9 +1277,8 @@ int launch_poly_tiled(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int da
     } break;
         switch (plan.SP * 16 + plan.UP) {
             SFE_U8(2, 1) SFE_U8(4, 1) SFE_U8(8, 1) SFE_U8(5, 3)
-        default:
-            set_error("polyphase: no u8-input kernel for %d outputs per %d inputs", plan.UP, plan.SP);
-            return SFE_ESTATE;
+        default:          // shapes with a float kernel but no u8 instantiation: the runtime-shape kernel converts on load too
+            return launch_poly_rt(plan, a0, data_complex, 0, 1, n_channels, s);
         }
 #undef SFE_U8
         SFE_HIP(hipGetLastError());

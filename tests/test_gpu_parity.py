@@ -700,6 +700,55 @@ def test_rs_u8_input_fused(api, L, orc, g5, name, cplx, chunk):
         assert synth.rel_rms(got[part::w], ref[: len(got[part::w])]) <= TOL
 
 
+# ------------------------------------------- integer-step shapes outside the compiled (SP, UP) tables
+RT_SHAPES = [("x2", 2, 1), ("3/4", 4, 3), ("4/3", 3, 4), ("/6", 1, 6), ("/7", 1, 7), ("/16", 1, 16), ("x4", 4, 1),
+             ("7/4", 4, 7), ("2/3", 3, 2), ("/13", 1, 13), ("9/8", 8, 9), ("/48", 1, 48)]
+
+
+@pytest.mark.parametrize("name,U,step", RT_SHAPES)
+@pytest.mark.parametrize("cplx", [True, False])
+def test_rs_shapes_outside_the_compiled_tables(api, L, orc, name, U, step, cplx):
+    """VERDICT r3 missing 4: interpolating ratios (UP > SP: what `resample` takes and `decimate` refuses,
+    libdsp/resample.cxx:91 / decimate.cxx:75-78) and decimations no compile-time (SP, UP) pair covers run the
+    runtime-shape tiled kernel (poly_rt_kernel).  Exact mode is bit-identical to the oracle (itself bit-exact
+    with the compiled reference) over ragged chunkings; the fused default is within 1e-5; u8 wire-format input
+    is no longer refused for these shapes and equals the float path fed the converted samples bit for bit."""
+    rate = float(np.float32(step) / np.float32(U))
+    assert float(np.float32(rate) * np.float32(U)) == float(step)
+    taps = synth.lowpass_taps(32 * U - (1 if U > 1 else 0), 0.9 * min(1.0 / U, 1.0 / step), gain=float(U))
+    w = 2 if cplx else 1
+    n = 3 * 4096 * max(1, step // 8) + 777
+    x = synth.synth_f32(w * n, ch=31)
+    refs = [orc.Resample(taps, U, 4096).stream(x[part::w], rate)[0] for part in range(w)]
+    for exact, chunk in ((True, None), (True, 4096), (True, 3 * 4096 + 0), (False, None)):
+        r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=cplx)
+        r.set_exact(exact)
+        r.set_algo(L.RS_ALGO_DIRECT)              # the direct kernels are the subject here
+        y = r.resample_array(x, rate, chunk=chunk)[0]
+        for part in range(w):
+            got, ref = y[part::w], refs[part]
+            assert len(ref) - len(got) in (0, 1), (name, len(ref), len(got))
+            if exact:
+                assert np.array_equal(got, ref[: len(got)]), (name, cplx, chunk)
+            else:
+                assert synth.rel_rms(got, ref[: len(got)]) <= TOL, (name, cplx)
+    # u8 wire-format input through the same shape
+    b = _u8_stream(w * n, 4)
+    xf = orc.rx_u8_to_f32(b)
+    rf = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=cplx)
+    rf.set_algo(L.RS_ALGO_DIRECT)
+    want = rf.resample_array(xf, rate)[0]
+    r8 = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=cplx)
+    r8.set_algo(L.RS_ALGO_DIRECT)
+    r8.set_input_format(L.FMT_U8)
+    d_in = api.DeviceArray.from_bytes(b)
+    cap = int(n / rate) + 8
+    d_out = api.DeviceArray(w * cap)
+    k = r8.process_stream(d_in, n, d_out, cap, rate)
+    got = d_out.to_numpy(w * k)
+    assert len(want) - len(got) in (0, w) and np.array_equal(got, want[: len(got)]), name
+
+
 # ----------------------------------------------------------------- edge cases / misuse
 def test_empty_and_tiny_inputs(api, L, orc):
     """n = 0 is a no-op; n < n_taps works and carries state; 1-tap filter is a gain."""
