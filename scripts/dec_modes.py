@@ -8,7 +8,10 @@ two modes ~7 % apart that flip from process to process on one box.  What decides
                                   k x 2 MiB (the reference point re-timed between groups)
     dec_modes.py realloc          ONE process: free and re-allocate the two buffers, with other allocations
                                   in between so that they land elsewhere
-Product library, product kernel; HIP events on the launch stream; 3 launches per sample."""
+    dec_modes.py windows          ONE process, DIAGNOSTIC library: the resident workgroups reading 1, 2, 4, ... separate
+                                  windows of the stream (interleaved A/B) -- does spreading the window remove the slow mode?
+Product library, product kernel (windows: the diagnostic flavour of the same kernel); HIP events on the launch
+stream; 3 launches per sample.  `one` also samples the memory / fabric / shader clock levels while launches are in flight."""
 import os
 import subprocess
 import sys
@@ -17,7 +20,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from simplefe_amd import api, lib, synth  # noqa: E402
+from simplefe_amd import lib  # noqa: E402
+if len(sys.argv) > 1 and sys.argv[1] == "windows":
+    from simplefe_amd import build
+    lib.LIB_PATH = build.build_lib(diag=True)
+from simplefe_amd import api, synth  # noqa: E402
 
 N = 1 << 30
 CAP = N // 8 + 8
@@ -45,6 +52,20 @@ def handle():
     return api.Rs(synth.taps_cfg4(), 1, 4096, mode=lib.RS_DECIMATE, data_complex=True), api.Timer()
 
 
+def clocks():
+    """current DPM level of the memory, fabric, SoC and shader clocks (sysfs), sampled while the GPU is busy"""
+    import glob
+    out = []
+    for name in ("pp_dpm_mclk", "pp_dpm_fclk", "pp_dpm_socclk", "pp_dpm_sclk"):
+        for f in sorted(glob.glob("/sys/class/drm/card*/device/" + name))[:1]:
+            try:
+                cur = [l.strip() for l in open(f).read().splitlines() if "*" in l]
+                out.append(name[7:] + " " + (cur[0].replace(" ", "") if cur else "?"))
+            except OSError:
+                out.append(name[7:] + " n/a")
+    return ", ".join(out) if out else "clocks n/a"
+
+
 def one():
     x = api.DeviceArray(2 * N)
     x.fill_synth(synth.SEED)
@@ -52,8 +73,12 @@ def one():
     r, t = handle()
     # burn ~150 ms first: the chip's start-up transient is not the question here
     med, lo, hi = time_at(r, t, x.ptr, y.ptr, rounds=15, warm=60)
+    for _ in range(300):                      # ~0.45 s of launches in flight while the clock levels are read
+        r.process_stream(x.ptr, N, y.ptr, CAP, 8.0)
+    clk = clocks()
+    api.sync()
     print(f"in {x.ptr:#014x} out {y.ptr:#014x}  in%2M {x.ptr % (2 << 20):#x} out%2M {y.ptr % (2 << 20):#x} "
-          f"(out-in)%1G {(y.ptr - x.ptr) % (1 << 30):#x}  median {med:.4f} ms  min {lo:.4f}  max {hi:.4f}  frac {frac(med):.3f}", flush=True)
+          f"(out-in)%1G {(y.ptr - x.ptr) % (1 << 30):#x}  median {med:.4f} ms  min {lo:.4f}  max {hi:.4f}  frac {frac(med):.3f}  [{clk}]", flush=True)
 
 
 def many(n):
@@ -117,6 +142,24 @@ def realloc():
             keep.append(api.DeviceArray(int(rng.integers(1 << 24, 1 << 28)) + 1023))
 
 
+def windows():
+    x = api.DeviceArray(2 * N)
+    x.fill_synth(synth.SEED)
+    y = api.DeviceArray(2 * CAP)
+    r, t = handle()
+    time_at(r, t, x.ptr, y.ptr, rounds=3, warm=60)
+    wins = [1, 2, 4, 8, 16, 64, 256]
+    res = {w: [] for w in wins}
+    for k in range(8):
+        for w in wins:
+            os.environ["SFE_TILED_WIN"] = str(w)
+            res[w].append(time_at(r, t, x.ptr, y.ptr, rounds=3, warm=2)[0])
+    print(f"in {x.ptr:#014x} out {y.ptr:#014x}")
+    for w in wins:
+        a = np.array(res[w])
+        print(f"windows {w:4d}: median {np.median(a):.4f} ms  min {a.min():.4f}  max {a.max():.4f}  frac {frac(float(np.median(a))):.3f}", flush=True)
+
+
 if __name__ == "__main__":
     cmd = sys.argv[1] if len(sys.argv) > 1 else "one"
     if cmd == "one":
@@ -127,5 +170,7 @@ if __name__ == "__main__":
         sweep()
     elif cmd == "realloc":
         realloc()
+    elif cmd == "windows":
+        windows()
     else:
         raise SystemExit(__doc__)

@@ -90,8 +90,10 @@ struct PlanCache {
     std::map<std::pair<int, long long>, PolyTiledPlan> plans;   // (step, pos0) -> plan
     void clear()
     {
-        for (auto &kv : plans)
+        for (auto &kv : plans) {
             if (kv.second.d_G) (void)hipFree(kv.second.d_G);
+            if (kv.second.d_Gt) (void)hipFree(kv.second.d_Gt);
+        }
         plans.clear();
     }
 };
@@ -166,8 +168,17 @@ static const PolyTiledPlan *get_tiled_plan(PlanCache &cache, const std::vector<f
     }
     hipError_t e = hipMalloc(&pl.d_G, f.G.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(pl.d_G, f.G.data(), f.G.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && pl.UP <= 8) {
+        // the same taps transposed, [local time][phase] padded to 8 phases (the runtime-shape kernel reads a row per tap)
+        std::vector<float> gt((size_t)pl.Lp * 8, 0.0f);
+        for (int r = 0; r < pl.UP; r++)
+            for (int q = 0; q < pl.Lp; q++) gt[(size_t)q * 8 + r] = f.G[(size_t)r * pl.Lp + q];
+        e = hipMalloc(&pl.d_Gt, gt.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(pl.d_Gt, gt.data(), gt.size() * sizeof(float), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
         if (pl.d_G) (void)hipFree(pl.d_G);
+        if (pl.d_Gt) (void)hipFree(pl.d_Gt);
         *rc = hip_fail(e, "tiled plan upload");
         return nullptr;
     }
@@ -752,6 +763,7 @@ static int fir_run(Fir *f, const void *d_in, void *d_out, size_t n, size_t in_st
             ta.out = d_out;
             ta.hist = f->d_hist[f->cur];
             ta.G = pl->d_G;
+            ta.Gt = pl->d_Gt;
             ta.n_in = (long long)n;
             ta.in_stride = (long long)in_stride;
             ta.out_stride = (long long)out_stride;
@@ -1860,6 +1872,7 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
             ta.hist_out = can_fuse && !r->exact_stream ? r->d_hist[r->cur ^ 1] : nullptr;      // exact kernels: separate carry-over launch
             hist_fused = ta.hist_out != nullptr;
             ta.G = pl->d_G;
+            ta.Gt = pl->d_Gt;
             ta.n_in = (long long)n_in;
             ta.in_stride = (long long)in_stride;
             ta.out_stride = (long long)out_stride;

@@ -134,6 +134,7 @@ int launch_poly_int(const PolyArgs &a, int data_complex, int taps_complex, int e
 struct PolyTiledPlan {
     int    SP = 0, UP = 0, Lp = 0, e_max = 0;
     float *d_G = nullptr;        // [UP][Lp]
+    float *d_Gt = nullptr;       // [Lp][8]: the same taps, one row of all UP phases per local time (poly_rt_kernel: one scalar load per tap)
 };
 struct PolyTiledArgs {
     const void *in;
@@ -141,8 +142,11 @@ struct PolyTiledArgs {
     const void *hist;
     void       *hist_out = nullptr;   // if non-null (needs n_in >= hl): one extra workgroup per channel writes the next call's history
     unsigned    tiles = 0;            // set by the launcher: tiles per channel (blockIdx.x == tiles is that extra workgroup)
+    unsigned    win = 0;              // > 1: workgroup i takes tile (i % win) * ceil(tiles / win) + i / win -- the resident workgroups
+                                      // read `win` separate windows of the stream instead of one (experiment)
     unsigned    tpw = 1;              // poly_stream_kernel: consecutive tiles per workgroup (the extra workgroup is blockIdx.x == ceil(tiles / tpw))
     const float *G;
+    const float *Gt = nullptr;        // PolyTiledPlan::d_Gt
     long long   n_in, in_stride, out_stride, n_out;
     int         hl, Lp, e_max;
     // poly_rt_kernel (any SP, UP as launch arguments; set by the launcher)

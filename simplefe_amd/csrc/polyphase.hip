@@ -187,7 +187,13 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
     // decimator 12 VGPRs -- 82 instead of 70, five waves per SIMD instead of seven, 1.59 -> 2.05 ms at 2^30.
     // (fused-arithmetic instantiations only: the exact-mode kernels -- the class-compatible path, a few thousand samples per
     // call -- are left as they were, two of them sit on a register / scalar-register step that the extra arguments cross)
-    if (!EXACT && a.hist_out && blockIdx.x == a.tiles) {
+    unsigned bx = blockIdx.x, nwork = a.tiles;
+    if (a.win > 1u) {                            // `win` windows: see PolyTiledArgs
+        const unsigned per = (a.tiles + a.win - 1u) / a.win;
+        nwork = per * a.win;
+        bx = (blockIdx.x % a.win) * per + blockIdx.x / a.win;
+    }
+    if (!EXACT && a.hist_out && blockIdx.x == nwork) {
         T *ho = static_cast<T *>(a.hist_out) + (size_t)ch * a.hl;
 #pragma unroll 1
         for (unsigned i = tid; i < (unsigned)a.hl; i += 256u) {
@@ -196,7 +202,8 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
         }
         return;
     }
-    const long long m0 = (long long)blockIdx.x * TM;
+    if (bx >= a.tiles) return;
+    const long long m0 = (long long)bx * TM;
     const long long n_org = (long long)SP * m0 + a.e_max - (a.Lp - 1);   // stream index of local sample 0
     const int n_tile = SP * TM + a.Lp;
     constexpr int MAIN = SP * TM / 256;       // unrolled loads per thread for the body of the tile
@@ -391,8 +398,10 @@ __global__ __launch_bounds__(256) void poly_rt_kernel(PolyTiledArgs a)
     const long long m0 = (long long)blockIdx.x * TMr;
     const long long n_org = (long long)SP * m0 + a.e_max - (a.Lp - 1);   // stream index of local sample 0
     const unsigned n_tile = SP * (unsigned)TMr + (unsigned)a.Lp;
-    // local sample s -> cell (s % SP) * RL + s / SP, the division as a multiply (exact: s < 2^16, SP <= 64)
+    // local sample s -> cell (s % SP) * RL + s / SP, the division as a multiply (exact: s < 2^16, SP <= 64;
+    // SP = 1 has no 32-bit multiplier and needs none)
     auto cell_of = [&](unsigned s) -> unsigned {
+        if (SP == 1u) return s;
         const unsigned q = __umulhi(s, a.sp_inv);
         return (s - q * SP) * RL + q;
     };
@@ -419,8 +428,8 @@ __global__ __launch_bounds__(256) void poly_rt_kernel(PolyTiledArgs a)
     }
     __syncthreads();
 
-    typedef const __attribute__((address_space(4))) float *cfp;
-    const cfp g = (cfp)a.G;
+    // taps: row qt of Gt holds the UP phases' taps at local time qt (padded to 8 floats): ONE scalar load per tap
+    const __attribute__((address_space(4))) float *gt = (const __attribute__((address_space(4))) float *)a.Gt;
     const int Lq = a.Lp / (int)SP;
 #pragma unroll 1
     for (int mi = (int)tid; mi < TMr; mi += 256) {
@@ -428,16 +437,22 @@ __global__ __launch_bounds__(256) void poly_rt_kernel(PolyTiledArgs a)
 #pragma unroll
         for (int r = 0; r < UPM; r++) acc[r] = Elem<CPLX>::zero();
         // local time qt = SP qq + p descending = tap index ascending; sample (mi, qt) sits at row p, column mi + qq
-        const T *col = X + mi;
-#pragma unroll 1
-        for (int qq = Lq - 1; qq >= 0; --qq) {
-#pragma unroll 1
-            for (int p = (int)SP - 1; p >= 0; --p) {
-                const T x = col[(unsigned)p * RL + (unsigned)qq];
-                const int qt = qq * (int)SP + p;
+        unsigned off = (SP - 1u) * RL + (unsigned)(Lq - 1) + (unsigned)mi;
+        unsigned p = SP - 1u;
+#pragma unroll 4
+        for (int qt = a.Lp - 1; qt >= 0; --qt) {
+            const T x = X[off];
+            float tp[UPM];
 #pragma unroll
-                for (int r = 0; r < UPM; r++)
-                    if (UPM == 1 || r < UP) acc[r] = mac<EXACT>(acc[r], g[r * a.Lp + qt], x);
+            for (int r = 0; r < UPM; r++) tp[r] = gt[8 * qt + r];       // consecutive scalar loads: merged into one s_load_dwordxN
+#pragma unroll
+            for (int r = 0; r < UPM; r++) acc[r] = mac<EXACT>(acc[r], tp[r], x);     // phases beyond UP meet the table's zeros and are not stored
+            if (p == 0u) {
+                p = SP - 1u;
+                off += (SP - 1u) * RL - 1u;                         // row SP - 1 of the column before
+            } else {
+                p--;
+                off -= RL;
             }
         }
         const long long k = (long long)UP * (m0 + mi);
@@ -1214,7 +1229,14 @@ int launch_poly_tiled(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int da
     PolyTiledArgs a = a0;
     a.tiles = (unsigned)tiles;
     if (exact) a.hist_out = nullptr;
-    dim3 grid((unsigned)tiles + (a.hist_out ? 1u : 0u), (unsigned)n_channels), block(256);      // + the history workgroup
+    unsigned nwork = (unsigned)tiles;
+#ifdef SFE_DIAG
+    if (const char *e = getenv("SFE_TILED_WIN")) {      // scripts/dec_modes.py windows: the resident workgroups over `win` windows
+        a.win = (unsigned)atoi(e);
+        if (a.win > 1u) nwork = (unsigned)((tiles + a.win - 1) / a.win) * a.win;
+    }
+#endif
+    dim3 grid(nwork + (a.hist_out ? 1u : 0u), (unsigned)n_channels), block(256);      // + the history workgroup
     const size_t esz = data_complex ? 8 : 4;
 #ifdef SFE_DIAG
     // the streamed decimator (poly_stream_kernel): runs of consecutive tiles per workgroup with the next tile's samples
