@@ -4,7 +4,7 @@
 # the two transform kernels, and the variant / ablation tables from the diagnostic library.
 # Output under gpurun_out/prof_<tag>_*/; summarised into profiles/ by scripts/summarise_profiles.py
 # (run in the authoring container).   usage: scripts/collect_profiles.sh [tag]
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp; export TMPDIR=/tmp
 for WL in fir decimate resample; do
@@ -19,6 +19,17 @@ for WL in fir decimate resample; do
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu --no-others > $O/write.log 2>&1 || exit 1
   tail -1 $O/kt.log | cut -c1-200
 done
+# the per-rank launches of the N = 2, 4, 8 channel-sharded job (and the whole job on one GPU), so that
+# roofline.traffic is not null in a SCALE line: key fir256_cf32_2p<k>_<c>ch = what ONE rank launches
+for SHAPE in "64 30" "32 29" "16 28" "8 27"; do
+  set -- $SHAPE
+  O=$R/gpurun_out/prof_${TAG}_fir_$1ch
+  mkdir -p $O
+  (cd $R && python3 -m simplefe_amd.build --hash) > $O/csrc_hash.txt
+  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --channels $1 --log2n $2 --steps 3 --warmup 1 --no-cpu --no-others > $O/fetch.log 2>&1 || exit 1
+  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --channels $1 --log2n $2 --steps 3 --warmup 1 --no-cpu --no-others > $O/write.log 2>&1 || exit 1
+done
+set --
 # the driver's own command shape (all legs in one process)
 O=$R/gpurun_out/prof_${TAG}_default
 mkdir -p $O

@@ -21,7 +21,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from simplefe_amd import lib  # noqa: E402
-if len(sys.argv) > 1 and sys.argv[1] == "windows":
+if len(sys.argv) > 1 and sys.argv[1] in ("windows", "tlb", "tlbmany"):
     from simplefe_amd import build
     lib.LIB_PATH = build.build_lib(diag=True)
 from simplefe_amd import api, synth  # noqa: E402
@@ -160,6 +160,30 @@ def windows():
         print(f"windows {w:4d}: median {np.median(a):.4f} ms  min {a.min():.4f}  max {a.max():.4f}  frac {frac(float(np.median(a))):.3f}", flush=True)
 
 
+def tlb():
+    """ONE process, diagnostic library: a one-lane look-ahead touch of the tile N tiles further on (address translation
+    in flight before that tile's workgroup starts), interleaved A/B against none."""
+    x = api.DeviceArray(2 * N)
+    x.fill_synth(synth.SEED)
+    y = api.DeviceArray(2 * CAP)
+    r, t = handle()
+    time_at(r, t, x.ptr, y.ptr, rounds=3, warm=60)
+    aheads = [0, 256, 1024, 2048, 4096, 16384]
+    res = {w: [] for w in aheads}
+    for k in range(6):
+        for w in aheads:
+            os.environ["SFE_TILED_TLB"] = str(w)
+            res[w].append(time_at(r, t, x.ptr, y.ptr, rounds=3, warm=2)[0])
+    print("ahead:" + "".join(f"  {w}: {np.median(res[w]):.4f}" for w in aheads), flush=True)
+
+
+def tlbmany(n):
+    for i in range(n):
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "tlb"], capture_output=True, text=True, timeout=300)
+        line = (out.stdout.strip().splitlines() or ["(no output) " + out.stderr[-300:]])[-1]
+        print(f"process {i:2d}: {line}", flush=True)
+
+
 if __name__ == "__main__":
     cmd = sys.argv[1] if len(sys.argv) > 1 else "one"
     if cmd == "one":
@@ -172,5 +196,9 @@ if __name__ == "__main__":
         realloc()
     elif cmd == "windows":
         windows()
+    elif cmd == "tlb":
+        tlb()
+    elif cmd == "tlbmany":
+        tlbmany(int(sys.argv[2]) if len(sys.argv) > 2 else 8)
     else:
         raise SystemExit(__doc__)

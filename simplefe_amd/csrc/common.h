@@ -144,6 +144,8 @@ struct PolyTiledArgs {
     unsigned    tiles = 0;            // set by the launcher: tiles per channel (blockIdx.x == tiles is that extra workgroup)
     unsigned    win = 0;              // > 1: workgroup i takes tile (i % win) * ceil(tiles / win) + i / win -- the resident workgroups
                                       // read `win` separate windows of the stream instead of one (experiment)
+    unsigned    tlb_ahead = 0;        // > 0: one lane of every workgroup touches the input and the output `tlb_ahead` tiles ahead of its own,
+                                      // so that the address translation of that part of the stream is resident when its workgroups start
     unsigned    tpw = 1;              // poly_stream_kernel: consecutive tiles per workgroup (the extra workgroup is blockIdx.x == ceil(tiles / tpw))
     const float *G;
     const float *Gt = nullptr;        // PolyTiledPlan::d_Gt

@@ -18,7 +18,7 @@
 //   s(p) and s(p + 1) then lie in what the block's inverse transforms produce validly.
 //   0. the runs (timelaw.h: t_i = t0 + i d, exact in double) of the one or two reference calls the block
 //      overlaps are copied to LDS; every thread finds the block's first and last output by the same
-//      uniform search and expands ITS outputs k = k0 + tid + 256 q into (position, mu), kept in registers
+//      uniform search and expands ITS outputs k = k0 + tid + 256 q into (position, mu), kept in LDS [q][thread]
 //   1. forward transform -> this thread's 16 bins X, kept in registers
 //   2. for each phase j: X H_j -> inverse transform -> S_j[n] into the exchange buffer -> every thread
 //      adds its outputs' share: (1 - mu) S_j[n] where the output's first sample has phase j, mu S_j[n'] where
@@ -46,10 +46,15 @@ static_assert(sizeof(RunLds) == 24, "TlSeg layout");
 constexpr int GEN_MAX_RUNS = 1024;       // runs of the (at most two) calls a block overlaps, in LDS: 24 KiB of the 34 KiB buffer
 
 // KPT: outputs per thread (the block owns at most 256 KPT outputs; the launcher picks it from the rate)
+// Registers: X (32) + the transform's working set (32) + the spectrum loads in flight + KPT accumulators is what fits three
+// workgroups per CU (<= 168 VGPRs); so the twiddle bases are re-read from L2 where a stage needs them (24 VGPRs) and each
+// thread's (position, mu) table sits in LDS behind the exchange buffer, [q][thread] (2 KPT VGPRs).
 template <int KPT>
-__global__ __launch_bounds__(256) void poly_gen4096_kernel(PolyGenArgs a)
+__global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(PolyGenArgs a)
 {
     __shared__ v2f lds[FFT_ROWS * LDS_K2_STRIDE];
+    __shared__ unsigned tab_pos[KPT * 256];
+    __shared__ float tab_mu[KPT * 256];
     const unsigned t = threadIdx.x, lo = t & 15u, hi = t >> 4;
     const int ch = blockIdx.y;
     const long long blk = blockIdx.x;
@@ -127,13 +132,12 @@ __global__ __launch_bounds__(256) void poly_gen4096_kernel(PolyGenArgs a)
     const int Ta = ka_hi - ka_lo, T = Ta + (kb_hi - kb_lo);        // T <= 256 KPT (launcher)
     const long long k_first = Ta > 0 || c1 == c0 ? ca.k_first + ka_lo : cb.k_first + kb_lo;   // the block's outputs are consecutive
 
-    unsigned posl[KPT];       // position inside the block, P - Plo (< U A); 0xFFFFFFFF: no output
-    float mu[KPT];
-#pragma unroll
+    // tab_pos: position inside the block, P - Plo (< U A); 0xFFFFFFFF: no output
+#pragma unroll 1
     for (int q = 0; q < KPT; q++) {
         const int idx = (int)t + 256 * q;
-        posl[q] = 0xFFFFFFFFu;
-        mu[q] = 0.0f;
+        unsigned pl_q = 0xFFFFFFFFu;
+        float mu_q = 0.0f;
         if (idx < T) {
             const bool second = idx >= Ta;
             const RunLds *rs = second ? rb : ra;
@@ -147,21 +151,36 @@ __global__ __launch_bounds__(256) void poly_gen4096_kernel(PolyGenArgs a)
             const RunLds g = rs[l];
             const double tt = g.t0 + (double)(kk - g.k0) * (double)g.d;      // exact (timelaw.h)
             const double fl = floor(tt);
-            mu[q] = (float)(tt - fl);
-            posl[q] = (unsigned)((second ? offb : offa) + (long long)fl - Plo);
+            mu_q = (float)(tt - fl);
+            pl_q = (unsigned)((second ? offb : offa) + (long long)fl - Plo);
         }
+        tab_pos[256 * q + t] = pl_q;
+        tab_mu[256 * q + t] = mu_q;
     }
     lds_barrier();                               // the runs are dead: the buffer is the exchange buffer from here on
 
-    // ---- twiddle bases (fir_fft.hip: W^(e (4a + b)) = q[a] p[b])
+    // ---- twiddle bases (fir_fft.hip: W^(e (4a + b)) = q[a] p[b]), re-read where a stage needs them: the index is made
+    // opaque each time so that the loads are not hoisted back out of the phase loop into 24 resident registers
     v2f p1[4], q1[4], p2[4], q2[4];
+    auto load_tw1 = [&]() {
+        unsigned tt = t;
+        asm volatile("" : "+v"(tt));
 #pragma unroll
-    for (int k = 1; k < 4; k++) {
-        p1[k] = a.tw1[k * 256 + t];
-        q1[k] = a.tw1[(k + 3) * 256 + t];
-        p2[k] = a.tw2[k * 16 + lo];
-        q2[k] = a.tw2[(k + 3) * 16 + lo];
-    }
+        for (int k = 1; k < 4; k++) {
+            p1[k] = a.tw1[k * 256 + tt];
+            q1[k] = a.tw1[(k + 3) * 256 + tt];
+        }
+    };
+    auto load_tw2 = [&]() {
+        unsigned ll = lo;
+        asm volatile("" : "+v"(ll));
+#pragma unroll
+        for (int k = 1; k < 4; k++) {
+            p2[k] = a.tw2[k * 16 + ll];
+            q2[k] = a.tw2[(k + 3) * 16 + ll];
+        }
+    };
+    load_tw1();
     const unsigned base_b = hi * LDS_K2_STRIDE + lo, base_c = hi * LDS_K2_STRIDE + lo * LDS_K1_STRIDE;
 
     // ---- 1. forward transform: F1 over n2, F2 over n1, F3 over n0 -> bin k of this thread in X[k]
@@ -174,6 +193,7 @@ __global__ __launch_bounds__(256) void poly_gen4096_kernel(PolyGenArgs a)
         else if (k & 3) x = cmul(x, p1[k & 3]);
         lds[t + (unsigned)k * LDS_K2_STRIDE] = x;
     }
+    load_tw2();
     lds_barrier();
     v2f v[16];
 #pragma unroll
@@ -209,6 +229,7 @@ __global__ __launch_bounds__(256) void poly_gen4096_kernel(PolyGenArgs a)
         dft16_rev<+1>(v);
 #pragma unroll
         for (int k = 0; k < 16; k++) lds[base_c + k] = v[k];
+        load_tw2();
         lds_barrier();
         // I2: over k1
 #pragma unroll
@@ -223,6 +244,7 @@ __global__ __launch_bounds__(256) void poly_gen4096_kernel(PolyGenArgs a)
         lds_barrier();
 #pragma unroll
         for (int k = 0; k < 16; k++) lds[base_b + 16u * k] = v[P16(k)];
+        load_tw1();
         lds_barrier();
         // I3: over k2 -> S_j of transform elements t + 256 r, written back to the cells this thread read
 #pragma unroll
@@ -241,27 +263,28 @@ __global__ __launch_bounds__(256) void poly_gen4096_kernel(PolyGenArgs a)
         const unsigned ju = (unsigned)j;
 #pragma unroll
         for (int q = 0; q < KPT; q++) {
-            const unsigned pl = posl[q];
+            const unsigned pl = tab_pos[256 * q + t];
             if (pl == 0xFFFFFFFFu) continue;
+            const float mu_q = tab_mu[256 * q + t];
             const unsigned n = Uu > 1u ? __umulhi(pl, Minv) : pl, ph = pl - n * Uu;
             const bool wrap = ph + 1u == Uu;                         // the second sample is phase 0 of the NEXT input sample
             if (ph == ju) {
                 const unsigned e = e0 + n;
                 const v2f s0 = lds[(e >> 8) * LDS_K2_STRIDE + (e & 255u)];
-                const float om = 1.0f - mu[q];                      // resample.cxx:147
+                const float om = 1.0f - mu_q;                      // resample.cxx:147
                 acc[q] = __builtin_elementwise_fma((v2f){om, om}, s0, acc[q]);
             }
             if ((wrap ? 0u : ph + 1u) == ju) {
                 const unsigned e = e0 + n + (wrap ? 1u : 0u);
                 const v2f s1 = lds[(e >> 8) * LDS_K2_STRIDE + (e & 255u)];
-                acc[q] = __builtin_elementwise_fma((v2f){mu[q], mu[q]}, s1, acc[q]);
+                acc[q] = __builtin_elementwise_fma((v2f){mu_q, mu_q}, s1, acc[q]);
             }
         }
     }
     // ---- 3. lanes = consecutive outputs
 #pragma unroll
     for (int q = 0; q < KPT; q++)
-        if (posl[q] != 0xFFFFFFFFu) __builtin_nontemporal_store(acc[q], out + k_first + (long long)t + 256 * q);
+        if ((int)t + 256 * q < T) __builtin_nontemporal_store(acc[q], out + k_first + (long long)t + 256 * q);
 }
 
 }  // namespace

@@ -206,6 +206,14 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
     const long long m0 = (long long)bx * TM;
     const long long n_org = (long long)SP * m0 + a.e_max - (a.Lp - 1);   // stream index of local sample 0
     const int n_tile = SP * TM + a.Lp;
+    // translation look-ahead (PolyTiledArgs::tlb_ahead): a one-lane read of the first input sample and the first output of the
+    // tile `tlb_ahead` further on; what it returns is looked at after the tile's own stores, i.e. never waited for early
+    float touch = 0.0f;
+    if (!IN_U8 && a.tlb_ahead && tid == 0) {
+        const long long ni = n_org + (long long)a.tlb_ahead * SP * TM, ko = (long long)UP * (m0 + (long long)a.tlb_ahead * TM);
+        if (ni >= 0 && ni < a.n_in) touch = __builtin_nontemporal_load(reinterpret_cast<const float *>(in + ni));
+        if (ko < a.n_out) touch += __builtin_nontemporal_load(reinterpret_cast<const float *>(out + ko));
+    }
     constexpr int MAIN = SP * TM / 256;       // unrolled loads per thread for the body of the tile
 
     // ---- stage: coalesced 8-byte lanes in, transposed into the SP rows
@@ -356,6 +364,7 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
 #pragma unroll
         for (int i = 0; i < UP; i++) __builtin_nontemporal_store(Yp[tid + 256 * i], op + tid + 256 * i);
     }
+    if (!IN_U8 && a.tlb_ahead) asm volatile("" ::"v"(touch));      // the look-ahead reads end here
 }
 
 // ------------------------------------------- integer-step law, tiled, ANY (SP, UP): launch arguments
@@ -370,7 +379,10 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
 // through the constant address space (scalar loads: they are wave-uniform).  Accumulation runs tap index
 // ascending from 0.0f (the reference's order, libdsp/decimate.cxx:134-137): EXACT is bit-identical to the
 // compiled reference, the default fuses multiply and add.  UPM = accumulators compiled in (>= UP).
-template <bool CPLX, bool EXACT, bool IN_U8, int UPM>
+// MB: m per thread that run TOGETHER through the tap loop (m, m + 256, ...): one tap row (a scalar load) and one loop
+// step feed MB sample reads and MB x UP multiply-accumulates -- with one m at a time the loop is bound by the latency of
+// the tap load and the LDS read (interpolate x2: 2.38 -> see profiles/r04/shapes.txt).
+template <bool CPLX, bool EXACT, bool IN_U8, int UPM, int MB>
 __global__ __launch_bounds__(256) void poly_rt_kernel(PolyTiledArgs a)
 {
     typedef typename Elem<CPLX>::T T;
@@ -431,22 +443,32 @@ __global__ __launch_bounds__(256) void poly_rt_kernel(PolyTiledArgs a)
     // taps: row qt of Gt holds the UP phases' taps at local time qt (padded to 8 floats): ONE scalar load per tap
     const __attribute__((address_space(4))) float *gt = (const __attribute__((address_space(4))) float *)a.Gt;
     const int Lq = a.Lp / (int)SP;
+    const bool out16 = CPLX && (UP % 2 == 0) && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;     // a thread's UP outputs as 16-byte pairs
 #pragma unroll 1
-    for (int mi = (int)tid; mi < TMr; mi += 256) {
-        T acc[UPM];
+    for (int mi0 = (int)tid; mi0 < TMr; mi0 += 256 * MB) {
+        T acc[MB][UPM];
+        unsigned cj[MB];                                             // column of m_j relative to m_0 (a clamped one beyond the tile: not stored)
 #pragma unroll
-        for (int r = 0; r < UPM; r++) acc[r] = Elem<CPLX>::zero();
+        for (int j = 0; j < MB; j++) {
+            cj[j] = mi0 + 256 * j < TMr ? 256u * j : 0u;
+#pragma unroll
+            for (int r = 0; r < UPM; r++) acc[j][r] = Elem<CPLX>::zero();
+        }
         // local time qt = SP qq + p descending = tap index ascending; sample (mi, qt) sits at row p, column mi + qq
-        unsigned off = (SP - 1u) * RL + (unsigned)(Lq - 1) + (unsigned)mi;
+        unsigned off = (SP - 1u) * RL + (unsigned)(Lq - 1) + (unsigned)mi0;
         unsigned p = SP - 1u;
-#pragma unroll 4
+#pragma unroll 2
         for (int qt = a.Lp - 1; qt >= 0; --qt) {
-            const T x = X[off];
+            T x[MB];
+#pragma unroll
+            for (int j = 0; j < MB; j++) x[j] = X[off + cj[j]];
             float tp[UPM];
 #pragma unroll
             for (int r = 0; r < UPM; r++) tp[r] = gt[8 * qt + r];       // consecutive scalar loads: merged into one s_load_dwordxN
 #pragma unroll
-            for (int r = 0; r < UPM; r++) acc[r] = mac<EXACT>(acc[r], tp[r], x);     // phases beyond UP meet the table's zeros and are not stored
+            for (int j = 0; j < MB; j++)
+#pragma unroll
+                for (int r = 0; r < UPM; r++) acc[j][r] = mac<EXACT>(acc[j][r], tp[r], x[j]);     // phases beyond UP meet the table's zeros and are not stored
             if (p == 0u) {
                 p = SP - 1u;
                 off += (SP - 1u) * RL - 1u;                         // row SP - 1 of the column before
@@ -455,10 +477,23 @@ __global__ __launch_bounds__(256) void poly_rt_kernel(PolyTiledArgs a)
                 off -= RL;
             }
         }
-        const long long k = (long long)UP * (m0 + mi);
 #pragma unroll
-        for (int r = 0; r < UPM; r++)
-            if ((UPM == 1 || r < UP) && k + r < a.n_out) out[k + r] = acc[r];
+        for (int j = 0; j < MB; j++) {
+            const int mi = mi0 + 256 * j;
+            if (mi >= TMr) continue;
+            const long long k = (long long)UP * (m0 + mi);
+            if constexpr (CPLX && UPM >= 2) {
+                if (out16 && k + UP <= a.n_out) {
+#pragma unroll
+                    for (int r = 0; r + 1 < UPM; r += 2)
+                        if (r < UP) *reinterpret_cast<v4f *>(out + k + r) = (v4f){acc[j][r].x, acc[j][r].y, acc[j][r + 1].x, acc[j][r + 1].y};
+                    continue;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < UPM; r++)
+                if ((UPM == 1 || r < UP) && k + r < a.n_out) out[k + r] = acc[j][r];
+        }
     }
 }
 
@@ -1195,12 +1230,23 @@ static int launch_poly_rt(const PolyTiledPlan &plan, const PolyTiledArgs &a0, in
     if (exact) a.hist_out = nullptr;
     dim3 grid((unsigned)tiles + (a.hist_out ? 1u : 0u), (unsigned)n_channels), block(256);
     const size_t sh = (size_t)plan.SP * a.rowlen * esz;
+    // m per thread run together: as many as the tile gives a thread, up to 4 (2 for eight phase sums: registers)
+    const int per_thread = (a.tm + 255) / 256;
 #define SFE_RT(C, E, U8)                                                                             \
     do {                                                                                              \
-        if (plan.UP == 1) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 1>), grid, block, sh, s, a);   \
-        else if (plan.UP == 2) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 2>), grid, block, sh, s, a); \
-        else if (plan.UP <= 4) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 4>), grid, block, sh, s, a); \
-        else hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 8>), grid, block, sh, s, a);                \
+        if (plan.UP == 1) {                                                                           \
+            if (per_thread >= 4) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 1, 4>), grid, block, sh, s, a);      \
+            else if (per_thread >= 2) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 1, 2>), grid, block, sh, s, a); \
+            else hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 1, 1>), grid, block, sh, s, a);                      \
+        } else if (plan.UP == 2) {                                                                    \
+            if (per_thread >= 4) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 2, 4>), grid, block, sh, s, a);      \
+            else hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 2, 2>), grid, block, sh, s, a);                      \
+        } else if (plan.UP <= 4) {                                                                    \
+            if (per_thread >= 4) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 4, 4>), grid, block, sh, s, a);      \
+            else hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 4, 2>), grid, block, sh, s, a);                      \
+        } else {                                                                                      \
+            hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 8, 2>), grid, block, sh, s, a);              \
+        }                                                                                             \
     } while (0)
     if (in_u8) {
         if (data_complex) SFE_RT(true, false, true); else SFE_RT(false, false, true);
@@ -1235,6 +1281,7 @@ int launch_poly_tiled(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int da
         a.win = (unsigned)atoi(e);
         if (a.win > 1u) nwork = (unsigned)((tiles + a.win - 1) / a.win) * a.win;
     }
+    if (const char *e = getenv("SFE_TILED_TLB")) a.tlb_ahead = (unsigned)atoi(e);      // scripts/dec_modes.py tlb
 #endif
     dim3 grid(nwork + (a.hist_out ? 1u : 0u), (unsigned)n_channels), block(256);      // + the history workgroup
     const size_t esz = data_complex ? 8 : 4;
