@@ -465,6 +465,59 @@ def make_rs_leg(ctx, which, log2n, in_fmt="f32", short_proto=False):
     return leg
 
 
+def make_general_rate_leg(ctx, log2n=28, rate=1.77):
+    """the general (non-integer-step) rate at bulk size -- BASELINE cfg3's 381-tap prototype in 3 phases at
+    rate 1.77 (the rate of the reference's own driver, libdsp/test/test_decimate.py:24), 2^28 cf32 in.  The library's default
+    dispatch takes the transform-domain kernel (poly_gen.hip).  Not a BASELINE config: an other_configs row.
+    Parity: the time law makes windows of a later call awkward to restart on the CPU, so the check runs the SAME handle
+    type from a fresh state over the stream's first 2^20 samples and compares ALL of that call's outputs (and their count)
+    with the oracle fed the same samples."""
+    torch, api, lib, synth = ctx["torch"], ctx["api"], ctx["lib"], ctx["synth"]
+    dev, stream, L = ctx["dev"], ctx["stream"], ctx["L"]
+    leg = Leg()
+    leg.name, leg.kind = "general_rate", "rs"
+    n = 1 << log2n
+    taps, U = synth.taps_cfg3(), 3
+    rate = float(np.float32(rate))
+    leg.n, leg.nch, leg.n_gpu = n, 1, n
+    leg.workload = "general-rate resample, rate %.2f (non-integer step %.2f), 381-tap prototype in 3 phases, 2^%d cf32 in" % (rate, rate * U, log2n)
+    leg.key = "resample_rate1p77_cf32_2p%d" % log2n
+    x = torch.empty(n * 2, dtype=torch.float32, device=dev)
+    api.check(L.sfe_dsp_synth_fill(x.data_ptr(), 2 * n, synth.SEED, 0, 0, stream))
+    out_cap = int(n / rate) + 4096
+    leg.x = x
+    leg.y = torch.empty(out_cap * 2, dtype=torch.float32, device=dev)
+    leg.obj = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=True, n_channels=1, device=ctx["local_rank"])
+    leg.kernel = "poly_gen4096_kernel"
+    leg.n_out = 0
+    sp, yp = x.data_ptr(), leg.y.data_ptr()
+
+    def step():
+        leg.n_out = leg.obj.process_stream(sp, n, yp, out_cap, rate, stream=stream)
+    leg.step = step
+    step()
+    leg.bytes_per_launch = 8.0 * n + 8.0 * leg.n_out
+
+    def check(full):
+        from oracle import binding as orc
+        m = 1 << 20
+        r = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=True, n_channels=1, device=ctx["local_rank"])
+        r.set_algo(lib.RS_ALGO_FFT)             # the kernel the timed leg's bulk calls take, also at this size
+        y = torch.empty((int(m / rate) + 64) * 2, dtype=torch.float32, device=dev)
+        k = r.process_stream(sp, m, y.data_ptr(), y.numel() // 2, rate, stream=stream)
+        torch.cuda.synchronize()
+        got, xin = y[: 2 * k].cpu().numpy(), x[: 2 * m].cpu().numpy()
+        worst = 0.0
+        for part in (0, 1):
+            ref, _ = orc.Resample(taps, U, 4096).stream(np.ascontiguousarray(xin[part::2]), rate)
+            if len(ref) != k:
+                return 1.0, 1, k                # a different number of outputs is a failure whatever the values
+            worst = max(worst, synth.rel_rms(got[part::2], ref))
+        return worst, 1, k
+    leg.check = check
+    return leg
+
+
 def group_leg(ctx, taps, total_channels, n_ch, devices, steps, warmup):
     """ONE process, len(devices) devices: the channel partition made inside the library
     (sfe_dsp_fir_group_*, include/sfe_dsp.h) instead of one rank per GPU.  Launches go to every
@@ -746,6 +799,7 @@ def main():
         tr, ti = synth.complex_taps(256, 0.2)
         makers = [lambda: make_rs_leg(ctx, "resample", 28), lambda: make_rs_leg(ctx, "resample", 28, short_proto=True),
                   lambda: make_rs_leg(ctx, "decimate", 30),
+                  lambda: make_general_rate_leg(ctx),
                   lambda: make_fir_leg(ctx, "fir_64ch", synth.taps_cfg2(), 1 << 24, 64),
                   lambda: make_fir_leg(ctx, "fir_64ch_pctaps", synth.taps_per_channel(64), 1 << 24, 64, per_channel=True,
                                        x_share=next(l.x for l in others if l.name == "fir_64ch")),
@@ -778,6 +832,11 @@ def main():
                "frac": leg.bytes_per_launch / (kmean * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if getattr(leg, "variant", None):
             row["variant"] = leg.variant["ran"]
+        if leg.name == "decimate":
+            # this launch runs in one of two modes ~6 % apart that belong to how the process's 8 GiB + 1 GiB buffers
+            # happen to be backed physically, not to the kernel (profiles/r04/decimate_modes_*.txt):
+            # the line says which one this process landed in
+            row["mode"] = "fast (<= 1.53 ms)" if kmean <= 1.53 else "slow (> 1.53 ms: the allocation's physical backing, DESIGN.md 4.2)"
         if world > 1:
             row["scaling"] = "weak"
             row["workload"] += " -- per rank, %d ranks (weak scaling: the per-GPU launch is the same at every N)" % world

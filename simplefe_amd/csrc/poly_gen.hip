@@ -181,6 +181,7 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
         }
     };
     load_tw1();
+    load_tw2();                                  // the sixteen-entry bases stay resident (12 VGPRs); the 256-entry ones are re-read
     const unsigned base_b = hi * LDS_K2_STRIDE + lo, base_c = hi * LDS_K2_STRIDE + lo * LDS_K1_STRIDE;
 
     // ---- 1. forward transform: F1 over n2, F2 over n1, F3 over n0 -> bin k of this thread in X[k]
@@ -193,7 +194,6 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
         else if (k & 3) x = cmul(x, p1[k & 3]);
         lds[t + (unsigned)k * LDS_K2_STRIDE] = x;
     }
-    load_tw2();
     lds_barrier();
     v2f v[16];
 #pragma unroll
@@ -209,6 +209,17 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
         lds[base_b + (unsigned)LDS_K1_STRIDE * k] = x;
     }
     lds_barrier();
+    // the first phase's spectrum: requested here, it lands under the last forward stage; phase j + 1's is requested as soon
+    // as phase j's has been multiplied in (16 loads from L2 per phase that nothing waits for)
+    v2f hn[16];
+    auto load_h = [&](int j) {
+        unsigned tt = t;
+        asm volatile("" : "+v"(tt));
+        const v2f *hs = a.hs + (size_t)j * 16 * 256;
+#pragma unroll
+        for (int k = 0; k < 16; k++) hn[k] = hs[k * 256 + tt];
+    };
+    load_h(0);
     v2f X[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) X[r] = lds[base_c + r];
@@ -223,13 +234,13 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
 #pragma unroll 1
     for (int j = 0; j < U; j++) {
         lds_barrier();                           // (j > 0: every thread is done reading S_{j-1})
-        const v2f *hs = a.hs + (size_t)j * 16 * 256;
 #pragma unroll
-        for (int k = 0; k < 16; k++) v[P16(k)] = cmul(X[P16(k)], hs[k * 256 + t]);
+        for (int k = 0; k < 16; k++) v[P16(k)] = cmul(X[P16(k)], hn[k]);
+        if (j + 1 < U) load_h(j + 1);
+        load_tw1();                              // for this phase's last stage
         dft16_rev<+1>(v);
 #pragma unroll
         for (int k = 0; k < 16; k++) lds[base_c + k] = v[k];
-        load_tw2();
         lds_barrier();
         // I2: over k1
 #pragma unroll
@@ -244,7 +255,6 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
         lds_barrier();
 #pragma unroll
         for (int k = 0; k < 16; k++) lds[base_b + 16u * k] = v[P16(k)];
-        load_tw1();
         lds_barrier();
         // I3: over k2 -> S_j of transform elements t + 256 r, written back to the cells this thread read
 #pragma unroll

@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void poly_rt_kernel(PolyTiledArgs a)
             if (mi >= TMr) continue;
             const long long k = (long long)UP * (m0 + mi);
             if constexpr (CPLX && UPM >= 2) {
-                if (out16 && k + UP <= a.n_out) {
+                if (out16 && k + UP <= a.n_out) {        // UP even here: whole pairs
 #pragma unroll
                     for (int r = 0; r + 1 < UPM; r += 2)
                         if (r < UP) *reinterpret_cast<v4f *>(out + k + r) = (v4f){acc[j][r].x, acc[j][r].y, acc[j][r + 1].x, acc[j][r + 1].y};
@@ -1241,7 +1241,10 @@ static int launch_poly_rt(const PolyTiledPlan &plan, const PolyTiledArgs &a0, in
         } else if (plan.UP == 2) {                                                                    \
             if (per_thread >= 4) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 2, 4>), grid, block, sh, s, a);      \
             else hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 2, 2>), grid, block, sh, s, a);                      \
-        } else if (plan.UP <= 4) {                                                                    \
+        } else if (plan.UP == 3) {                                                                    \
+            if (per_thread >= 4) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 3, 4>), grid, block, sh, s, a);      \
+            else hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 3, 2>), grid, block, sh, s, a);                      \
+        } else if (plan.UP == 4) {                                                                    \
             if (per_thread >= 4) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 4, 4>), grid, block, sh, s, a);      \
             else hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 4, 2>), grid, block, sh, s, a);                      \
         } else {                                                                                      \
