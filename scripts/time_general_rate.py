@@ -13,8 +13,12 @@ x = api.DeviceArray(2 * n); x.fill_synth(synth.SEED)
 cap = int(n / 1.77) + 8192
 y = api.DeviceArray(2 * cap)
 # a short filter (31 taps in 4 phases: 8 per dot product) and BASELINE cfg3's (381 taps in 3 phases: 127 per dot product)
-for name, taps, U, rates in (("31 taps, U = 4", synth.lowpass_taps(31, 0.18, gain=4.0), 4, (1.77, 2.0)),
-                             ("381 taps, U = 3", synth.taps_cfg3(), 3, (1.77,))):
+shapes = (("31 taps, U = 4", synth.lowpass_taps(31, 0.18, gain=4.0), 4, (1.77, 2.0)),
+          ("381 taps, U = 3", synth.taps_cfg3(), 3, (1.77,)))
+if os.environ.get("GENERAL_ONLY"):         # counter passes: the long filter alone (the transform-domain kernel's shape)
+    shapes = shapes[1:]
+timer = api.Timer()
+for name, taps, U, rates in shapes:
   r = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=True)
   print(f"-- {name}")
   for rate in rates:
@@ -28,3 +32,15 @@ for name, taps, U, rates in (("31 taps, U = 4", synth.lowpass_taps(31, 0.18, gai
     api.sync()
     dt = (time.perf_counter() - t0) / 3
     print(f"rate {rate}: 2^{log2n} cf32 in -> {k} out: {dt * 1e3:.2f} ms per call ({n / dt / 1e6:.0f} MS/s)")
+    # ... and what of that is the kernel (HIP events on the launch stream) with each of the two kernels
+    for algo, label in ((lib.RS_ALGO_AUTO, "default dispatch"), (lib.RS_ALGO_DIRECT, "direct form (poly_seg_kernel)")):
+        r.set_algo(algo)
+        r.process_stream(x, n, y, cap, rate)
+        v = []
+        for _ in range(7):
+            timer.start()
+            r.process_stream(x, n, y, cap, rate)
+            timer.stop()
+            v.append(timer.elapsed_ms())
+        print(f"rate {rate}: {label}: HIP events around one call: median {np.median(v):.4f} ms  min {min(v):.4f}  max {max(v):.4f}")
+    r.set_algo(lib.RS_ALGO_AUTO)

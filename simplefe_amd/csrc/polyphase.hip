@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
 // read consecutive cells of one row (conflict-free), every sample read feeds all UP phase sums, taps come
 // through the constant address space (scalar loads: they are wave-uniform).  Accumulation runs tap index
 // ascending from 0.0f (the reference's order, libdsp/decimate.cxx:134-137): EXACT is bit-identical to the
-// compiled reference, the default fuses multiply and add.  UPM = accumulators compiled in (>= UP).
+// compiled reference, the default fuses multiply and add.  UPM = phase sums compiled in (= UP, 1..8).
 // MB: m per thread that run TOGETHER through the tap loop (m, m + 256, ...): one tap row (a scalar load) and one loop
 // step feed MB sample reads and MB x UP multiply-accumulates -- with one m at a time the loop is bound by the latency of
 // the tap load and the LDS read (interpolate x2: 2.38 -> see profiles/r04/shapes.txt).
@@ -1247,6 +1247,12 @@ static int launch_poly_rt(const PolyTiledPlan &plan, const PolyTiledArgs &a0, in
         } else if (plan.UP == 4) {                                                                    \
             if (per_thread >= 4) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 4, 4>), grid, block, sh, s, a);      \
             else hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 4, 2>), grid, block, sh, s, a);                      \
+        } else if (plan.UP == 5) {                                                                    \
+            hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 5, 2>), grid, block, sh, s, a);              \
+        } else if (plan.UP == 6) {                                                                    \
+            hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 6, 2>), grid, block, sh, s, a);              \
+        } else if (plan.UP == 7) {                                                                    \
+            hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 7, 2>), grid, block, sh, s, a);              \
         } else {                                                                                      \
             hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 8, 2>), grid, block, sh, s, a);              \
         }                                                                                             \
