@@ -306,7 +306,7 @@ def make_fir_leg(ctx, name, taps, n, nch, ch0=0, algo="auto", in_fmt="f32", out_
     def step():
         leg.obj.process_stream(sp, yp, n, stream=stream)
     leg.step = step
-    # Stream calls never measure (api.hip: fir_pick_variant is a table look-up; register loads by default).
+    # Stream calls never measure (api_fir.hip: fir_pick_variant is a table look-up; register loads by default).
     # The headline leg asks for the measurement explicitly, untimed, before any warm-up:
     # sfe_dsp_fir_calibrate on rank 0, the choice handed to every rank so that all of them run ONE kernel
     # (independently calibrating ranks were noise in a strong-scaling curve).
@@ -415,7 +415,7 @@ def make_rs_leg(ctx, which, log2n, in_fmt="f32", short_proto=False):
                      data_complex=True, n_channels=1, device=ctx["local_rank"])
     if in_fmt == "u8":
         leg.obj.set_input_format(lib.FMT_U8)
-    # the library picks the transform-domain kernel for long filters on cf32 streams (api.hip: get_fft_plan)
+    # the library picks the transform-domain kernel for long filters on cf32 streams (api_plans.hip: get_fft_plan)
     leg.kernel = "poly_fft256_kernel" if which == "resample" and not short_proto else "poly_tiled_kernel"
     leg.k_before = 0          # outputs produced by all calls before the most recent one
     leg.n_out = 0

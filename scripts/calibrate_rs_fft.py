@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Direct (tiled) vs transform-domain kernel over a grid of shapes: the data behind the selection
-rule in api.hip:get_fft_plan.  2^26 cf32 input samples per shape."""
+rule in api_plans.hip:get_fft_plan.  2^26 cf32 input samples per shape."""
 import os
 import sys
 

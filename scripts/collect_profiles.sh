@@ -40,6 +40,10 @@ cd $R
 bash scripts/prof_pmc.sh prof_${TAG}_sq_fir fir_fft4096 -- python3 $R/bench.py --workload fir --steps 3 --warmup 1 --no-cpu --no-others > /dev/null 2>&1 || exit 1
 bash scripts/prof_pmc.sh prof_${TAG}_sq_decimate poly_tiled -- python3 $R/bench.py --workload decimate --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1 || exit 1
 bash scripts/prof_pmc.sh prof_${TAG}_sq_resample poly_fft256 -- python3 $R/bench.py --workload resample --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1 || exit 1
+# round 4: the general-rate transform-domain kernel (2^28 samples at rate 1.77, 381 taps in 3 phases)
+export LOG2N=28 GENERAL_ONLY=1
+bash scripts/prof_pmc.sh prof_${TAG}_sq_general poly_gen4096 -- python3 $R/scripts/time_general_rate.py > /dev/null 2>&1 || exit 1
+unset LOG2N GENERAL_ONLY
 # COUNTERS_ONLY=1: stop here -- the kernel-trace / counter passes above are what is stamped with the source hash; the tables
 # below are interleaved A/B runs of named variants and stay valid while those variants' code does
 if [ -n "$COUNTERS_ONLY" ]; then echo collected counters; exit 0; fi

@@ -64,9 +64,9 @@ d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_default")
 ks = sorted(glob.glob(d + "/kt/**/*_kernel_stats.csv", recursive=True), key=os.path.getmtime)
 if ks:
     shutil.copy(ks[-1], os.path.join(ROOT, "profiles", tag, "default_line_kernel_stats.csv"))
-for wl in ("fir", "resample", "decimate"):
+for wl in ("fir", "resample", "decimate", "general"):
     f = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_sq_{wl}", "summary.txt")
     if os.path.exists(f):
         shutil.copy(f, os.path.join(ROOT, "profiles", tag, f"{wl}_sq_counters.txt"))
-for f in glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_tables", "*.txt")):
+for f in glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_tables", "*.txt")) + glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_tables", "*.json")):
     shutil.copy(f, os.path.join(ROOT, "profiles", tag, os.path.basename(f)))

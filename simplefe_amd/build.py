@@ -23,7 +23,7 @@ ARCH = "gfx950"
 EXACT_SOURCES = ("polyphase.hip", "util.hip")
 TICKET_SOURCES = ("fir_fft.hip", "poly_fft.hip")
 # host side only (handles, plans, launch choices, device groups): not part of the kernel-source hash
-HOST_SOURCES = ("api.hip", "group.hip")
+HOST_SOURCES = ("api.hip", "api_plans.hip", "api_fir.hip", "api_rs.hip", "api_pipe.hip", "group.hip", "host.h")
 
 
 def sources():
@@ -36,7 +36,7 @@ def _deps():
 
 
 def csrc_hash():
-    """sha256 over the KERNEL sources (csrc/*.hip and csrc/*.h except api.hip, the host side: handles, plans,
+    """sha256 over the KERNEL sources (csrc/*.hip and csrc/*.h except HOST_SOURCES, the host side: handles, plans,
     launch choices -- what the counters count is the kernels' traffic; file names and CODE: `//` comments, blank
     lines and indentation are left out, so that rewording a comment does not orphan a counter pass).
     Stamped into profiles/pmc_*.json when counters are collected; bench.py reports roofline.traffic

@@ -93,7 +93,7 @@ struct FirFftArgs {
 //   WP   DMA into a wave-private exchange layout (two workgroup barriers fewer per transform)
 // Which is fastest differs by a few percent between boxes of one pool (-5.7 % ... +3.7 % for DMA
 // against REG), so the handle measures them on its first large call per device and shape
-// (api.hip: fir_pick_variant) instead of compiling one in.
+// (api_fir.hip: fir_pick_variant) instead of compiling one in.
 enum { FIR_VAR_AUTO = -1, FIR_VAR_REG = 0, FIR_VAR_DMA = 1, FIR_VAR_WP = 2, FIR_VAR_COUNT = 3 };
 // true when the launch described by (a, flags) has more than one data-movement variant
 bool fir_fft_has_variants(const FirFftArgs &a, int in_complex, int out_complex, int in_u8, int out_tx10, int n_channels, int accumulate);

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
     // (lanes 0-31 / 32-63), 128 contiguous cells, pieces 144 apart: 144 = 16 mod 32 keeps the F2
     // reads / I2 writes (two adjacent k2 per 32 lanes) conflict-free exactly as 272 does.
     static_assert(!WP || DMA, "the wave-private layout exists for the LDS-DMA path");
-    // ACC / a.shift (filters longer than one transform can overlap: partitioned convolution, api.hip
+    // ACC / a.shift (filters longer than one transform can overlap: partitioned convolution, api_fir.hip
     // fir_run): this launch applies ONE partition h_p = h[p*hl .. (p+1)*hl) of the taps to the stream
     // delayed by a.shift = p*hl samples and, with ACC, adds its result to what the earlier partitions
     // left in the output.  a.hist_len >= a.hl + a.shift samples of history precede the input.
@@ -1067,7 +1067,7 @@ int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in
     const bool pair = !in_complex && !out_complex;     // real stream, real taps: two segments per transform
     // LDS-DMA moves 16-byte lanes: every channel's first sample must sit on a 16-byte boundary
     const bool dma_ok = (reinterpret_cast<uintptr_t>(a.in) & 15u) == 0 && (n_channels == 1 || (a.in_stride & 1) == 0);
-    // data movement of an aligned cf32 stream: what the caller measured (api.hip: fir_pick_variant), else register loads
+    // data movement of an aligned cf32 stream: what the caller measured (api_fir.hip: fir_pick_variant), else register loads
     const int var = !dma_ok ? FIR_VAR_REG : (a.variant == FIR_VAR_DMA || a.variant == FIR_VAR_WP ? a.variant : FIR_VAR_REG);
 #ifdef SFE_DIAG
     // SFE_FIR_VARIANT = "<waves 2-4><p|n>[s][h]" | "c" | "d" | "e",  SFE_FIR_DIAG = bit 0 no loads, bit 1 no stores,

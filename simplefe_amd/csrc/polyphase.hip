@@ -188,11 +188,13 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
     // (fused-arithmetic instantiations only: the exact-mode kernels -- the class-compatible path, a few thousand samples per
     // call -- are left as they were, two of them sit on a register / scalar-register step that the extra arguments cross)
     unsigned bx = blockIdx.x, nwork = a.tiles;
-    if (a.win > 1u) {                            // `win` windows: see PolyTiledArgs
+#ifdef SFE_DIAG
+    if (a.win > 1u) {                            // `win` windows: see PolyTiledArgs (measured, not kept: DESIGN.md 4.2)
         const unsigned per = (a.tiles + a.win - 1u) / a.win;
         nwork = per * a.win;
         bx = (blockIdx.x % a.win) * per + blockIdx.x / a.win;
     }
+#endif
     if (!EXACT && a.hist_out && blockIdx.x == nwork) {
         T *ho = static_cast<T *>(a.hist_out) + (size_t)ch * a.hl;
 #pragma unroll 1
@@ -206,14 +208,16 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
     const long long m0 = (long long)bx * TM;
     const long long n_org = (long long)SP * m0 + a.e_max - (a.Lp - 1);   // stream index of local sample 0
     const int n_tile = SP * TM + a.Lp;
-    // translation look-ahead (PolyTiledArgs::tlb_ahead): a one-lane read of the first input sample and the first output of the
+    // translation look-ahead (PolyTiledArgs::tlb_ahead; diagnostic library only -- measured 5-6 % slower): a one-lane read of the first input sample and the first output of the
     // tile `tlb_ahead` further on; what it returns is looked at after the tile's own stores, i.e. never waited for early
+#ifdef SFE_DIAG
     float touch = 0.0f;
     if (!IN_U8 && a.tlb_ahead && tid == 0) {
         const long long ni = n_org + (long long)a.tlb_ahead * SP * TM, ko = (long long)UP * (m0 + (long long)a.tlb_ahead * TM);
         if (ni >= 0 && ni < a.n_in) touch = __builtin_nontemporal_load(reinterpret_cast<const float *>(in + ni));
         if (ko < a.n_out) touch += __builtin_nontemporal_load(reinterpret_cast<const float *>(out + ko));
     }
+#endif
     constexpr int MAIN = SP * TM / 256;       // unrolled loads per thread for the body of the tile
 
     // ---- stage: coalesced 8-byte lanes in, transposed into the SP rows
@@ -364,7 +368,9 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
 #pragma unroll
         for (int i = 0; i < UP; i++) __builtin_nontemporal_store(Yp[tid + 256 * i], op + tid + 256 * i);
     }
+#ifdef SFE_DIAG
     if (!IN_U8 && a.tlb_ahead) asm volatile("" ::"v"(touch));      // the look-ahead reads end here
+#endif
 }
 
 // ------------------------------------------- integer-step law, tiled, ANY (SP, UP): launch arguments
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
 // every interpolating ratio -- what `resample` accepts and `decimate` does not, libdsp/resample.cxx:91 against
 // libdsp/decimate.cxx:75-78 -- and decimations such as 6, 7, 16 fell to poly_int_kernel (one output per thread,
 // per-lane tap rows, samples read at stride `step`).  This kernel is the tiled form with SP and UP as
-// ARGUMENTS: the same zero-padded rows G[UP][Lp] (api.hip: fold_rows), the same LDS image -- the tile
+// ARGUMENTS: the same zero-padded rows G[UP][Lp] (api_plans.hip: fold_rows), the same LDS image -- the tile
 // de-interleaved by a runtime SP, X[p][c] = x[n_org + SP c + p], row pitch chosen by the launcher so that the
 // scatter spreads over the banks -- and per thread m = tid, tid + 256, ...: for a fixed tap the lanes of a wave
 // read consecutive cells of one row (conflict-free), every sample read feeds all UP phase sums, taps come
@@ -1160,13 +1166,15 @@ static bool poly_tiled_compiled(int SP, int UP, int Lp)
 
 // ---- poly_rt_kernel's tile: m per workgroup and the LDS row pitch --------------------------------
 constexpr int RT_MAX_SP = 64, RT_MAX_UP = 8, RT_LDS_MAX = 60 * 1024;
-// tm m per tile so that the larger of the input and the output tile is ~4096 samples (a multiple of 64 m, <= 2048)
+// tm m per tile so that the larger of the input and the output tile is ~4096 samples: a power of two of 256 .. 2048 m
+// (a thread then runs 1, 2, 4 or 8 m, whole groups of MB), multiples of 64 below
 static int rt_tile_m(int SP, int UP)
 {
     const int w = SP > UP ? SP : UP;
-    int tm = (4096 / w) / 64 * 64;
-    if (tm < 64) tm = 64;
-    if (tm > 2048) tm = 2048;
+    const int ideal = 4096 / w;
+    if (ideal < 256) return ideal < 64 ? 64 : ideal / 64 * 64;
+    int tm = 256;
+    while (tm < 2048 && tm * 2 * 2 <= ideal * 3) tm *= 2;        // the power of two nearest to `ideal` (ratio below 1.5)
     return tm;
 }
 // row pitch >= tm + Lq: the scatter writes sample s to cell (s % SP) * RL + s / SP; lanes hold consecutive s.
@@ -1248,13 +1256,17 @@ static int launch_poly_rt(const PolyTiledPlan &plan, const PolyTiledArgs &a0, in
             if (per_thread >= 4) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 4, 4>), grid, block, sh, s, a);      \
             else hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 4, 2>), grid, block, sh, s, a);                      \
         } else if (plan.UP == 5) {                                                                    \
-            hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 5, 2>), grid, block, sh, s, a);              \
+            if (per_thread >= 4) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 5, 4>), grid, block, sh, s, a);      \
+            else hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 5, 2>), grid, block, sh, s, a);                      \
         } else if (plan.UP == 6) {                                                                    \
-            hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 6, 2>), grid, block, sh, s, a);              \
+            if (per_thread >= 4) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 6, 4>), grid, block, sh, s, a);      \
+            else hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 6, 2>), grid, block, sh, s, a);                      \
         } else if (plan.UP == 7) {                                                                    \
-            hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 7, 2>), grid, block, sh, s, a);              \
+            if (per_thread >= 4) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 7, 4>), grid, block, sh, s, a);      \
+            else hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 7, 2>), grid, block, sh, s, a);                      \
         } else {                                                                                      \
-            hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 8, 2>), grid, block, sh, s, a);              \
+            if (per_thread >= 4) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 8, 4>), grid, block, sh, s, a);      \
+            else hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 8, 2>), grid, block, sh, s, a);                      \
         }                                                                                             \
     } while (0)
     if (in_u8) {

@@ -1,7 +1,7 @@
 """Capturable streams: ONE *_process_stream call captured into a hipGraph,
 replayed over consecutive chunks of a stream, equals the eager stream bit for bit -- the carried
 state (history; the resamplers' time state) lives on the device or does not move between replays
-(api.hip: stream_is_capturing).  The reference's carried state: libdsp/blkconv.h:56 (m_overlap),
+(api_fir.hip: stream_is_capturing).  The reference's carried state: libdsp/blkconv.h:56 (m_overlap),
 libdsp/resample.h:49-59 (m_history, m_pos, m_mu, m_is_leftover)."""
 import ctypes as C
 

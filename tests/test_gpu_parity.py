@@ -973,7 +973,7 @@ def test_fir_long_filters_partitioned(api, L, n_taps, cplx, nch):
     """blkconv accepts any n_taps that leaves a block (blkconv.cxx:47; the reference's bpsk example
     offers a 551-tap prototype at fft 8192, examples/bpsk/bpsk.cxx:58-63).  Beyond what one
     4096-point transform can overlap usefully the tap vector is cut into partitions, one launch
-    each, accumulated in the output (api.hip fir_choose_partition).  Against the float64
+    each, accumulated in the output (api_fir.hip fir_choose_partition).  Against the float64
     convolution; chunked calls shorter than the carried history exercise the unfused state update."""
     from scipy.signal import fftconvolve
     rng = np.random.default_rng(n_taps)
