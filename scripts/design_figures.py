@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from simplefe_amd.build import fir_kernel_flags  # noqa: E402
 
-tag = next((a for a in sys.argv[1:] if not a.startswith("--")), "r03")
+tag = next((a for a in sys.argv[1:] if not a.startswith("--")), "r04")
 P = os.path.join(ROOT, "profiles", tag)
 ALG = {"fir": 16 * 2 ** 28, "decimate": 9 * 2 ** 30, "resample": 8 * 2 ** 28 + 8 * 161061273}
 
@@ -85,8 +85,8 @@ def _other(j, key):
 def collection_block():
     drv, dfl = _line("bench_driver_shape"), _line("bench_default")
     rows = []
-    keys = {"fir": None, "resample": "381-tap", "decimate": "decimate by 8"}
-    for w, label in (("fir", "256-tap FIR, 2^28 cf32 (`fir_fft4096_kernel`, the variant the process measured as fastest)"),
+    keys = {"fir": None, "resample": "381-tap prototype (127", "decimate": "decimate by 8"}
+    for w, label in (("fir", "256-tap FIR, 2^28 cf32 (`fir_fft4096_kernel`, register loads)"),
                      ("resample", "resample 5/3, 381 taps, 2^28 cf32 (`poly_fft256_kernel`)"),
                      ("decimate", "decimate ÷8, 64 taps, 2^30 cf32 (`poly_tiled_kernel`)")):
         calls, ns = _stats(w)
@@ -103,24 +103,26 @@ def collection_block():
                     f"{f_ms:.4f} ms, `frac` {f_fr:.3f} (`profiles/{tag}/bench_default.json`) | {pmc['hbm_bytes_per_launch'] / 1e9:.2f} GB, "
                     f"+{(pmc['hbm_bytes_per_launch'] / ALG[w] - 1) * 100:.1f} % over algorithmic (`profiles/pmc_{tag}_{w}.json`) |")
     r, c = drv["roofline"], drv["cpu_baseline"]
-    o = {k: _other(drv, k) for k in ("381-tap", "127-tap", "decimate by 8", "complex-tap")}
+    o = {k: _other(drv, k) for k in ("381-tap prototype (127", "127-tap", "decimate by 8", "complex-tap", "general-rate")}
+    o["381-tap"] = o["381-tap prototype (127"]
     ch64 = [x for x in drv["other_configs"] if "64 channel" in x["workload"]][0]
     head = (f"The driver's command shape measured by the builder (`python bench.py --gpus 1 --steps 20 --warmup 5`, `profiles/{tag}/bench_driver_shape.json`): "
             f"**{drv['value']:,.0f} MS/s, `ms_per_step` {drv['ms_per_step']:.3f}, `roofline.frac` {r['frac']:.3f}** (kernel {r['kernel_ms']:.4f} ms mean, "
-            f"{r['kernel_ms_min']:.4f} min, {r['kernel_ms_max']:.4f} max; `traffic` {r['traffic'] / 1e9:.3f} GB; variant: {r['variant']['ran']}), parity "
+            f"{r['kernel_ms_min']:.4f} min, {r['kernel_ms_max']:.4f} max; `traffic` {r['traffic'] / 1e9:.3f} GB; variant: {r['variant']['ran']}, {r['variant'].get('chosen_by', '')}), parity "
             f"{drv['parity']['rel_rms_max']:.1e}; `other_configs`: resample 5/3 {o['381-tap']['ms']:.4f} ms ({o['381-tap']['frac']:.3f}), with the 127-tap prototype "
-            f"{o['127-tap']['ms']:.4f} ms ({o['127-tap']['frac']:.3f}), decimate ÷8 {o['decimate by 8']['ms']:.4f} ms ({o['decimate by 8']['frac']:.3f}), 64 channels × 2^24 "
+            f"{o['127-tap']['ms']:.4f} ms ({o['127-tap']['frac']:.3f}), decimate ÷8 {o['decimate by 8']['ms']:.4f} ms ({o['decimate by 8']['frac']:.3f}; mode: {o['decimate by 8'].get('mode', '?').split(' (')[0]}), "
+            f"general rate 1.77 {o['general-rate']['ms']:.4f} ms ({o['general-rate']['frac']:.3f}), 64 channels × 2^24 "
             f"{ch64['ms']:.2f} ms ({ch64['frac']:.3f}), complex taps {o['complex-tap']['ms']:.4f} ms ({o['complex-tap']['frac']:.3f}), every parity check green; "
             f"`cpu_baseline` {c['value']:.0f} MS/s on one thread, {c['all_cores']['value']:.0f} MS/s on the box's {c['host_cores']} host cores"
             + (f", BASELINE configs[0] (CPU only) {c['configs0_cpu_only']['value']:.0f} real MS/s" if "configs0_cpu_only" in c else "") + ".")
     head = head.replace(f"{drv['value']:,.0f}", f"{drv['value']:,.0f}".replace(",", " ")).replace(f"{r['traffic'] / 1e9:.3f} GB", f"{r['traffic'] / 1e9:.2f} GB")
     earlier = []
-    for f in sorted(os.listdir(os.path.join(P, "earlier"))):
+    for f in (sorted(os.listdir(os.path.join(P, "earlier"))) if os.path.isdir(os.path.join(P, "earlier")) else []):
         if f.endswith("bench_driver_shape.json"):
             j = json.loads(open(os.path.join(P, "earlier", f)).read().strip().splitlines()[-1])
             earlier.append(f"`{f.split('_')[0]}` {j['value']:,.0f} MS/s / {j['roofline']['frac']:.3f}".replace(",", " "))
     tail = ("Earlier collections of the round, other boxes of the pool, same product kernels (`profiles/" + tag + "/earlier/`, driver shape, MS/s / `frac`): "
-            + ", ".join(earlier) + ".")
+            + ", ".join(earlier) + ".") if earlier else ""
     table = ("| kernel | under rocprofv3 (`bench.py --workload … --no-others --no-cpu`) | un-profiled, driver-shape line | un-profiled, default line | PMC traffic |\n"
              "|---|---|---|---|---|\n" + "\n".join(rows))
     return head + "\n\n" + table + "\n\n" + tail
