@@ -133,5 +133,6 @@ if "--write" in sys.argv:
     text = open(path).read()
     b, e = "<!-- collection:begin -->", "<!-- collection:end -->"
     i, j = text.index(b) + len(b), text.index(e)
-    open(path, "w").write(text[:i] + "\n" + collection_block() + "\n" + text[j:])
+    block = collection_block()                  # may raise: nothing has been opened for writing yet
+    open(path, "w").write(text[:i] + "\n" + block + "\n" + text[j:])
     print("DESIGN.md: collection block rewritten")
