@@ -317,11 +317,18 @@ int sfe_dsp_rs_process(sfe_rs_t h, const float *in, int n_in, float *out, int ou
 int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t in_stride,
                               void *d_out, size_t out_cap, size_t out_stride, float rate,
                               size_t *n_out, sfe_stream_t stream);
-/* Which kernel the integer-step bulk path (fused numerics) takes.  AUTO: the calibrated rule of
- * DESIGN.md 4.2c (transform-domain kernel for long filters on long calls, else the tiled direct
- * kernel).  DIRECT: never the transform-domain kernel.  FFT: the transform-domain kernel wherever
- * the shape is instantiated.  MFMA: the f32 matrix-pipe form of the direct kernel (measured slower,
- * kept as evidence: DESIGN.md 4.2b).  The library reads no environment variable. */
+/* Which kernel the bulk path (fused numerics) takes.  Integer-valued steps -- AUTO: the calibrated
+ * rule of DESIGN.md 4.2c (transform-domain kernel for long filters on long calls, else a tiled direct
+ * kernel: a compile-time (inputs, outputs)-per-period instantiation or, for any other ratio up to
+ * 64 : 8, the runtime-shape one).  DIRECT: never a transform-domain kernel.  FFT: the
+ * transform-domain kernel wherever the shape is instantiated.  MFMA: the f32 matrix-pipe form of the
+ * direct kernel (measured slower, kept as evidence: DESIGN.md 4.2b).
+ * Any other step (the general rate) -- AUTO: complex float32 calls of >= 65536 samples at rate >= 1
+ * with >= 12 taps per phase take the 4096-point transform kernel (all phases of every
+ * input sample by one forward and `upsample` inverse transforms, blended by the reference's own
+ * (pos, mu) sequence); FFT: at any size; DIRECT, the exact mode, real or u8 streams and rate < 1: the
+ * direct kernel.  The number of outputs per call is the reference's in every case.
+ * The library reads no environment variable. */
 #define SFE_RS_ALGO_AUTO    0
 #define SFE_RS_ALGO_DIRECT  1
 #define SFE_RS_ALGO_FFT     2

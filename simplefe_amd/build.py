@@ -31,7 +31,7 @@ def sources():
 
 
 def _deps():
-    return sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(
+    return sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "diag", "*.inc")) + glob.glob(
         os.path.join(os.path.dirname(HERE), "include", "*.h"))
 
 
@@ -135,7 +135,7 @@ def build_lib(force=False, verbose=False, extra=(), diag=False):
         obj = os.path.join(odir, os.path.basename(src) + ".o")
         objs.append(obj)
         if (not force and os.path.exists(obj) and
-                os.path.getmtime(obj) > max(os.path.getmtime(p) for p in [src] + glob.glob(os.path.join(CSRC, "*.h"))
+                os.path.getmtime(obj) > max(os.path.getmtime(p) for p in [src] + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "diag", "*.inc"))
                                             + glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h")))):
             continue
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,

@@ -726,309 +726,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 
 
 #ifdef SFE_DIAG
-// Diagnostic only (SFE_FIR_VARIANT=c): the kernel's global access pattern with no transform --
-// each workgroup loads its 16 rows and stores rows row0..15 unchanged.  Times the memory side
-// of the FIR kernel alone (results are NOT a filter output; never used by the product path).
-template <int WAVES>
-__global__ __launch_bounds__(256, WAVES) void fir_copy_pattern_kernel(FirFftArgs a)
-{
-    const unsigned t = threadIdx.x;
-    const char *in_c = static_cast<const char *>(a.in) + (size_t)blockIdx.y * a.in_stride * 8;
-    char *out_c = static_cast<char *>(a.out) + (size_t)blockIdx.y * a.out_stride * 8;
-    const int row0 = a.hl >> 8;
-    for (long long blk = blockIdx.x; blk < a.nblk; blk += gridDim.x) {
-        const long long base = blk * a.advance - a.hl;
-        if (base < 0 || base + FFT_N > a.n) continue;
-        v2f v[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) v[r] = load_sample<true>(in_c + (base + 256 * r) * 8, t);
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-            if (r >= row0) reinterpret_cast<v2f *>(out_c + (base + 256 * r) * 8)[t] = v[r];
-    }
-}
-
-
-// Diagnostic only (SFE_FIR_VARIANT=d / e): same bytes as fir_copy_pattern_kernel moved with
-// 16-byte lanes (d) and with nontemporal 8-byte lanes (e).
-template <int WAVES>
-__global__ __launch_bounds__(256, WAVES) void fir_copy_pattern16_kernel(FirFftArgs a)
-{
-    const unsigned t = threadIdx.x;
-    const char *in_c = static_cast<const char *>(a.in) + (size_t)blockIdx.y * a.in_stride * 8;
-    char *out_c = static_cast<char *>(a.out) + (size_t)blockIdx.y * a.out_stride * 8;
-    const int row0 = a.hl >> 8;
-    const unsigned half = t >> 7, col2 = t & 127;
-    for (long long blk = blockIdx.x; blk < a.nblk; blk += gridDim.x) {
-        const long long base = blk * a.advance - a.hl;
-        if (base < 0 || base + FFT_N > a.n) continue;
-        v4f v[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            v[j] = reinterpret_cast<const v4f *>(in_c + (base + 256 * (2 * j)) * 8)[col2 + 128 * half];
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            if (2 * j + (int)half >= row0)
-                reinterpret_cast<v4f *>(out_c + (base + 256 * (2 * j)) * 8)[col2 + 128 * half] = v[j];
-    }
-}
-
-// SFE_FIR_TRACE=<file>: per workgroup of the e / E pattern kernels {start, end (100 MHz ticks), transforms
-// done, XCC_ID, HW_ID} -- where and when the launch's work was done (scripts/probes/fir_trace.py)
-#define FIR_TRACE_WGS 163840
-__device__ unsigned long long g_fir_trace[5 * FIR_TRACE_WGS];
-__device__ unsigned long long g_fir_tdone[FIR_TRACE_WGS];
-__device__ unsigned long long g_fir_tclk[FIR_TRACE_WGS];        // the same instant on the shader clock (s_memtime)
-__device__ int g_fir_gate;         // SFE_FIR_GATE=k: loads only while bit k of the 100 MHz device clock is 0, stores while it is 1
-__device__ int g_fir_order;        // SFE_FIR_ORDER: 0 in address order, 1 reversed, 2 scattered (x 48271 mod the count)       // per transform: when its rows had landed and its stores were issued
-
-template <int WAVES, bool TICKET, bool BAR = false, bool TRACE = false>
-__global__ __launch_bounds__(256, WAVES) void fir_copy_pattern_nt_kernel(FirFftArgs a)
-{
-    __shared__ unsigned s_next;
-    const unsigned t = threadIdx.x;
-    const unsigned long long t_start = TRACE ? wall_clock64() : 0ull;
-    const int gate = TRACE ? g_fir_gate : 0;          // the gate and the order switch exist in the traced build only
-    const int order = TRACE ? g_fir_order : 0;
-    unsigned n_done = 0;
-    const unsigned wg_lin = blockIdx.x + blockIdx.y * gridDim.x;
-    auto leave = [&]() {
-        if (TRACE && t == 0 && wg_lin < FIR_TRACE_WGS) {
-            unsigned long long *r = g_fir_trace + 5ull * wg_lin;
-            r[0] = t_start; r[1] = wall_clock64(); r[2] = n_done;
-            r[3] = __builtin_amdgcn_s_getreg(20 | (3 << 11));      // XCC_ID[3:0]
-            r[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));      // HW_ID
-        }
-    };
-    const int row0 = a.hl >> 8;
-    const unsigned nblk32 = (unsigned)a.nblk;
-    // (one address serves an atomic every ~13 ns -- 70 000 draws from ONE counter take as long as the
-    // whole launch -- so the workgroups are dealt into a.tgroups groups, group g drawing the
-    // transforms g, g + tgroups, ... from its own counter, 128 bytes apart)
-    const unsigned tg = a.tgroups, grp = blockIdx.x % tg;
-    unsigned *const my_ticket = a.ticket + 32u * grp;
-    const unsigned last_draw = (a.total > grp ? (a.total - grp + tg - 1u) / tg : 0u) + (gridDim.x - grp + tg - 1u) / tg - 1u;
-    auto draw = [&]() -> unsigned {
-        const unsigned c = __hip_atomic_fetch_add(my_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (c == last_draw) __hip_atomic_store(my_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long k = (unsigned long long)c * tg + grp;
-        return k < a.total ? (unsigned)k : 0xFFFFFFFFu;
-    };
-    unsigned kt = 0;
-    long long blk = blockIdx.x;
-    int ch = TICKET ? 0 : blockIdx.y;
-    if (TICKET) {
-        if (t == 0) s_next = draw();
-        lds_barrier();
-        kt = __builtin_amdgcn_readfirstlane(s_next);
-        lds_barrier();
-    }
-    for (;;) {
-        if (TICKET) {
-            if (kt >= a.total) break;
-            ch = (int)(kt / nblk32);
-            blk = kt - (unsigned)ch * nblk32;
-        } else if (blk >= a.nblk) break;
-        const char *in_c = static_cast<const char *>(a.in) + (size_t)ch * a.in_stride * 8;
-        char *out_c = static_cast<char *>(a.out) + (size_t)ch * a.out_stride * 8;
-        long long pblk = blk;
-        if (order == 1) pblk = a.nblk - 1 - blk;
-        else if (order == 2) pblk = (long long)(((unsigned long long)blk * 48271ull) % (unsigned long long)a.nblk);
-        const long long base = pblk * a.advance - a.hl;
-        unsigned drawn = 0;
-        if (TICKET && t == 0) drawn = draw();
-        if (base >= 0 && base + FFT_N <= a.n) {
-            v2f v[16];
-            if (gate) while (((wall_clock64() >> gate) & 1ull) != 0ull) __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                v[r] = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(in_c + (base + 256 * r) * 8) + t);
-            if (BAR) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_barrier(); lds_barrier(); }
-            if (gate) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                while (((wall_clock64() >> gate) & 1ull) != 1ull) __builtin_amdgcn_s_sleep(1);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                if (r >= row0) __builtin_nontemporal_store(v[r], reinterpret_cast<v2f *>(out_c + (base + 256 * r) * 8) + t);
-            if (TRACE && t == 0 && v[15].x != 1.2345e38f) {
-                const unsigned long long lin = (unsigned long long)ch * nblk32 + (unsigned long long)blk;
-                if (lin < FIR_TRACE_WGS) { g_fir_tdone[lin] = wall_clock64(); g_fir_tclk[lin] = clock64(); }
-            }
-        }
-        n_done++;
-        if (TICKET) {
-            if (t == 0) s_next = drawn;
-            lds_barrier();
-            kt = __builtin_amdgcn_readfirstlane(s_next);
-            lds_barrier();
-        } else blk += gridDim.x;
-    }
-    leave();
-}
-
-// Diagnostic only (SFE_FIR_VARIANT=p): the 8-byte nontemporal pattern, software-pipelined -- the next
-// transform's 16 loads are issued BEFORE this transform's 15 stores, so no load is ever waited for
-// behind an older store of the same wave (vmcnt retires in issue order).
-template <int WAVES>
-__global__ __launch_bounds__(256, WAVES) void fir_copy_pattern_pipe_kernel(FirFftArgs a)
-{
-    const unsigned t = threadIdx.x;
-    const char *in_c = static_cast<const char *>(a.in) + (size_t)blockIdx.y * a.in_stride * 8;
-    char *out_c = static_cast<char *>(a.out) + (size_t)blockIdx.y * a.out_stride * 8;
-    const int row0 = a.hl >> 8;
-    // interior transforms only, walked at a fixed stride; ping-pong register sets (no copies: a copy
-    // would make the compiler wait for the loads it has just issued)
-    auto ok = [&](long long blk) { const long long b = blk * a.advance - a.hl; return blk < a.nblk && b >= 0 && b + FFT_N <= a.n; };
-    auto load = [&](v2f (&x)[16], long long blk) {
-        const long long base = blk * a.advance - a.hl;
-#pragma unroll
-        for (int r = 0; r < 16; r++) x[r] = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(in_c + (base + 256 * r) * 8) + t);
-    };
-    auto store = [&](const v2f (&x)[16], long long blk) {
-        const long long base = blk * a.advance - a.hl;
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-            if (r >= row0) __builtin_nontemporal_store(x[r], reinterpret_cast<v2f *>(out_c + (base + 256 * r) * 8) + t);
-    };
-    long long blk = blockIdx.x + gridDim.x;            // skip transform 0 (history) and stay interior
-    const long long step = gridDim.x;
-    if (!ok(blk)) return;
-    v2f A[16], B[16];
-    load(A, blk);
-    for (;;) {
-        const long long b1 = blk + step;
-        const bool more1 = ok(b1);
-        if (more1) load(B, b1);
-        store(A, blk);
-        if (!more1) break;
-        const long long b2 = b1 + step;
-        const bool more2 = ok(b2);
-        if (more2) load(A, b2);
-        store(B, b1);
-        if (!more2) break;
-        blk = b2;
-    }
-}
-
-// Diagnostic only (SFE_FIR_VARIANT=g): the access pattern of the LDS-DMA variant -- rows requested by
-// global_load_lds_dwordx4 into the padded layout, picked up column-wise, stored with nontemporal
-// 8-byte lanes; the next transform's request goes out before this one's stores.
-template <int WAVES, bool NT>
-__global__ __launch_bounds__(256, WAVES) void fir_copy_pattern_dma_kernel(FirFftArgs a)
-{
-    __shared__ v2f lds[FFT_ROWS * LDS_K2_STRIDE];
-    const unsigned t = threadIdx.x;
-    const char *in_c = static_cast<const char *>(a.in) + (size_t)blockIdx.y * a.in_stride * 8;
-    char *out_c = static_cast<char *>(a.out) + (size_t)blockIdx.y * a.out_stride * 8;
-    const int row0 = a.hl >> 8;
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) v2f *)lds;
-    const unsigned wv = __builtin_amdgcn_readfirstlane(t >> 6), lane16 = (t & 63u) * 16u;
-    auto ok = [&](long long blk) { const long long b = blk * a.advance - a.hl; return blk < a.nblk && b >= 0 && b + FFT_N <= a.n; };
-    auto dma_rows = [&](long long blk) {
-        const char *g = in_c + (blk * a.advance - a.hl) * 8;
-#pragma unroll
-        for (int p = 0; p < 8; p++) {
-            const unsigned row = 4u * wv + (p >> 1), half = p & 1;
-            const unsigned dst = lds_base + (row * LDS_K2_STRIDE + half * 128u) * 8u;
-            const unsigned off = (row * 256u + half * 128u) * 8u + lane16;
-            unsigned keep;
-            if constexpr (NT)
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(off), "s"(g), "s"(dst) : "memory");
-            else
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(off), "s"(g), "s"(dst) : "memory");
-        }
-    };
-    long long blk = blockIdx.x;
-    while (blk < a.nblk && !ok(blk)) blk += gridDim.x;
-    if (blk < a.nblk) dma_rows(blk);
-    bool first = true;
-    while (blk < a.nblk) {
-        // as the product kernel: the pieces are older than the previous transform's 15 stores
-        if (first || row0 != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-        first = false;
-        lds_barrier();
-        v2f v[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) v[r] = lds[t + r * LDS_K2_STRIDE];
-        lds_barrier();
-        long long nb = blk + gridDim.x;
-        while (nb < a.nblk && !ok(nb)) nb += gridDim.x;
-        if (nb < a.nblk) dma_rows(nb);
-        const long long base = blk * a.advance - a.hl;
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-            if (r >= row0) __builtin_nontemporal_store(v[r], reinterpret_cast<v2f *>(out_c + (base + 256 * r) * 8) + t);
-        blk = nb;
-    }
-}
-// Diagnostic only (SFE_FIR_VARIANT=q / Q): the LDS-DMA pattern with TWO landing areas: the
-// rows of transform i+1 are requested before transform i's are even waited for, so no wave ever waits for a load
-// that was not issued a whole transform earlier.  64 KiB of LDS per workgroup: two per CU.  DELAY: SFE_FIR_DELAY
-// microsecond-ish idle steps between pick-up and stores stand in for the transform's on-chip time (g takes it too).
-__device__ int g_fir_delay;
-template <int WAVES, bool DOUBLE>
-__global__ __launch_bounds__(256, WAVES) void fir_copy_pattern_dma2_kernel(FirFftArgs a)
-{
-    __shared__ v2f lds[(DOUBLE ? 2 : 1) * FFT_N];
-    const unsigned t = threadIdx.x;
-    const char *in_c = static_cast<const char *>(a.in) + (size_t)blockIdx.y * a.in_stride * 8;
-    char *out_c = static_cast<char *>(a.out) + (size_t)blockIdx.y * a.out_stride * 8;
-    const int row0 = a.hl >> 8;
-    const int delay = g_fir_delay;
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) v2f *)lds;
-    const unsigned wv = __builtin_amdgcn_readfirstlane(t >> 6), lane16 = (t & 63u) * 16u;
-    auto ok = [&](long long blk) { const long long b = blk * a.advance - a.hl; return blk < a.nblk && b >= 0 && b + FFT_N <= a.n; };
-    auto dma_rows = [&](long long blk, unsigned area) {
-        const char *g = in_c + (blk * a.advance - a.hl) * 8;
-#pragma unroll
-        for (int p = 0; p < 8; p++) {
-            const unsigned row = 4u * wv + (p >> 1), half = p & 1;
-            const unsigned dst = lds_base + (area * FFT_N + row * 256u + half * 128u) * 8u;
-            const unsigned off = (row * 256u + half * 128u) * 8u + lane16;
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(off), "s"(g), "s"(dst) : "memory");
-        }
-    };
-    auto next_of = [&](long long blk) { long long nb = blk + gridDim.x; while (nb < a.nblk && !ok(nb)) nb += gridDim.x; return nb; };
-    long long blk = blockIdx.x;
-    while (blk < a.nblk && !ok(blk)) blk += gridDim.x;
-    if (blk < a.nblk) dma_rows(blk, 0);
-    unsigned cur = 0;
-    bool first = true;
-    while (blk < a.nblk) {
-        const long long nb = next_of(blk);
-        if constexpr (DOUBLE) {
-            // request i+1 FIRST; then i's eight pieces are older than (15 stores of i-1 +) the 8 just issued
-            if (nb < a.nblk) {
-                dma_rows(nb, cur ^ 1u);
-                if (first || row0 != 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(23)" ::: "memory");
-            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            if (first || row0 != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-        }
-        first = false;
-        lds_barrier();
-        v2f v[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) v[r] = lds[(DOUBLE ? cur * FFT_N : 0u) + t + r * 256u];
-        lds_barrier();
-        if constexpr (!DOUBLE) { if (nb < a.nblk) dma_rows(nb, 0); }
-        for (int d = 0; d < delay; d++) __builtin_amdgcn_s_sleep(32);
-        const long long base = blk * a.advance - a.hl;
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-            if (r >= row0) __builtin_nontemporal_store(v[r], reinterpret_cast<v2f *>(out_c + (base + 256 * r) * 8) + t);
-        blk = nb;
-        cur ^= 1u;
-    }
-}
+#include "diag/fir_fft_diag.inc"
 #endif  // SFE_DIAG
 
 }  // namespace
@@ -1112,96 +810,7 @@ int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in
 #define SFE_K2(...) hipLaunchKernelGGL((fir_fft4096_kernel<__VA_ARGS__>), grid2, block, 0, s, a)
 #endif
 #ifdef SFE_DIAG
-    if (ev && in_complex && out_complex && !in_u8 && !out_tx10) {
-        // round-1 kernels: fixed-stride walk, register loads  <waves><p|n>[s][h]
-#define SFE_STATIC(W, PF, SW, HR, DG) SFE_K2(true, true, W, PF, SW, HR, false, false, false, false, DG, false)
-        // D = LDS-DMA + fixed stride, T = tickets + register loads, X = tickets + LDS-DMA, W = X + wave-private layout
-#define SFE_NEW(DM, TK, DG, WPV) do { if (TK) SFE_K(true, true, 4, false, false, true, false, false, false, DM, DG, TK, false, WPV); \
-                                 else SFE_K2(true, true, 4, false, false, true, false, false, false, DM, DG, TK, false, WPV); } while (0)
-#define SFE_NEW_DG(DM, TK, WPV) do { if (diag == 1) SFE_NEW(DM, TK, 1, WPV); else if (diag == 2) SFE_NEW(DM, TK, 2, WPV); \
-                                else if (diag == 3) SFE_NEW(DM, TK, 3, WPV); else SFE_NEW(DM, TK, 0, WPV); } while (0)
-        bool done = true;
-        // SFE_FIR_TRACE / _ORDER / _GATE select the instrumented build of the e / E pattern (its clock reads cost time:
-        // A/B timings use the plain one)
-        const bool traced = (ev[0] == 'e' || ev[0] == 'E') && (getenv("SFE_FIR_TRACE") || getenv("SFE_FIR_ORDER") || getenv("SFE_FIR_GATE"));
-        if (traced) {
-            const int order = getenv("SFE_FIR_ORDER") ? atoi(getenv("SFE_FIR_ORDER")) : 0;
-            SFE_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_fir_order), &order, sizeof order, 0, hipMemcpyHostToDevice, s));
-            const int gate = getenv("SFE_FIR_GATE") ? atoi(getenv("SFE_FIR_GATE")) : 0;
-            SFE_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_fir_gate), &gate, sizeof gate, 0, hipMemcpyHostToDevice, s));
-        }
-        if (ev[0] == 'c') hipLaunchKernelGGL((fir_copy_pattern_kernel<4>), grid2, block, 0, s, a);
-        else if (ev[0] == 'd') hipLaunchKernelGGL((fir_copy_pattern16_kernel<4>), grid2, block, 0, s, a);
-        else if (ev[0] == 'e' && traced) hipLaunchKernelGGL((fir_copy_pattern_nt_kernel<4, false, false, true>), grid2, block, 0, s, a);
-        else if (ev[0] == 'E' && traced) hipLaunchKernelGGL((fir_copy_pattern_nt_kernel<4, true, false, true>), grid, block, 0, s, a);
-        else if (ev[0] == 'e') hipLaunchKernelGGL((fir_copy_pattern_nt_kernel<4, false>), grid2, block, 0, s, a);
-        else if (ev[0] == 'E') hipLaunchKernelGGL((fir_copy_pattern_nt_kernel<4, true>), grid, block, 0, s, a);
-        else if (ev[0] == 'b') hipLaunchKernelGGL((fir_copy_pattern_nt_kernel<4, false, true>), grid2, block, 0, s, a);
-        else if (ev[0] == 'g') hipLaunchKernelGGL((fir_copy_pattern_dma_kernel<4, true>), grid2, block, 0, s, a);
-        else if (ev[0] == 'G') hipLaunchKernelGGL((fir_copy_pattern_dma_kernel<4, false>), grid2, block, 0, s, a);
-        else if (ev[0] == 'q' || ev[0] == 'Q') {
-            const int delay = getenv("SFE_FIR_DELAY") ? atoi(getenv("SFE_FIR_DELAY")) : 0;
-            SFE_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_fir_delay), &delay, sizeof delay, 0, hipMemcpyHostToDevice, s));
-            if (ev[0] == 'q') hipLaunchKernelGGL((fir_copy_pattern_dma2_kernel<2, true>), grid2, block, 0, s, a);
-            else hipLaunchKernelGGL((fir_copy_pattern_dma2_kernel<4, false>), grid2, block, 0, s, a);
-        }
-        else if (ev[0] == 'p') hipLaunchKernelGGL((fir_copy_pattern_pipe_kernel<4>), grid2, block, 0, s, a);
-        else if (ev[0] == 'D') SFE_NEW_DG(true, false, false);
-        else if (ev[0] == 'T') SFE_NEW_DG(false, true, false);
-        else if (ev[0] == 'X') SFE_NEW_DG(true, true, false);
-        else if (ev[0] == 'W') SFE_NEW_DG(true, true, true);           // + wave-private first/last layout
-        else if (ev[0] == 'y') SFE_NEW(true, true, 8, false);          // X, a row's store issued as soon as its butterfly is done (spills)
-        else if (ev[0] == 'u') SFE_NEW(false, true, 8, false);         // T, likewise
-        else if (ev[0] == 'x') SFE_NEW(true, true, 4, false);          // X with the round-2 guarded store loop
-        else if (ev[0] == 't') SFE_NEW(false, true, 4, false);         // T with the round-2 guarded store loop
-        else if (ev[0] == 'w') SFE_NEW(true, true, 4, true);           // W with the round-2 guarded store loop
-        else if (ev[0] == '4' && diag) {                                                           // ablations of "4n.h"
-            if (diag == 1) SFE_STATIC(4, false, false, true, 1);
-            else if (diag == 2) SFE_STATIC(4, false, false, true, 2);
-            else SFE_STATIC(4, false, false, true, 3);
-        } else if (ev[0] >= '2' && ev[0] <= '4') {
-            const int w = ev[0] - '0', pf = ev[1] == 'p', sw = ev[1] && ev[2] == 's';
-            const int hr = (ev[1] && ev[2] == 'h') || (ev[1] && ev[2] && ev[3] == 'h');
-            switch (w * 8 + pf * 4 + sw * 2 + hr) {
-            case 3 * 8 + 0: SFE_STATIC(3, false, false, false, 0); break;
-            case 3 * 8 + 1: SFE_STATIC(3, false, false, true, 0); break;
-            case 3 * 8 + 3: SFE_STATIC(3, false, true, true, 0); break;
-            case 3 * 8 + 4: SFE_STATIC(3, true, false, false, 0); break;
-            case 3 * 8 + 5: SFE_STATIC(3, true, false, true, 0); break;
-            case 4 * 8 + 0: SFE_STATIC(4, false, false, false, 0); break;
-            case 4 * 8 + 3: SFE_STATIC(4, false, true, true, 0); break;
-            default: SFE_STATIC(4, false, false, true, 0); break;
-            }
-        } else done = false;
-#undef SFE_STATIC
-#undef SFE_NEW
-#undef SFE_NEW_DG
-        if (done) {
-            SFE_HIP(hipGetLastError());
-            if (const char *tp = getenv("SFE_FIR_TRACE")) {          // e / E only: dump the per-workgroup trace of THIS launch
-                if (traced) {
-                    const size_t nwg = (ev[0] == 'E' ? (size_t)grid.x : (size_t)grid2.x * grid2.y);
-                    const size_t cnt = 5 * (nwg < FIR_TRACE_WGS ? nwg : FIR_TRACE_WGS);
-                    unsigned long long *h = (unsigned long long *)malloc(cnt * 8);
-                    SFE_HIP(hipStreamSynchronize(s));
-                    SFE_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fir_trace), cnt * 8));
-                    if (FILE *f = fopen(tp, "wb")) { fwrite(h, 8, cnt, f); fclose(f); }
-                    free(h);
-                    const size_t nt = a.total < FIR_TRACE_WGS ? a.total : FIR_TRACE_WGS;
-                    h = (unsigned long long *)malloc(nt * 8);
-                    SFE_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fir_tdone), nt * 8));
-                    char tp2[512];
-                    snprintf(tp2, sizeof tp2, "%s.done", tp);
-                    if (FILE *f = fopen(tp2, "wb")) { fwrite(h, 8, nt, f); fclose(f); }
-                    SFE_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fir_tclk), nt * 8));
-                    snprintf(tp2, sizeof tp2, "%s.clk", tp);
-                    if (FILE *f = fopen(tp2, "wb")) { fwrite(h, 8, nt, f); fclose(f); }
-                    free(h);
-                }
-            }
-            return SFE_OK;
-        }
-    }
+#include "diag/fir_fft_launch_diag.inc"
 #endif
     //       IN_C   OUT_C  WAVES PREFETCH SWZ  HREG  IN_U8  PAIR   OUT_TX10 DMA DIAG TICKET ACC
     if (a.hs_stride) {          // per-channel taps: the channel's spectrum is reloaded into registers on a channel change (cf32 streams only)

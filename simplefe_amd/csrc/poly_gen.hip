@@ -132,7 +132,12 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
     const int Ta = ka_hi - ka_lo, T = Ta + (kb_hi - kb_lo);        // T <= 256 KPT (launcher)
     const long long k_first = Ta > 0 || c1 == c0 ? ca.k_first + ka_lo : cb.k_first + kb_lo;   // the block's outputs are consecutive
 
-    // tab_pos: position inside the block, P - Plo (< U A); 0xFFFFFFFF: no output
+    // tab_pos: where the output's first phase sample sits, (transform element << 8) | phase; 0xFFFFFFFF: no output.
+    // A thread's outputs k, k + 256, ... lie ~4 runs apart: the run of the first one is found by binary search, the
+    // next ones by walking on from it (a fresh search per output was a sixth of the kernel's vector instructions).
+    const unsigned Uu = (unsigned)U, Minv = Uu > 1u ? 0xFFFFFFFFu / Uu + 1u : 0u;      // floor(x / U) = mulhi(x, Minv), x < U A
+    const unsigned e0 = (unsigned)a.ovl - 1u;    // transform element of the block's first owned input sample
+    int la = -1, lb = -1;                        // run of this thread's previous output in call a / call b
 #pragma unroll 1
     for (int q = 0; q < KPT; q++) {
         const int idx = (int)t + 256 * q;
@@ -143,16 +148,25 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
             const RunLds *rs = second ? rb : ra;
             const int ns = second ? nb : na;
             const int kk = second ? kb_lo + (idx - Ta) : ka_lo + idx;
-            int l = 0, h = ns;                   // first run with k0 + count > kk
-            while (l < h) {
-                const int m = (l + h) >> 1;
-                if (rs[m].k0 + rs[m].count <= kk) l = m + 1; else h = m;
+            int l = second ? lb : la;
+            if (l < 0) {                         // first run with k0 + count > kk
+                int h = ns;
+                l = 0;
+                while (l < h) {
+                    const int m = (l + h) >> 1;
+                    if (rs[m].k0 + rs[m].count <= kk) l = m + 1; else h = m;
+                }
+            } else {
+                while (rs[l].k0 + rs[l].count <= kk) l++;
             }
+            if (second) lb = l; else la = l;
             const RunLds g = rs[l];
             const double tt = g.t0 + (double)(kk - g.k0) * (double)g.d;      // exact (timelaw.h)
             const double fl = floor(tt);
             mu_q = (float)(tt - fl);
-            pl_q = (unsigned)((second ? offb : offa) + (long long)fl - Plo);
+            const unsigned pl = (unsigned)((second ? offb : offa) + (long long)fl - Plo);      // position inside the block, < U A
+            const unsigned n = Uu > 1u ? __umulhi(pl, Minv) : pl;
+            pl_q = ((e0 + n) << 8) | (pl - n * Uu);
         }
         tab_pos[256 * q + t] = pl_q;
         tab_mu[256 * q + t] = mu_q;
@@ -229,8 +243,6 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
     v2f acc[KPT];
 #pragma unroll
     for (int q = 0; q < KPT; q++) acc[q] = (v2f){0.0f, 0.0f};
-    const unsigned Uu = (unsigned)U, Minv = Uu > 1u ? 0xFFFFFFFFu / Uu + 1u : 0u;      // floor(x / U) = mulhi(x, Minv), x < U A
-    const unsigned e0 = (unsigned)a.ovl - 1u;    // transform element of the block's first owned input sample
 #pragma unroll 1
     for (int j = 0; j < U; j++) {
         lds_barrier();                           // (j > 0: every thread is done reading S_{j-1})
@@ -276,17 +288,16 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
             const unsigned pl = tab_pos[256 * q + t];
             if (pl == 0xFFFFFFFFu) continue;
             const float mu_q = tab_mu[256 * q + t];
-            const unsigned n = Uu > 1u ? __umulhi(pl, Minv) : pl, ph = pl - n * Uu;
+            const unsigned e = pl >> 8, ph = pl & 255u;
             const bool wrap = ph + 1u == Uu;                         // the second sample is phase 0 of the NEXT input sample
             if (ph == ju) {
-                const unsigned e = e0 + n;
                 const v2f s0 = lds[(e >> 8) * LDS_K2_STRIDE + (e & 255u)];
                 const float om = 1.0f - mu_q;                      // resample.cxx:147
                 acc[q] = __builtin_elementwise_fma((v2f){om, om}, s0, acc[q]);
             }
             if ((wrap ? 0u : ph + 1u) == ju) {
-                const unsigned e = e0 + n + (wrap ? 1u : 0u);
-                const v2f s1 = lds[(e >> 8) * LDS_K2_STRIDE + (e & 255u)];
+                const unsigned e1 = e + (wrap ? 1u : 0u);
+                const v2f s1 = lds[(e1 >> 8) * LDS_K2_STRIDE + (e1 & 255u)];
                 acc[q] = __builtin_elementwise_fma((v2f){mu_q, mu_q}, s1, acc[q]);
             }
         }

@@ -450,6 +450,7 @@ __global__ __launch_bounds__(256) void poly_rt_kernel(PolyTiledArgs a)
     const __attribute__((address_space(4))) float *gt = (const __attribute__((address_space(4))) float *)a.Gt;
     const int Lq = a.Lp / (int)SP;
     const bool out16 = CPLX && (UP % 2 == 0) && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;     // a thread's UP outputs as 16-byte pairs
+    const bool out_pairs = CPLX && (UP & 1) && UP == UPM && (reinterpret_cast<uintptr_t>(out) & 15u) == 0 && !(TMr & 1);      // odd UP: lane pairs (below)
 #pragma unroll 1
     for (int mi0 = (int)tid; mi0 < TMr; mi0 += 256 * MB) {
         T acc[MB][UPM];
@@ -488,6 +489,28 @@ __global__ __launch_bounds__(256) void poly_rt_kernel(PolyTiledArgs a)
             const int mi = mi0 + 256 * j;
             if (mi >= TMr) continue;
             const long long k = (long long)UP * (m0 + mi);
+            if constexpr (CPLX && (UPM == 3 || UPM == 5 || UPM == 7)) {
+                // an ODD number of outputs per m: lanes 2i, 2i + 1 hold 2 UP consecutive outputs between them, starting on a
+                // 16-byte boundary (m of the even lane is even).  The even lane takes the odd lane's first output beside its own
+                // last one, so that both store aligned 16-byte pairs only -- (UP + 1) / 2 and (UP - 1) / 2 of them -- instead
+                // of UP 8-byte pieces at a stride of 8 UP bytes each.  (tm is even and tiles start on even m.)
+                const long long kp = (long long)UP * (m0 + (mi & ~1));          // the pair's first output: the same in both lanes
+                const bool pair_ok = out_pairs && kp + 2 * UP <= a.n_out;
+                const v2f first = acc[j][0];
+                const v2f nxt0 = (v2f){__shfl_down(first.x, 1), __shfl_down(first.y, 1)};       // the odd lane's first output, in the even lane
+                if (pair_ok) {
+                    const bool odd = (tid & 1u) != 0;
+                    constexpr int H = (UPM - 1) / 2;
+#pragma unroll
+                    for (int i = 0; i < H; i++) {            // even lane: (2i, 2i + 1) at k + 2i; odd lane: (2i + 1, 2i + 2) at k + 2i + 1
+                        const v2f lo2 = odd ? acc[j][2 * i + 1] : acc[j][2 * i];
+                        const v2f hi2 = odd ? acc[j][2 * i + 2] : acc[j][2 * i + 1];
+                        *reinterpret_cast<v4f *>(out + k + 2 * i + (odd ? 1 : 0)) = (v4f){lo2.x, lo2.y, hi2.x, hi2.y};
+                    }
+                    if (!odd) *reinterpret_cast<v4f *>(out + k + UPM - 1) = (v4f){acc[j][UPM - 1].x, acc[j][UPM - 1].y, nxt0.x, nxt0.y};
+                    continue;
+                }
+            }
             if constexpr (CPLX && UPM >= 2) {
                 if (out16 && k + UP <= a.n_out) {        // UP even here: whole pairs
 #pragma unroll
@@ -504,247 +527,7 @@ __global__ __launch_bounds__(256) void poly_rt_kernel(PolyTiledArgs a)
 }
 
 #ifdef SFE_DIAG
-// ------------------------------------------------------ integer-step decimation, streamed (UP == 1)
-// DIAGNOSTIC LIBRARY ONLY (SFE_TILED_TPW=N, scripts/ab_dec.py tN): measured 3-10 % SLOWER than one tile per workgroup
-// on every box (profiles/r03/decimate_stream.txt) -- kept as the record of that experiment.
-// The same tile, the same LDS image and the same dot products as poly_tiled_kernel -- bit-identical results --
-// for the bulk decimator (UP == 1, fused arithmetic, float32 input, Lp <= 256): a workgroup takes a.tpw CONSECUTIVE
-// tiles, and
-//   * tile i + 1's SP*TM body samples are requested (into registers) as soon as tile i's have been staged, so they
-//     travel while tile i's dot products and stores run: the one-tile kernel has loads in flight for about half of a
-//     workgroup's life and LDS, not registers, bounds its residency (4 workgroups per CU at 70 VGPRs);
-//   * the Lp samples two consecutive tiles share stay in LDS (the last columns of tile i are the first of tile
-//     i + 1): every input sample is read from HBM once.
-// Workgroups whose tiles touch the history, the end of the input or the end of the output take the guarded
-// per-tile path (the first and the last workgroup of a channel).
-template <int SP, int UP, bool CPLX, bool EXACT>
-__device__ __forceinline__ void tiled_dot(const typename Elem<CPLX>::T *X, const float *G, int Lp, unsigned tid,
-                                          typename Elem<CPLX>::T (&acc)[2][UP])
-{
-    typedef typename Pair<CPLX>::P P2;
-    constexpr int ROWLEN = tiled_rowlen(SP);
-#pragma unroll
-    for (int b = 0; b < 2; b++)
-#pragma unroll
-        for (int r = 0; r < UP; r++) acc[b][r] = Elem<CPLX>::zero();
-    const int nchunk = Lp / SP;                                     // even (host pads Lp)
-    const P2 *xp = reinterpret_cast<const P2 *>(X) + tid + nchunk / 2;   // pair column (2*tid + cc)/2
-    // The taps are read through the CONSTANT address space: wave-uniform loads from it become scalar loads
-    // (s_load_dwordx4..x16 into SGPRs).  Through the generic pointer the compiler emits vector loads
-    // (global_load_dwordx4 with a uniform address), and a wait for one of those is a wait for every older
-    // vector-memory operation of the wave -- here the next tile's sixteen body loads, i.e. the whole prefetch.
-    typedef const __attribute__((address_space(4))) float *cfp;
-    cfp g = (cfp)G + (size_t)(nchunk - 1) * SP;                     // taps of chunk cc+1
-    auto step = [&](P2 (&cur)[SP], const P2 (&nxt)[SP]) {
-        xp -= 1;
-#pragma unroll
-        for (int p = 0; p < SP; p++) cur[p] = xp[p * (ROWLEN / 2)];
-#pragma unroll
-        for (int p = SP - 1; p >= 0; --p) {                          // chunk cc+1
-#pragma unroll
-            for (int r = 0; r < UP; r++) {
-                const float t = g[r * Lp + p];                       // wave-uniform
-                acc[0][r] = mac<EXACT>(acc[0][r], t, pair_hi(cur[p]));
-                acc[1][r] = mac<EXACT>(acc[1][r], t, pair_lo(nxt[p]));
-            }
-        }
-#pragma unroll
-        for (int p = SP - 1; p >= 0; --p) {                          // chunk cc
-#pragma unroll
-            for (int r = 0; r < UP; r++) {
-                const float t = g[r * Lp + p - SP];
-                acc[0][r] = mac<EXACT>(acc[0][r], t, pair_lo(cur[p]));
-                acc[1][r] = mac<EXACT>(acc[1][r], t, pair_hi(cur[p]));
-            }
-        }
-        g -= 2 * SP;
-    };
-    P2 pa[SP], pb[SP];
-#pragma unroll
-    for (int p = 0; p < SP; p++) pa[p] = xp[p * (ROWLEN / 2)];      // pairs at column 2*tid + nchunk
-    int steps = nchunk / 2;
-    if (steps & 1) {                                                 // odd count: peel one, landing in pa
-        step(pb, pa);
-#pragma unroll
-        for (int p = 0; p < SP; p++) pa[p] = pb[p];
-        steps--;
-    }
-    for (; steps > 0; steps -= 2) {
-        step(pb, pa);
-        step(pa, pb);
-    }
-}
-
-template <int SP, bool CPLX>
-__global__ __launch_bounds__(256, 4) void poly_stream_kernel(PolyTiledArgs a)      // 4 per SIMD: what the 37 KB tile image allows anyway
-{
-    typedef typename Elem<CPLX>::T T;
-    typedef typename Pair<CPLX>::P P2;
-    constexpr int ROWLEN = tiled_rowlen(SP);
-    constexpr int MAIN = SP * TM / 256;       // body loads per thread and tile
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    T *X = reinterpret_cast<T *>(smem);
-
-    const unsigned tid = threadIdx.x;
-    const int ch = blockIdx.y;
-    const T *in = static_cast<const T *>(a.in) + (size_t)ch * a.in_stride;
-    const T *hist = static_cast<const T *>(a.hist) + (size_t)ch * a.hl;
-    T *out = static_cast<T *>(a.out) + (size_t)ch * a.out_stride;
-
-    const unsigned groups = (a.tiles + a.tpw - 1u) / a.tpw;
-    if (blockIdx.x == groups) {                  // the history workgroup (poly_tiled_kernel has the reasoning); the launcher adds it only with hist_out
-        T *ho = static_cast<T *>(a.hist_out) + (size_t)ch * a.hl;
-#pragma unroll 1
-        for (unsigned i = tid; i < (unsigned)a.hl; i += 256u) ho[i] = in[a.n_in - a.hl + i];
-        return;
-    }
-    const long long t0 = (long long)blockIdx.x * a.tpw;
-    const long long t1 = t0 + a.tpw < (long long)a.tiles ? t0 + a.tpw : (long long)a.tiles;
-    const int n_tile = SP * TM + a.Lp;
-    const long long org0 = (long long)SP * TM * t0 + a.e_max - (a.Lp - 1);          // stream index of tile t0's local sample 0
-    const long long org_last = org0 + (long long)SP * TM * (t1 - 1 - t0);
-    const bool fast = org0 >= 0 && org_last + n_tile <= a.n_in && t1 * TM <= a.n_out &&
-                      (reinterpret_cast<uintptr_t>(out) & 15) == 0;
-    T acc[2][1];
-    if (!fast) {
-        for (long long t = t0; t < t1; t++) {
-            const long long n_org = org0 + (long long)SP * TM * (t - t0);
-            for (unsigned s = tid; s < (unsigned)n_tile; s += 256)
-                X[(s % SP) * ROWLEN + s / SP] = vload<CPLX>(in, hist, n_org + s, a.n_in, a.hl);
-            __syncthreads();
-            tiled_dot<SP, 1, CPLX, false>(X, a.G, a.Lp, tid, acc);
-            const long long k = t * TM + 2 * tid;
-            if (k < a.n_out) out[k] = acc[0][0];
-            if (k + 1 < a.n_out) out[k + 1] = acc[1][0];
-            __syncthreads();                     // everyone is done reading X
-        }
-        return;
-    }
-
-    const unsigned uLp = (unsigned)a.Lp, C0 = uLp / SP;
-    const T *src = in + org0;                                           // uniform
-    if (tid < uLp) X[(tid % SP) * ROWLEN + tid / SP] = __builtin_nontemporal_load(src + tid);      // head of the first tile
-    T v[MAIN];
-#pragma unroll
-    for (int i = 0; i < MAIN; i++) v[i] = __builtin_nontemporal_load(src + uLp + tid + 256u * i);
-    // cell of body sample j = tid + 256 i (local sample Lp + j, Lp a multiple of SP): row j % SP, column C0 + j / SP;
-    // j = SP (q0 + c_i) + (r0 + d_i) with compile-time c_i, d_i (poly_tiled_kernel)
-    const unsigned q0 = tid / SP, r0 = tid % SP;
-    const unsigned cell0 = r0 * ROWLEN + q0 + C0;
-    const unsigned carry_src = r0 * ROWLEN + TM + q0, carry_dst = r0 * ROWLEN + q0;
-    P2 w = {};
-    for (long long t = t0;; t++) {
-#pragma unroll
-        for (int i = 0; i < MAIN; i++) {
-            constexpr unsigned W = SP * ROWLEN - 1;         // row wrap: -SP rows, +1 column
-            const unsigned ci = (256u * i) / SP, di = (256u * i) % SP;
-            const unsigned cell = cell0 + di * ROWLEN + ci;
-            X[(r0 + di >= (unsigned)SP) ? cell - W : cell] = v[i];
-        }
-        __syncthreads();
-        // the PREVIOUS tile's outputs go out here, in front of the next tile's requests: vector-memory operations
-        // retire in issue order, so a store issued behind those requests (right after its dot products) would be
-        // waited for -- write acknowledge included -- by the wait for the samples at the top of the next iteration
-        if (t > t0) __builtin_nontemporal_store(w, reinterpret_cast<P2 *>(out + (t - 1) * TM) + tid);
-        const bool more = t + 1 < t1;
-        if (more) {
-            src += SP * TM;
-#pragma unroll
-            for (int i = 0; i < MAIN; i++) v[i] = __builtin_nontemporal_load(src + uLp + tid + 256u * i);
-        }
-        tiled_dot<SP, 1, CPLX, false>(X, a.G, a.Lp, tid, acc);
-        if constexpr (CPLX) w = (v4f){acc[0][0].x, acc[0][0].y, acc[1][0].x, acc[1][0].y};
-        else w = (v2f){acc[0][0], acc[1][0]};
-        if (!more) {
-            __builtin_nontemporal_store(w, reinterpret_cast<P2 *>(out + t * TM) + tid);
-            break;
-        }
-        T carry = Elem<CPLX>::zero();
-        if (tid < uLp) carry = X[carry_src];     // the Lp samples the next tile starts with
-        __syncthreads();                         // every read of this tile's image is done
-        if (tid < uLp) X[carry_dst] = carry;
-    }
-}
-
-// Diagnostic (SFE_TILED_TPW=-N): the streamed decimator with its N tiles taken at the stride of the grid instead of
-// consecutively -- the tiles in flight chip-wide are then always consecutive ones (one compact window, as with one tile
-// per workgroup) and nothing is carried in LDS: every tile loads its whole span, the next tile's in flight meanwhile.
-template <int SP, bool CPLX>
-__global__ __launch_bounds__(256, 4) void poly_stream_strided_kernel(PolyTiledArgs a)
-{
-    typedef typename Elem<CPLX>::T T;
-    typedef typename Pair<CPLX>::P P2;
-    constexpr int ROWLEN = tiled_rowlen(SP);
-    constexpr int MAIN = SP * TM / 256;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    T *X = reinterpret_cast<T *>(smem);
-    const unsigned tid = threadIdx.x;
-    const int ch = blockIdx.y;
-    const T *in = static_cast<const T *>(a.in) + (size_t)ch * a.in_stride;
-    const T *hist = static_cast<const T *>(a.hist) + (size_t)ch * a.hl;
-    T *out = static_cast<T *>(a.out) + (size_t)ch * a.out_stride;
-    const unsigned groups = (a.tiles + a.tpw - 1u) / a.tpw;
-    if (blockIdx.x == groups) {
-        T *ho = static_cast<T *>(a.hist_out) + (size_t)ch * a.hl;
-#pragma unroll 1
-        for (unsigned i = tid; i < (unsigned)a.hl; i += 256u) ho[i] = in[a.n_in - a.hl + i];
-        return;
-    }
-    const int n_tile = SP * TM + a.Lp;
-    const unsigned uLp = (unsigned)a.Lp;
-    const bool al = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
-    auto org_of = [&](long long t) { return (long long)SP * TM * t + a.e_max - (a.Lp - 1); };
-    auto interior = [&](long long t) { return t < (long long)a.tiles && org_of(t) >= 0 && org_of(t) + n_tile <= a.n_in && (t + 1) * TM <= a.n_out && al; };
-    T v[MAIN], vt = Elem<CPLX>::zero();
-    auto request = [&](long long t) {
-        const T *src = in + org_of(t);
-#pragma unroll
-        for (int i = 0; i < MAIN; i++) v[i] = __builtin_nontemporal_load(src + tid + 256u * i);
-        if (tid < uLp) vt = __builtin_nontemporal_load(src + SP * TM + tid);
-    };
-    const unsigned q0 = tid / SP, r0 = tid % SP;
-    const unsigned cell0 = r0 * ROWLEN + q0;
-    long long t = blockIdx.x;
-    bool got = interior(t);
-    if (got) request(t);
-    P2 w = {};
-    long long tw = -1;              // tile whose outputs wait in w
-    T acc[2][1];
-    for (; t < (long long)a.tiles; t += groups) {
-        if (got) {
-#pragma unroll
-            for (int i = 0; i < MAIN; i++) {
-                constexpr unsigned W = SP * ROWLEN - 1;
-                const unsigned ci = (256u * i) / SP, di = (256u * i) % SP;
-                const unsigned cell = cell0 + di * ROWLEN + ci;
-                X[(r0 + di >= (unsigned)SP) ? cell - W : cell] = v[i];
-            }
-            if (tid < uLp) X[r0 * ROWLEN + TM + q0] = vt;
-        } else {
-            const long long n_org = org_of(t);
-            for (unsigned s = tid; s < (unsigned)n_tile; s += 256)
-                X[(s % SP) * ROWLEN + s / SP] = vload<CPLX>(in, hist, n_org + s, a.n_in, a.hl);
-        }
-        __syncthreads();
-        if (tw >= 0) __builtin_nontemporal_store(w, reinterpret_cast<P2 *>(out + tw * TM) + tid);
-        tw = -1;
-        const bool cur_fast = got;
-        got = interior(t + groups);
-        if (got) request(t + groups);
-        tiled_dot<SP, 1, CPLX, false>(X, a.G, a.Lp, tid, acc);
-        if (cur_fast) {
-            if constexpr (CPLX) w = (v4f){acc[0][0].x, acc[0][0].y, acc[1][0].x, acc[1][0].y};
-            else w = (v2f){acc[0][0], acc[1][0]};
-            tw = t;
-        } else {
-            const long long k = t * TM + 2 * tid;
-            if (k < a.n_out) out[k] = acc[0][0];
-            if (k + 1 < a.n_out) out[k + 1] = acc[1][0];
-        }
-        __syncthreads();                         // every read of this tile's image is done
-    }
-    if (tw >= 0) __builtin_nontemporal_store(w, reinterpret_cast<P2 *>(out + tw * TM) + tid);
-}
+#include "diag/polyphase_diag.inc"
 #endif
 
 // ------------------------------------------- integer-step law on the matrix pipe (f32 MFMA)

@@ -77,8 +77,13 @@ def test_product_tree_never_touches_the_oracle():
 def test_product_library_reads_no_environment():
     """the product library takes its switches through the C ABI
     (sfe_dsp_rs_set_algo, sfe_dsp_fir_set_zero_copy_max), never from the environment: no getenv in
-    the sources outside #ifdef SFE_DIAG blocks, and the built libsfe_dsp.so does not even import it."""
-    for f in sorted(os.listdir(os.path.join(ROOT, "simplefe_amd", "csrc"))):
+    the sources outside #ifdef SFE_DIAG blocks (csrc/diag/*.inc are included under one only: checked too),
+    and the built libsfe_dsp.so does not even import it."""
+    csrc = os.path.join(ROOT, "simplefe_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if os.path.isdir(os.path.join(csrc, f)):
+            assert f == "diag", f
+            continue
         depth, diag_at = 0, None          # preprocessor nesting; depth at which an SFE_DIAG block opened
         for ln, line in enumerate(open(os.path.join(ROOT, "simplefe_amd", "csrc", f), errors="replace"), 1):
             st = line.strip()
@@ -92,6 +97,8 @@ def test_product_library_reads_no_environment():
                 depth -= 1
             elif "getenv" in line and not st.startswith("//") and diag_at is None:
                 raise AssertionError(f"{f}:{ln}: getenv outside #ifdef SFE_DIAG: {st}")
+            elif re.match(r'#\s*include\s+"diag/', st) and diag_at is None:
+                raise AssertionError(f"{f}:{ln}: a diagnostic include outside #ifdef SFE_DIAG: {st}")
     lib = os.path.join(ROOT, "simplefe_amd", "libsfe_dsp.so")
     syms = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True).stdout
     assert "getenv" not in syms, [l for l in syms.splitlines() if "getenv" in l]
