@@ -23,12 +23,12 @@
 #define SK(x) do { int r_ = (x); if (r_ != SFE_OK) { fprintf(stderr, "%s: %s\n", #x, sfe_dsp_last_error()); exit(1); } } while (0)
 
 struct Vm {
-    void *va = nullptr;
-    size_t size = 0;
+    void *va = nullptr, *res = nullptr;
+    size_t size = 0, res_size = 0;
     std::vector<hipMemGenericAllocationHandle_t> h;
 };
 
-static Vm vm_alloc(size_t bytes, size_t chunk)
+static Vm vm_alloc(size_t bytes, size_t chunk, size_t va_shift = 0)
 {
     Vm v;
     hipMemAllocationProp prop = {};
@@ -40,7 +40,13 @@ static Vm vm_alloc(size_t bytes, size_t chunk)
     if (chunk == 0) chunk = bytes;
     chunk = (chunk + gran - 1) / gran * gran;
     v.size = (bytes + chunk - 1) / chunk * chunk;
-    CK(hipMemAddressReserve(&v.va, v.size, chunk < ((size_t)1 << 30) ? chunk : ((size_t)1 << 30), nullptr, 0));
+    // va_shift: the mapping starts that many bytes behind a chunk-aligned address (is it the alignment of the VIRTUAL range
+    // that matters, or the size of the physical pieces?)
+    void *res = nullptr;
+    CK(hipMemAddressReserve(&res, v.size + va_shift, chunk < ((size_t)1 << 30) ? chunk : ((size_t)1 << 30), nullptr, 0));
+    v.res = res;
+    v.res_size = v.size + va_shift;
+    v.va = (char *)res + va_shift;
     for (size_t off = 0; off < v.size; off += chunk) {
         hipMemGenericAllocationHandle_t h;
         CK(hipMemCreate(&h, chunk, &prop, 0));
@@ -58,7 +64,7 @@ static void vm_free(Vm &v)
 {
     CK(hipMemUnmap(v.va, v.size));
     for (auto h : v.h) CK(hipMemRelease(h));
-    CK(hipMemAddressFree(v.va, v.size));
+    CK(hipMemAddressFree(v.res, v.res_size));
     v = Vm();
 }
 
@@ -89,23 +95,34 @@ int main(int argc, char **argv)
         std::sort(v.begin(), v.end());
         return v[v.size() / 2];
     };
-    struct Variant { const char *name; size_t chunk; int kind; };       // kind 0 hipMalloc, 1 VMM
-    const Variant vars[] = {{"M  hipMalloc", 0, 0},
-                            {"V  hipMemCreate, one allocation per buffer", 0, 1},
-                            {"C  hipMemCreate, 2 MiB chunks", (size_t)2 << 20, 1},
-                            {"C  hipMemCreate, 32 MiB chunks", (size_t)32 << 20, 1},
-                            {"C  hipMemCreate, 1 GiB chunks", (size_t)1 << 30, 1}};
+    struct Variant { const char *name; size_t chunk; int kind; size_t shift; };       // kind 0 hipMalloc, 1 VMM
+    const Variant set_a[] = {{"M  hipMalloc", 0, 0, 0},
+                             {"V  hipMemCreate, one allocation per buffer", 0, 1, 0},
+                             {"C  hipMemCreate, 2 MiB chunks", (size_t)2 << 20, 1, 0},
+                             {"C  hipMemCreate, 32 MiB chunks", (size_t)32 << 20, 1, 0},
+                             {"C  hipMemCreate, 1 GiB chunks", (size_t)1 << 30, 1, 0}};
+    const Variant set_b[] = {{"M  hipMalloc", 0, 0, 0},
+                             {"C  hipMemCreate, 128 MiB chunks", (size_t)128 << 20, 1, 0},
+                             {"C  hipMemCreate, 256 MiB chunks", (size_t)256 << 20, 1, 0},
+                             {"C  hipMemCreate, 512 MiB chunks", (size_t)512 << 20, 1, 0},
+                             {"C  hipMemCreate, 1 GiB chunks", (size_t)1 << 30, 1, 0},
+                             {"C  1 GiB chunks, mapped 2 MiB off alignment", (size_t)1 << 30, 1, (size_t)2 << 20},
+                             {"C  hipMemCreate, 2 GiB chunks", (size_t)2 << 30, 1, 0}};
     const int rounds = argc > 1 ? atoi(argv[1]) : 2;
+    const bool second = argc > 2 && argv[2][0] == 'b';
+    const Variant *vars = second ? set_b : set_a;
+    const int nvars = second ? 7 : 5;
     for (int round = 0; round < rounds; round++)
-        for (const Variant &v : vars) {
+        for (int vi_ = 0; vi_ < nvars; vi_++) {
+            const Variant &v = vars[vi_];
             void *in = nullptr, *out = nullptr;
             Vm vi, vo;
             if (v.kind == 0) {
                 CK(hipMalloc(&in, N * 8));
                 CK(hipMalloc(&out, CAP * 8));
             } else {
-                vi = vm_alloc(N * 8, v.chunk);
-                vo = vm_alloc(CAP * 8, v.chunk);
+                vi = vm_alloc(N * 8, v.chunk, v.shift);
+                vo = vm_alloc(CAP * 8, v.chunk, v.shift);
                 in = vi.va;
                 out = vo.va;
             }

@@ -40,7 +40,7 @@ def test_transform_domain_general_rate_random_shapes(api, L, seed):
     U = int(rng.choice([1, 2, 3, 4, 5, 8]))
     plen = int(rng.choice([1, 8, 43, 127, 128, 255, 256, 257, 300]))
     n_taps = U * plen - int(rng.integers(0, U))
-    B = 4096
+    B = int(rng.choice([4096, 4096, 5000, 16384, 3840]))          # calls at least one block advance long (shorter: the direct kernel)
     taps = (rng.standard_normal(n_taps) / np.sqrt(plen)).astype(np.float32)
     rate = float(np.float32(rng.uniform(1.0, 6.0)))
     if seed % 6 == 0:
