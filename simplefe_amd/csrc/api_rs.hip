@@ -474,9 +474,16 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         size_t K = 0;
         int max_m = 0;
         int prev_ref = -1;          // plan of the previous (memoised) call of this launch: its `next` link is followed / filled in
+        // A reference call that runs out of out_len mid-block leaves its time state BEFORE the next call's first sample
+        // (pos < -1; SURVEY.md section 5 -- it happens when the float32 recurrence drifts by more outputs than the
+        // ceil(n_in / rate) + 2 a call is given, e.g. blksize 16384 x 3 phases at a step of 3.005).  The direct kernel
+        // reproduces that state output for output; the transform-domain kernel assigns outputs to blocks by position and
+        // does not take such calls.
+        bool exhausted = false;
         for (size_t off = 0; off < n_in; off += (size_t)r->blksize) {
             const int m = (int)((n_in - off) < (size_t)r->blksize ? (n_in - off) : (size_t)r->blksize);
             const int cap = (int)ceilf((float)m / rate) + 2;
+            exhausted = exhausted || st.pos < -1;
             SegChunk c;
             c.in_off = (long long)off;
             c.k_first = (long long)K;
@@ -593,7 +600,7 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         // all U phases of every input by one forward and U inverse 4096-point transforms, outputs picked and blended from
         // LDS by the same runs.  sfe_dsp_rs_set_algo(SFE_RS_ALGO_DIRECT) and the exact mode keep poly_seg_kernel.
         rc = SFE_ESTATE;
-        if (!r->exact_stream && r->data_complex && !r->in_u8 && r->fft_mode >= 0 && stepf >= (float)r->U &&
+        if (!exhausted && !r->exact_stream && r->data_complex && !r->in_u8 && r->fft_mode >= 0 && stepf >= (float)r->U &&
             (r->fft_mode > 0 || (n_in >= ((size_t)1 << 16) && r->plen >= 12))) {
             if (!r->gen_tried) {
                 // spectra of the U phase filters (taps[i U + j], i < plen; one zero behind so that the overlap the FIR
