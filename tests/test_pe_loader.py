@@ -37,6 +37,19 @@ def test_reference_test_program_on_reference_fftw(built):
 
 
 @needs_reference
+def test_loader_and_stubs_are_clean_under_asan_and_ubsan():
+    """The same program with peload.c / win_stubs.c / fftwf_tramp.c built -fsanitize=address,undefined: mapping, relocating,
+    binding, the start-up code's calls into the stubs and the six forwarded FFTW calls raise no report."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref_fftw_asan"])
+    out = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "test_blkconv_fftw_asan")], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="halt_on_error=1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-2000:]
+    vals = [float(v) for v in out.stdout.split()[3:]]
+    assert vals == [1, 2, 3, 4] + [5] * 24 + [4, 3, 2, 1] + [0] * 24
+
+
+@needs_reference
 def test_live_reference_reproduces_the_committed_fixture(built, orc, g7):
     """The fixture is what the reference computes here, today: every case regenerated and
     compared.  Bit-equal on the CPU that wrote it (FFTW chooses codelets by CPU features, so another
