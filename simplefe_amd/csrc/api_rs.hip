@@ -635,7 +635,7 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
                 ga.hl = r->hl;
                 ga.U = r->U;
                 ga.plen = r->plen;
-                ga.ovl = r->gen_tables->ovl;
+                ga.ovl = (r->plen + 15) & ~15;              // >= plen; the spectra do not depend on it
                 ga.blksize = r->blksize;
                 ga.n_chunks = (int)chunks.size();
                 int max_runs = 0;

@@ -13,7 +13,8 @@
 //
 // One workgroup = one block of the stream, the FIR kernel's transform (fir_fft.hip: N = 16 x 16 x 16, thread t
 // owns 16 complex values, padded exchange buffer, the same twiddle tables and the same spectrum layout):
-//   block b transforms x[b A - ovl .. b A - ovl + 4096), A = 4096 - ovl, ovl >= plen a multiple of 256, and
+//   block b transforms x[b A - ovl .. b A - ovl + 4096), A = 4096 - ovl, ovl >= plen a multiple of 16 (the outputs are
+//   picked from LDS sample by sample, so the overlap need not be whole rows of 256 as in the FIR kernel), and
 //   OWNS the outputs whose first phase sample is s(p) with floor(p / U) in [b A - 1, (b + 1) A - 1): both
 //   s(p) and s(p + 1) then lie in what the block's inverse transforms produce validly.
 //   0. the runs (timelaw.h: t_i = t0 + i d, exact in double) of the one or two reference calls the block
@@ -123,12 +124,19 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
     };
     const RunLds *ra = runs, *rb = runs + na;
     const long long offa = ca.in_off * U, offb = cb.in_off * U;
-    const int ka_lo = count_below(ra, na, ca.n_out, Plo - offa), ka_hi = count_below(ra, na, ca.n_out, Phi - offa);
-    int kb_lo = 0, kb_hi = 0;
-    if (c1 > c0) {
-        kb_lo = count_below(rb, nb, cb.n_out, Plo - offb);
-        kb_hi = count_below(rb, nb, cb.n_out, Phi - offb);
+    // four bounds, four waves: wave w finds ONE of them (the search is uniform inside a wave: every lane of all four waves
+    // running all four searches was a seventh of the kernel's vector instructions) and lane 0 publishes it
+    __shared__ int s_bound[4];
+    {
+        const unsigned w = __builtin_amdgcn_readfirstlane(t >> 6);
+        const bool in_b = w >= 2u;
+        const int r = (in_b && c1 == c0) ? 0
+                                         : count_below(in_b ? rb : ra, in_b ? nb : na, in_b ? cb.n_out : ca.n_out,
+                                                       ((w & 1u) ? Phi : Plo) - (in_b ? offb : offa));
+        if ((t & 63u) == 0) s_bound[w] = r;
     }
+    lds_barrier();
+    const int ka_lo = s_bound[0], ka_hi = s_bound[1], kb_lo = s_bound[2], kb_hi = s_bound[3];
     const int Ta = ka_hi - ka_lo, T = Ta + (kb_hi - kb_lo);        // T <= 256 KPT (launcher)
     const long long k_first = Ta > 0 || c1 == c0 ? ca.k_first + ka_lo : cb.k_first + kb_lo;   // the block's outputs are consecutive
 
@@ -321,7 +329,7 @@ int poly_gen_outputs_per_block(int U, int ovl, float step)
 int launch_poly_gen(const PolyGenArgs &a, int max_runs_two_calls, float step, int n_channels, hipStream_t s)
 {
     if (a.n_chunks <= 0) return SFE_OK;
-    if (a.ovl < a.plen || a.ovl >= FFT_N || (a.ovl & 255) || a.blksize < FFT_N - a.ovl || max_runs_two_calls > GEN_MAX_RUNS)
+    if (a.ovl < a.plen || a.ovl >= FFT_N / 2 || (a.ovl & 15) || a.blksize < FFT_N - a.ovl || max_runs_two_calls > GEN_MAX_RUNS)
         return SFE_ESTATE;
     const int per_block = poly_gen_outputs_per_block(a.U, a.ovl, step);
     if (per_block > 256 * 16) return SFE_ESTATE;
