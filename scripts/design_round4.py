@@ -57,9 +57,28 @@ def shapes_block():
             + "\n".join(f"| {n} | {u} | {st} | {ms} | {fr} | {ex} |" for n, u, st, ms, fr, ex in rows) + "\n")
 
 
+def modes_block():
+    import csv
+    prof = float(list(csv.DictReader(open(os.path.join(P, "decimate_kernel_stats.csv"))))[0]["AverageNs"]) / 1e6
+    drv, dfl = line("bench_driver_shape"), line("bench_default")
+    d1 = [o for o in drv["other_configs"] if "decimate" in o.get("workload", "")][0]["ms"]
+    d2 = [o for o in dfl["other_configs"] if "decimate" in o.get("workload", "")][0]["ms"]
+    a, b = line("earlier/c1_bench_driver_shape"), line("earlier/c1_bench_default")
+    e1 = [o for o in a["other_configs"] if "decimate" in o.get("workload", "")][0]["ms"]
+    e2 = [o for o in b["other_configs"] if "decimate" in o.get("workload", "")][0]["ms"]
+    mode = lambda ms: "fast" if ms <= 1.53 else "slow"
+    return (f"The three columns come from two `gpurun` calls: the counters and kernel stats from one, the bench lines from the next (they had to wait for "
+            f"the counter summaries to be in the tree to carry `traffic`). The decimate row shows §4.2's two modes: the profiled process ran in the {mode(prof)} one "
+            f"({prof:.4f} ms, `profiles/r04/decimate_kernel_stats.csv`), the two line processes {('both in the ' + mode(d1)) if mode(d1) == mode(d2) else ('in the ' + mode(d1) + ' and the ' + mode(d2))} one ({d1:.4f} and {d2:.4f} ms, "
+            f"`profiles/r04/bench_driver_shape.json`, `profiles/r04/bench_default.json`); an earlier collection of the round had them the other way round — its "
+            f"profiled process slow at 1.58 ms, its own lines, made minutes later on the same box and kept under `earlier/` (without `traffic`), at {e1:.4f} and "
+            f"{e2:.4f} ms (`profiles/r04/earlier/c1_bench_driver_shape.json`, `profiles/r04/earlier/c1_bench_default.json`): the mode is the process's, not the "
+            f"box's. The FIR and the resampler differ between the calls by the boxes' usual 2–3 %.\n")
+
+
 path = os.path.join(ROOT, "DESIGN.md")
 text = open(path).read()
-for tag, block in (("shapes", shapes_block()), ("general", general_block())):
+for tag, block in (("shapes", shapes_block()), ("general", general_block()), ("modes", modes_block())):
     b, e = f"<!-- {tag}:begin -->", f"<!-- {tag}:end -->"
     i, j = text.index(b) + len(b), text.index(e)
     text = text[:i] + "\n" + block + text[j:]
