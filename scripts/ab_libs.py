@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B of the SAME call through two builds of the library in one process (each loaded
-privately): ab_libs.py <libA.so> <libB.so> [real|cf32|tx10|wire|rtx10|rwire|decimate|resample]   -- 256-tap FIR, 2^29 real / 2^28 cf32 samples;
-tx10 = cf32 in, 10-bit packed out; wire = u8 (I,Q) bytes in, 10-bit packed out; rtx10 / rwire = the same for a real stream; decimate = by 8, 64 taps, 2^30 cf32; resample = 5/3, 381 taps, 2^28 cf32."""
+privately): ab_libs.py <libA.so> <libB.so> [real|cf32|tx10|wire|rtx10|rwire|decimate|resample|general]   -- 256-tap FIR, 2^29 real / 2^28 cf32 samples;
+tx10 = cf32 in, 10-bit packed out; wire = u8 (I,Q) bytes in, 10-bit packed out; rtx10 / rwire = the same for a real stream; decimate = by 8, 64 taps, 2^30 cf32; resample = 5/3, 381 taps, 2^28 cf32; general = the same filter at rate 1.77."""
 import ctypes as C
 import os
 import sys
@@ -23,10 +23,10 @@ for p in paths:
             getattr(h, name).restype, getattr(h, name).argtypes = res, args
     libs.append(h)
 taps = synth.taps_cfg2()
-rs = mode in ("decimate", "resample")
+rs = mode in ("decimate", "resample", "general")
 if rs:
-    taps, U, rate, n = (synth.taps_cfg4(), 1, 8.0, 1 << 30) if mode == "decimate" else (synth.taps_cfg3(), 3, float(np.float32(5) / np.float32(3)), 1 << 28)
-    cap = int(n / rate) + 64
+    taps, U, rate, n = (synth.taps_cfg4(), 1, 8.0, 1 << 30) if mode == "decimate" else (synth.taps_cfg3(), 3, 1.77 if mode == "general" else float(np.float32(5) / np.float32(3)), 1 << 28)
+    cap = int(n / rate) + 8192
 st = []
 for h in libs:
     x, y, f, t = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()

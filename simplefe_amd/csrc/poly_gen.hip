@@ -85,8 +85,16 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
     // c B U - 1 <= P < (c + 1) B U - 1 (its leftover output sits at relative position -1).
     const long long Plo = (long long)U * (blk * A - 1), Phi = Plo + (long long)U * A;
     const long long BU = (long long)a.blksize * U;
-    long long c0 = (Plo + 1) / BU, c1 = (Phi) / BU;              // Plo + 1 >= 0 except for block 0 (Plo = -U): floor of a negative
-    if (Plo + 1 < 0) c0 = 0;
+    // c0 = floor((Plo + 1) / BU), c1 = floor(Phi / BU): by a double-precision quotient and one correction either way (the
+    // 64-bit integer divisions were ~300 scalar instructions per wave)
+    auto fdiv = [&](long long x) -> long long {
+        if (x < 0) return 0;                                      // block 0: Plo + 1 = 1 - U
+        long long c = (long long)((double)x / (double)BU);
+        if (c * BU > x) c--;
+        if ((c + 1) * BU <= x) c++;
+        return c;
+    };
+    long long c0 = fdiv(Plo + 1), c1 = fdiv(Phi);
     if (c1 >= a.n_chunks) c1 = a.n_chunks - 1;
     if (c0 > c1) c0 = c1;
     const SegChunk ca = a.chunks[c0], cb = a.chunks[c1];
@@ -100,8 +108,10 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
         for (int i = (int)t; i < 3 * nb; i += 256) ws[3 * na + i] = gb[i];
     }
     lds_barrier();
-    // outputs of a call whose relative position is < bound (uniform: every thread runs the same search)
-    auto count_below = [&](const RunLds *rs, int n_seg, int n_out, long long bound) -> int {
+    // outputs of a call whose relative position is < bound (uniform: every thread runs the same search); *run: the run that
+    // holds that output (or the one behind the last)
+    auto count_below = [&](const RunLds *rs, int n_seg, int n_out, long long bound, int *run) -> int {
+        *run = 0;
         if (n_seg == 0 || bound <= -1) return 0;
         const double bd = (double)bound;
         int l = 0, h = n_seg;                    // first run whose t0 >= bound
@@ -119,6 +129,7 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
             while (i < g.count && g.t0 + (double)i * (double)g.d < bd) i++;
             while (i > 0 && g.t0 + (double)(i - 1) * (double)g.d >= bd) i--;
         }
+        *run = i < g.count ? l - 1 : l;
         const int k = g.k0 + (int)i;
         return k < n_out ? k : n_out;
     };
@@ -126,58 +137,65 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
     const long long offa = ca.in_off * U, offb = cb.in_off * U;
     // four bounds, four waves: wave w finds ONE of them (the search is uniform inside a wave: every lane of all four waves
     // running all four searches was a seventh of the kernel's vector instructions) and lane 0 publishes it
-    __shared__ int s_bound[4];
+    __shared__ int s_bound[8];
+    const unsigned w = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63u;
     {
-        const unsigned w = __builtin_amdgcn_readfirstlane(t >> 6);
         const bool in_b = w >= 2u;
+        int run = 0;
         const int r = (in_b && c1 == c0) ? 0
                                          : count_below(in_b ? rb : ra, in_b ? nb : na, in_b ? cb.n_out : ca.n_out,
-                                                       ((w & 1u) ? Phi : Plo) - (in_b ? offb : offa));
-        if ((t & 63u) == 0) s_bound[w] = r;
+                                                       ((w & 1u) ? Phi : Plo) - (in_b ? offb : offa), &run);
+        if (lane == 0) {
+            s_bound[w] = r;
+            s_bound[4 + w] = run;
+        }
     }
     lds_barrier();
-    const int ka_lo = s_bound[0], ka_hi = s_bound[1], kb_lo = s_bound[2], kb_hi = s_bound[3];
+    const int ka_lo = __builtin_amdgcn_readfirstlane(s_bound[0]), ka_hi = __builtin_amdgcn_readfirstlane(s_bound[1]);
+    const int kb_lo = __builtin_amdgcn_readfirstlane(s_bound[2]), kb_hi = __builtin_amdgcn_readfirstlane(s_bound[3]);
+    const int ra_lo = __builtin_amdgcn_readfirstlane(s_bound[4]), rb_lo = __builtin_amdgcn_readfirstlane(s_bound[6]);
     const int Ta = ka_hi - ka_lo, T = Ta + (kb_hi - kb_lo);        // T <= 256 KPT (launcher)
     const long long k_first = Ta > 0 || c1 == c0 ? ca.k_first + ka_lo : cb.k_first + kb_lo;   // the block's outputs are consecutive
 
-    // tab_pos: where the output's first phase sample sits, (transform element << 8) | phase; 0xFFFFFFFF: no output.
-    // A thread's outputs k, k + 256, ... lie ~4 runs apart: the run of the first one is found by binary search, the
-    // next ones by walking on from it (a fresh search per output was a sixth of the kernel's vector instructions).
+    // The table, [output of the block]: the byte address in the exchange buffer of the output's first phase sample << 16 |
+    // (cells to its second one: 0 the next phase of the same input sample, 1 / 17 phase 0 of the next one) << 10 | the
+    // second sample's phase << 5 | the first one's; and mu.  Filled 64 consecutive outputs of ONE call at a time (wave w:
+    // every fourth such piece), so that what a piece needs to know about its call is uniform and scalar: the run of its first
+    // output is found by walking on from the wave's previous piece, each lane then walks on to its own (pieces hold one to
+    // a few runs, except where a call starts: there a dozen binades pass in as many outputs).  Round 4's first version
+    // searched and walked per output, with 64-bit positions: 850 of the block's 2 900 vector instructions per wave.
     const unsigned Uu = (unsigned)U, Minv = Uu > 1u ? 0xFFFFFFFFu / Uu + 1u : 0u;      // floor(x / U) = mulhi(x, Minv), x < U A
     const unsigned e0 = (unsigned)a.ovl - 1u;    // transform element of the block's first owned input sample
-    int la = -1, lb = -1;                        // run of this thread's previous output in call a / call b
 #pragma unroll 1
-    for (int q = 0; q < KPT; q++) {
-        const int idx = (int)t + 256 * q;
-        unsigned pl_q = 0xFFFFFFFFu;
-        float mu_q = 0.0f;
-        if (idx < T) {
-            const bool second = idx >= Ta;
-            const RunLds *rs = second ? rb : ra;
-            const int ns = second ? nb : na;
-            const int kk = second ? kb_lo + (idx - Ta) : ka_lo + idx;
-            int l = second ? lb : la;
-            if (l < 0) {                         // first run with k0 + count > kk
-                int h = ns;
-                l = 0;
-                while (l < h) {
-                    const int m = (l + h) >> 1;
-                    if (rs[m].k0 + rs[m].count <= kk) l = m + 1; else h = m;
-                }
-            } else {
+    for (int part = 0; part < 2; part++) {
+        const RunLds *rs = part ? rb : ra;
+        const int ns = part ? nb : na, k_lo = part ? kb_lo : ka_lo, n_part = part ? T - Ta : Ta, idx_base = part ? Ta : 0;
+        const unsigned off32 = (unsigned)((part ? offb : offa) - Plo);       // + floor(t) (|.| < 2^31, launcher): < U A, mod 2^32
+        int lu = part ? rb_lo : ra_lo;
+        if (lu > ns - 1) lu = ns - 1;
+#pragma unroll 1
+        for (int c = (int)w; 64 * c < n_part; c += 4) {
+            const int kk0 = k_lo + 64 * c;
+            while (lu + 1 < ns && __builtin_amdgcn_readfirstlane(rs[lu].k0 + rs[lu].count) <= kk0) lu++;
+            const int i_part = 64 * c + (int)lane;
+            if (i_part < n_part) {
+                const int kk = kk0 + (int)lane;
+                int l = lu;
                 while (rs[l].k0 + rs[l].count <= kk) l++;
+                const RunLds g = rs[l];
+                const double tt = g.t0 + (double)(kk - g.k0) * (double)g.d;      // exact (timelaw.h)
+                const double fl = floor(tt);
+                const float mu = (float)(tt - fl);
+                const unsigned pl = off32 + (unsigned)(int)fl;                  // position inside the block, < U A
+                const unsigned n = Uu > 1u ? __umulhi(pl, Minv) : pl;
+                const unsigned ph = pl - n * Uu, e = e0 + n;
+                const bool wrap = ph + 1u == Uu;
+                const unsigned cell = (e >> 8) * LDS_K2_STRIDE + (e & 255u);
+                const unsigned dcell = wrap ? ((e & 255u) == 255u ? LDS_K2_STRIDE - 255u : 1u) : 0u;
+                tab_pos[idx_base + i_part] = (cell << 19) | (dcell << 10) | ((wrap ? 0u : ph + 1u) << 5) | ph;
+                tab_mu[idx_base + i_part] = mu;
             }
-            if (second) lb = l; else la = l;
-            const RunLds g = rs[l];
-            const double tt = g.t0 + (double)(kk - g.k0) * (double)g.d;      // exact (timelaw.h)
-            const double fl = floor(tt);
-            mu_q = (float)(tt - fl);
-            const unsigned pl = (unsigned)((second ? offb : offa) + (long long)fl - Plo);      // position inside the block, < U A
-            const unsigned n = Uu > 1u ? __umulhi(pl, Minv) : pl;
-            pl_q = ((e0 + n) << 8) | (pl - n * Uu);
         }
-        tab_pos[256 * q + t] = pl_q;
-        tab_mu[256 * q + t] = mu_q;
     }
     lds_barrier();                               // the runs are dead: the buffer is the exchange buffer from here on
 
@@ -289,23 +307,22 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
 #pragma unroll
         for (int r = 0; r < 16; r++) lds[t + (unsigned)r * LDS_K2_STRIDE] = v[P16(r)];
         lds_barrier();
-        // the outputs' shares of S_j: element e sits at cell 272 (e / 256) + e % 256
+        // the outputs' shares of S_j
         const unsigned ju = (unsigned)j;
+        const char *lb = reinterpret_cast<const char *>(lds);
 #pragma unroll
         for (int q = 0; q < KPT; q++) {
-            const unsigned pl = tab_pos[256 * q + t];
-            if (pl == 0xFFFFFFFFu) continue;
+            if ((int)t + 256 * q >= T) continue;
+            const unsigned pw = tab_pos[256 * q + t];
             const float mu_q = tab_mu[256 * q + t];
-            const unsigned e = pl >> 8, ph = pl & 255u;
-            const bool wrap = ph + 1u == Uu;                         // the second sample is phase 0 of the NEXT input sample
-            if (ph == ju) {
-                const v2f s0 = lds[(e >> 8) * LDS_K2_STRIDE + (e & 255u)];
+            const unsigned a0 = pw >> 16;                                      // byte address of the first sample
+            if ((pw & 31u) == ju) {
+                const v2f s0 = *reinterpret_cast<const v2f *>(lb + a0);
                 const float om = 1.0f - mu_q;                      // resample.cxx:147
                 acc[q] = __builtin_elementwise_fma((v2f){om, om}, s0, acc[q]);
             }
-            if ((wrap ? 0u : ph + 1u) == ju) {
-                const unsigned e1 = e + (wrap ? 1u : 0u);
-                const v2f s1 = lds[(e1 >> 8) * LDS_K2_STRIDE + (e1 & 255u)];
+            if (((pw >> 5) & 31u) == ju) {
+                const v2f s1 = *reinterpret_cast<const v2f *>(lb + a0 + (((pw >> 10) & 31u) << 3));
                 acc[q] = __builtin_elementwise_fma((v2f){mu_q, mu_q}, s1, acc[q]);
             }
         }
@@ -331,6 +348,8 @@ int launch_poly_gen(const PolyGenArgs &a, int max_runs_two_calls, float step, in
     if (a.n_chunks <= 0) return SFE_OK;
     if (a.ovl < a.plen || a.ovl >= FFT_N / 2 || (a.ovl & 15) || a.blksize < FFT_N - a.ovl || max_runs_two_calls > GEN_MAX_RUNS)
         return SFE_ESTATE;
+    // the table's fields: 5 bits per phase; a call's positions as 32-bit integers
+    if (a.U > 32 || (long long)a.blksize * a.U >= 0x7fffffffLL) return SFE_ESTATE;
     const int per_block = poly_gen_outputs_per_block(a.U, a.ovl, step);
     if (per_block > 256 * 16) return SFE_ESTATE;
     const long long A = FFT_N - a.ovl;
