@@ -11,8 +11,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from simplefe_amd import lib as L, synth  # noqa: E402
 
-paths = sys.argv[1:3]
-mode = sys.argv[3] if len(sys.argv) > 3 else "real"
+paths = [a for a in sys.argv[1:] if a.endswith(".so")]          # two or more builds
+mode = ([a for a in sys.argv[1:] if not a.endswith(".so")] or ["real"])[0]
 cplx = mode in ("cf32", "tx10", "wire")
 n = 1 << (28 if cplx else 29)
 libs = []
@@ -43,7 +43,7 @@ for h in libs:
         assert h.sfe_dsp_fir_set_output_format(f, 2) == 0
     assert h.sfe_dsp_timer_create(C.byref(t)) == 0
     st.append((h, x, y, f, t))
-res = [[], []]
+res = [[] for _ in paths]
 for r in range(int(os.environ.get("ROUNDS", "10")) + 1):
     for i, (h, x, y, f, t) in enumerate(st):
         h.sfe_dsp_timer_start(t, None)
@@ -58,5 +58,19 @@ for r in range(int(os.environ.get("ROUNDS", "10")) + 1):
         h.sfe_dsp_timer_elapsed_ms(t, C.byref(ms))
         if r:
             res[i].append(ms.value / 5)
-for p, a in zip(paths, res):
-    print(f"{os.path.basename(p):32s} median {np.median(a):.4f} ms  min {min(a):.4f}  max {max(a):.4f}")
+# the builds must agree: three windows of the output (first, middle, last written), against the first build's
+wins = []
+for h, x, y, f, t in st:
+    h.sfe_dsp_sync(None)
+    n_out_f = 2 * (int(k.value) if rs else n) if mode not in ("tx10", "wire", "rtx10", "rwire") else 0
+    got = []
+    for off in ((0, n_out_f // 2 - (1 << 17), n_out_f - (1 << 18)) if n_out_f else ()):
+        off -= off % 2
+        buf = np.empty(1 << 18, np.float32)
+        assert h.sfe_dsp_memcpy_d2h(buf.ctypes.data, C.c_void_p(y.value + 4 * off), buf.nbytes, None) == 0
+        h.sfe_dsp_sync(None)
+        got.append(buf)
+    wins.append(got)
+for p, a, g in zip(paths, res, wins):
+    dev = max([float(np.max(np.abs(u - v))) for u, v in zip(g, wins[0])] or [0.0])
+    print(f"{os.path.basename(p):32s} median {np.median(a):.4f} ms  min {min(a):.4f}  max {max(a):.4f}   max |y - y(first build)| {dev:.2e}")

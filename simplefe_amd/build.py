@@ -26,12 +26,13 @@ TICKET_SOURCES = ("fir_fft.hip", "poly_fft.hip")
 HOST_SOURCES = ("api.hip", "api_plans.hip", "api_fir.hip", "api_rs.hip", "api_pipe.hip", "group.hip", "host.h")
 
 
-def sources():
-    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+def sources(diag=False):
+    # the diagnostic flavour also holds whole kernels that were measured and not kept (csrc/diag/*.hip)
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + (sorted(glob.glob(os.path.join(CSRC, "diag", "*.hip"))) if diag else [])
 
 
 def _deps():
-    return sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "diag", "*.inc")) + glob.glob(
+    return sources(diag=True) + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "diag", "*.inc")) + glob.glob(
         os.path.join(os.path.dirname(HERE), "include", "*.h"))
 
 
@@ -131,7 +132,7 @@ def build_lib(force=False, verbose=False, extra=(), diag=False):
     odir = os.path.join(HERE, "build_diag" if diag else "build")
     os.makedirs(odir, exist_ok=True)
     procs = []
-    for src in sources():
+    for src in sources(diag):
         obj = os.path.join(odir, os.path.basename(src) + ".o")
         objs.append(obj)
         if (not force and os.path.exists(obj) and

@@ -257,6 +257,10 @@ struct PolyGenArgs {
     const SegChunk *chunks;
     long long   n_in, in_stride, out_stride;
     int         hl, U, plen, ovl, blksize, n_chunks;
+    // (the diagnostic persistent form only, diag/poly_gen_persistent.hip: blocks per channel in a launch's list, where the
+    // list starts, channels, blocks dealt by a device counter)
+    long long   nblk, blk_first;
+    int         n_channels, tickets;
 };
 // SFE_ESTATE: outside what the kernel takes (caller: launch_poly_seg)
 int launch_poly_gen(const PolyGenArgs &a, int max_runs_two_calls, float step, int n_channels, hipStream_t s);

@@ -12,6 +12,15 @@
 
 namespace sfe {
 
+// The W16 constants of the DFT16 are operands of packed instructions, which take no 64-bit literal: register pairs.  In a
+// kernel that loops over transforms the compiler materialises them once, outside the loop -- up to eight VGPR pairs that
+// live for the whole kernel.  A file that defines SFE_W16_SCALAR before including this header has them in SGPR pairs
+// instead (one scalar source per packed instruction is allowed); poly_gen.hip does, where sixteen VGPRs decide the occupancy.
+#ifdef SFE_W16_SCALAR
+#define SFE_W16_C "s"
+#else
+#define SFE_W16_C "v"
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 // a * w
 // (each primitive is ONE asm statement: hipcc pads an s_nop after every asm statement whose
@@ -22,6 +31,15 @@ __device__ __forceinline__ v2f cmul(v2f a, v2f w)
     asm("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[1,0]\n\t"                                        // t = (ax wx, ay wx)
         "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"        // (-ay wy, ax wy) + t
         : "=v"(r), "=&v"(t) : "v"(a), "v"(w));
+    return r;
+}
+// a * w, w one of the W16 constants
+__device__ __forceinline__ v2f cmul_k(v2f a, v2f w)
+{
+    v2f t, r;
+    asm("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+        : "=v"(r), "=&v"(t) : "v"(a), SFE_W16_C(w));
     return r;
 }
 // acc + a * w
@@ -68,28 +86,28 @@ __device__ __forceinline__ v2f w16_2_fwd(v2f a, v2f s)    // s (ax+ay, ay-ax)
 {
     v2f t, r;
     asm("v_pk_add_f32 %1, %2, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
-        "v_pk_mul_f32 %0, %1, %3 op_sel_hi:[1,0]" : "=v"(r), "=&v"(t) : "v"(a), "v"(s));
+        "v_pk_mul_f32 %0, %1, %3 op_sel_hi:[1,0]" : "=v"(r), "=&v"(t) : "v"(a), SFE_W16_C(s));
     return r;
 }
 __device__ __forceinline__ v2f w16_2_inv(v2f a, v2f s)    // s (ax-ay, ay+ax)
 {
     v2f t, r;
     asm("v_pk_add_f32 %1, %2, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
-        "v_pk_mul_f32 %0, %1, %3 op_sel_hi:[1,0]" : "=v"(r), "=&v"(t) : "v"(a), "v"(s));
+        "v_pk_mul_f32 %0, %1, %3 op_sel_hi:[1,0]" : "=v"(r), "=&v"(t) : "v"(a), SFE_W16_C(s));
     return r;
 }
 __device__ __forceinline__ v2f w16_6_fwd(v2f a, v2f s)    // -j * s (ax+ay, ay-ax)
 {
     v2f t, r;
     asm("v_pk_add_f32 %1, %2, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
-        "v_pk_mul_f32 %0, %1, %3 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r), "=&v"(t) : "v"(a), "v"(s));
+        "v_pk_mul_f32 %0, %1, %3 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r), "=&v"(t) : "v"(a), SFE_W16_C(s));
     return r;
 }
 __device__ __forceinline__ v2f w16_6_inv(v2f a, v2f s)    // +j * s (ax-ay, ay+ax)
 {
     v2f t, r;
     asm("v_pk_add_f32 %1, %2, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
-        "v_pk_mul_f32 %0, %1, %3 op_sel:[1,0] op_sel_hi:[0,0] neg_lo:[1,0]" : "=v"(r), "=&v"(t) : "v"(a), "v"(s));
+        "v_pk_mul_f32 %0, %1, %3 op_sel:[1,0] op_sel_hi:[0,0] neg_lo:[1,0]" : "=v"(r), "=&v"(t) : "v"(a), SFE_W16_C(s));
     return r;
 }
 // a - j b = (ax + by, ay - bx)
@@ -141,6 +159,7 @@ __device__ __forceinline__ v2f scale_pj(v2f a, v2f s)     // s * (-ay, ax)
 #else
 __host__ __device__ __forceinline__ v2f cmul(v2f a, v2f w) { return (v2f){a.x * w.x - a.y * w.y, a.y * w.x + a.x * w.y}; }
 __host__ __device__ __forceinline__ v2f cmul_conj(v2f a, v2f w) { return (v2f){a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y}; }
+__host__ __device__ __forceinline__ v2f cmul_k(v2f a, v2f w) { return cmul(a, w); }
 __host__ __device__ __forceinline__ v2f cmac(v2f acc, v2f a, v2f w) { return (v2f){acc.x + a.x * w.x - a.y * w.y, acc.y + a.y * w.x + a.x * w.y}; }
 __host__ __device__ __forceinline__ v2f add_mj(v2f a, v2f b) { return (v2f){a.x + b.y, a.y - b.x}; }
 __host__ __device__ __forceinline__ v2f add_pj(v2f a, v2f b) { return (v2f){a.x - b.y, a.y + b.x}; }
@@ -182,9 +201,9 @@ __host__ __device__ __forceinline__ v2f tw16(v2f a)
         return DIR < 0 ? w16_2_fwd(a, (v2f){R, R}) : w16_2_inv(a, (v2f){R, R});
     else if constexpr (M == 6)   // W^6 = -+j W^2
         return DIR < 0 ? w16_6_fwd(a, (v2f){R, R}) : w16_6_inv(a, (v2f){R, R});
-    else if constexpr (M == 1) return cmul(a, (v2f){C1, sg * S1});
-    else if constexpr (M == 3) return cmul(a, (v2f){S1, sg * C1});
-    else /* M == 9 */ return cmul(a, (v2f){-C1, -sg * S1});
+    else if constexpr (M == 1) return cmul_k(a, (v2f){C1, sg * S1});
+    else if constexpr (M == 3) return cmul_k(a, (v2f){S1, sg * C1});
+    else /* M == 9 */ return cmul_k(a, (v2f){-C1, -sg * S1});
 }
 
 // 16-point DFT in registers.  Result element k is left in v[P16(k)].

@@ -59,7 +59,7 @@ static_assert(pf_swz(7) < 16, "the swizzle must stay inside a row of 16");
 // wide-lane scatter (8 consecutive samples per lane) keeps the XOR form: under the rotation its
 // lanes would fall 8 deep on two cells.
 template <int SP> struct PfRot;
-template <> struct PfRot<1> { static constexpr unsigned v[1] = {0}; };
+template <> struct PfRot<1> { [[maybe_unused]] static constexpr unsigned v[1] = {0}; };
 template <> struct PfRot<2> { static constexpr unsigned v[2] = {0, 8}; };
 template <> struct PfRot<3> { static constexpr unsigned v[3] = {0, 11, 6}; };
 template <> struct PfRot<4> { static constexpr unsigned v[4] = {0, 4, 8, 12}; };

@@ -29,6 +29,9 @@
 // the arithmetic is fused and transform-domain: rel-RMS ~3e-7 against the oracle, the exact mode stays on
 // poly_seg_kernel.  Complex float32 streams, rate >= 1 (at most one output per owned input sample).
 #include <stdint.h>
+#ifdef SFE_DIAG
+#include <stdlib.h>
+#endif
 
 #include "common.h"
 #include "fft16.h"
@@ -335,6 +338,10 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
 
 }  // namespace
 
+#ifdef SFE_DIAG
+int launch_poly_gen_persistent(const PolyGenArgs &a, int max_runs_two_calls, float step, int n_channels, hipStream_t s, int tickets);
+#endif
+
 int poly_gen_outputs_per_block(int U, int ovl, float step)
 {
     // consecutive outputs are >= step (1 - 2^-22) apart on the upsampled grid
@@ -350,6 +357,11 @@ int launch_poly_gen(const PolyGenArgs &a, int max_runs_two_calls, float step, in
         return SFE_ESTATE;
     // the table's fields: 5 bits per phase; a call's positions as 32-bit integers
     if (a.U > 32 || (long long)a.blksize * a.U >= 0x7fffffffLL) return SFE_ESTATE;
+#ifdef SFE_DIAG
+    // the persistent form with the next block fetched ahead (measured and not kept: diag/poly_gen_persistent.hip)
+    if (const char *e = getenv("SFE_GEN_PERSISTENT"))
+        if (atoi(e) > 0) return launch_poly_gen_persistent(a, max_runs_two_calls, step, n_channels, s, atoi(e) > 1);
+#endif
     const int per_block = poly_gen_outputs_per_block(a.U, a.ovl, step);
     if (per_block > 256 * 16) return SFE_ESTATE;
     const long long A = FFT_N - a.ovl;
