@@ -24,7 +24,8 @@ n = 1 << log2n
 # name, U, step (= rate * U): rate = step / U
 SHAPES = [("interpolate x2 (rate 1/2)", 2, 1), ("3/4 (4 out per 3 in)", 4, 3), ("4/3 (3 out per 4 in)", 3, 4),
           ("decimate by 6", 1, 6), ("decimate by 7", 1, 7), ("decimate by 16", 1, 16),
-          ("interpolate x4 (rate 1/4)", 4, 1), ("7/4", 4, 7), ("2/3 (3 out per 2 in)", 3, 2), ("3/2 (2 out per 3 in)", 2, 3), ("7/3 (3 out per 7 in)", 3, 7), ("4/5 (5 out per 4 in)", 5, 4)]
+          ("interpolate x4 (rate 1/4)", 4, 1), ("7/4", 4, 7), ("2/3 (3 out per 2 in)", 3, 2), ("3/2 (2 out per 3 in)", 2, 3), ("7/3 (3 out per 7 in)", 3, 7), ("4/5 (5 out per 4 in)", 5, 4),
+          ("interpolate x3 (rate 1/3)", 3, 1), ("interpolate x8 (rate 1/8)", 8, 1)]
 if os.environ.get("SHAPES"):
     want = os.environ["SHAPES"].split(",")
     SHAPES = [s for s in SHAPES if any(w in s[0] for w in want)]

@@ -154,6 +154,7 @@ struct PolyTiledArgs {
     // poly_rt_kernel (any SP, UP as launch arguments; set by the launcher)
     int         SP = 0, UP = 0, tm = 0, rowlen = 0;
     unsigned    sp_inv = 0;           // ceil(2^32 / SP): floor(s / SP) = mulhi(s, sp_inv) for the s a tile meets
+    unsigned    y_off = 0;            // byte offset in LDS of the waves' output regions (0: none; UP >= 3, complex)
 };
 // returns SFE_OK, or SFE_ESTATE when (SP, UP, Lp) has no tiled instantiation (caller falls
 // back to launch_poly_int)

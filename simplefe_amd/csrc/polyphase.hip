@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void poly_tiled_kernel(PolyTiledArgs a)
 // MB: m per thread that run TOGETHER through the tap loop (m, m + 256, ...): one tap row (a scalar load) and one loop
 // step feed MB sample reads and MB x UP multiply-accumulates -- with one m at a time the loop is bound by the latency of
 // the tap load and the LDS read (interpolate x2: 2.38 -> see profiles/r04/shapes.txt).
-template <bool CPLX, bool EXACT, bool IN_U8, int UPM, int MB>
+template <bool CPLX, bool EXACT, bool IN_U8, int UPM, int MB, int NLD>
 __global__ __launch_bounds__(256) void poly_rt_kernel(PolyTiledArgs a)
 {
     typedef typename Elem<CPLX>::T T;
@@ -427,20 +427,25 @@ __global__ __launch_bounds__(256) void poly_rt_kernel(PolyTiledArgs a)
         for (unsigned s = tid; s < n_tile; s += 256u) X[cell_of(s)] = vload_u8<CPLX>(in8, hist, n_org + s, a.n_in, a.hl);
     } else if (n_org >= 0 && n_org + n_tile <= a.n_in) {
         const T *src = in + n_org;                                        // uniform
-#pragma unroll 1
-        for (unsigned i0 = tid; i0 < n_tile; i0 += 256u * 8u) {           // eight requests per thread in flight at a time
-            T v[8];
+        // The tile's requests go out before the first is looked at (eight at a time -- the first version -- left a
+        // workgroup waiting for memory two or three times over per tile).  NLD rows of 256 are compiled in: 6 or 10 for tiles
+        // of up to 1536 / 2560 samples (the interpolating shapes: their tile is bounded by its OUTPUT), 18 beyond -- SP tm
+        // <= 4096 samples plus arms of up to 32 taps; what is left of a longer tile follows one request at a time.
+        // (Eighteen for every shape cost the interpolators three waves of occupancy and a dozen redundant requests per
+        // thread: x4 2.71 -> 3.14 ms.)  Lanes beyond the tile read its last sample and drop it: straight-line code, no
+        // branch around a request (with a uniform guard per row the compiler took the requests apart again).
+        T v[NLD];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const unsigned i = i0 + 256u * u;
-                v[u] = i < n_tile ? __builtin_nontemporal_load(src + i) : Elem<CPLX>::zero();
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const unsigned i = i0 + 256u * u;
-                if (i < n_tile) X[cell_of(i)] = v[u];
-            }
+        for (int u = 0; u < NLD; u++) {
+            const unsigned i = tid + 256u * u;
+            v[u] = __builtin_nontemporal_load(src + (i < n_tile ? i : n_tile - 1u));
         }
+#pragma unroll
+        for (int u = 0; u < NLD; u++) {
+            const unsigned i = tid + 256u * u;
+            if (i < n_tile) X[cell_of(i)] = v[u];
+        }
+        for (unsigned i = tid + 256u * NLD; i < n_tile; i += 256u) X[cell_of(i)] = __builtin_nontemporal_load(src + i);
     } else {
         for (unsigned s = tid; s < n_tile; s += 256u) X[cell_of(s)] = vload<CPLX>(in, hist, n_org + s, a.n_in, a.hl);
     }
@@ -451,6 +456,7 @@ __global__ __launch_bounds__(256) void poly_rt_kernel(PolyTiledArgs a)
     const int Lq = a.Lp / (int)SP;
     const bool out16 = CPLX && (UP % 2 == 0) && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;     // a thread's UP outputs as 16-byte pairs
     const bool out_pairs = CPLX && (UP & 1) && UP == UPM && (reinterpret_cast<uintptr_t>(out) & 15u) == 0 && !(TMr & 1);      // odd UP: lane pairs (below)
+    const bool out16w = CPLX && UP == UPM && a.y_off && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;            // whole waves through LDS (below)
 #pragma unroll 1
     for (int mi0 = (int)tid; mi0 < TMr; mi0 += 256 * MB) {
         T acc[MB][UPM];
@@ -487,6 +493,32 @@ __global__ __launch_bounds__(256) void poly_rt_kernel(PolyTiledArgs a)
 #pragma unroll
         for (int j = 0; j < MB; j++) {
             const int mi = mi0 + 256 * j;
+            if constexpr (CPLX && UPM >= 3) {
+                // Three or more outputs per m: a lane's UP results are 8 UP bytes from its neighbour's, every store instruction
+                // of the forms below writes 16-byte pieces at that stride -- for the shapes that are all stores (x4: 32 of
+                // every 40 bytes, x8: 64 of 72) the worst pattern there is (x8: 0.39 of the roofline).  The wave's 64 m are
+                // 64 UP CONSECUTIVE outputs: laid out in a region of LDS of the wave's own (rows of UP + 1 cells: the writes
+                // spread over the banks) and read back pair by pair, they leave as whole contiguous kilobytes.  Nothing but
+                // the wave touches the region and a wave's LDS operations execute in order: no barrier.
+                const int mi_w = ((int)(tid & ~63u)) + (mi0 - (int)tid) + 256 * j;       // the wave's first m of this round
+                const long long kw = (long long)UP * (m0 + mi_w);
+                if (out16w && mi_w + 64 <= TMr && kw + 64LL * UP <= a.n_out) {                // uniform over the wave
+                    v2f *Yw = reinterpret_cast<v2f *>(smem + a.y_off) + (tid >> 6) * (64u * (UPM + 1));
+                    const unsigned lane = tid & 63u;
+#pragma unroll
+                    for (int r = 0; r < UPM; r++) Yw[lane * (UPM + 1) + r] = acc[j][r];
+#pragma unroll
+                    for (int i = 0; i < (32 * UPM + 63) / 64; i++) {
+                        const unsigned pi = lane + 64u * i;                              // pair of outputs 2 pi, 2 pi + 1
+                        if ((32 * UPM) % 64 == 0 || pi < 32u * UPM) {
+                            const unsigned o0 = 2u * pi, o1 = o0 + 1u;
+                            const v2f lo2 = Yw[(o0 / UPM) * (UPM + 1) + o0 % UPM], hi2 = Yw[(o1 / UPM) * (UPM + 1) + o1 % UPM];
+                            __builtin_nontemporal_store((v4f){lo2.x, lo2.y, hi2.x, hi2.y}, reinterpret_cast<v4f *>(out + kw + o0));
+                        }
+                    }
+                    continue;
+                }
+            }
             if (mi >= TMr) continue;
             const long long k = (long long)UP * (m0 + mi);
             if constexpr (CPLX && (UPM == 3 || UPM == 5 || UPM == 7)) {
@@ -522,6 +554,154 @@ __global__ __launch_bounds__(256) void poly_rt_kernel(PolyTiledArgs a)
 #pragma unroll
             for (int r = 0; r < UPM; r++)
                 if ((UPM == 1 || r < UP) && k + r < a.n_out) out[k + r] = acc[j][r];
+        }
+    }
+}
+
+// poly_rt_kernel for SP = 1 -- the pure interpolators (x2, x3, ... x8: every input sample yields UP outputs), where that
+// kernel is bound by LDS bandwidth: each thread reads every sample of its window once per m, 8 bytes per UP multiply-adds
+// (x2 at 2^28 samples: 69 GB of LDS reads = 0.87 ms of a 1.55 ms launch, twice the vector ALU's share).  Here a thread owns
+// PAIRS of consecutive m (2 tid + 512 j, + 1): with P(c) = (X[c], X[c + 1]), c even -- one aligned 16-byte read, lanes 16 bytes
+// apart: conflict-free -- the pair's two sums need, for local times 2s + 1 and 2s,
+//     m:      P(m + 2s).hi, P(m + 2s).lo          m + 1:  P(m + 2s + 2).lo, P(m + 2s).hi
+// i.e. ONE new pair per two taps and two m: half the bytes per multiply-add.  Both sums still run tap index ascending from
+// 0.0f (the reference's order): EXACT is bit-identical to the compiled reference.  (poly_tiled_kernel<1, UP> has the same
+// pairing but 512-m tiles, its taps by vector loads and its outputs staged through LDS: 0.37 of the roofline for x2 and x4
+// when instantiated, against 0.50 for poly_rt_kernel -- profiles/r04/shapes_interpolators.txt.)
+template <bool CPLX, bool EXACT, bool IN_U8, int UPM, int MBP, int NLD>
+__global__ __launch_bounds__(256) void poly_rt1_kernel(PolyTiledArgs a)
+{
+    typedef typename Elem<CPLX>::T T;
+    typedef typename Pair<CPLX>::P P2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T *X = reinterpret_cast<T *>(smem);
+
+    const unsigned tid = threadIdx.x;
+    const int ch = blockIdx.y;
+    const T *in = static_cast<const T *>(a.in) + (IN_U8 ? 0 : (size_t)ch * a.in_stride);
+    const unsigned char *in8 = static_cast<const unsigned char *>(a.in) + (size_t)ch * a.in_stride * (CPLX ? 2 : 1);
+    const T *hist = static_cast<const T *>(a.hist) + (size_t)ch * a.hl;
+    T *out = static_cast<T *>(a.out) + (size_t)ch * a.out_stride;
+
+    if (!EXACT && a.hist_out && blockIdx.x == a.tiles) {        // the history workgroup (poly_tiled_kernel has the reasoning)
+        T *ho = static_cast<T *>(a.hist_out) + (size_t)ch * a.hl;
+#pragma unroll 1
+        for (unsigned i = tid; i < (unsigned)a.hl; i += 256u) {
+            if constexpr (IN_U8) ho[i] = vload_u8<CPLX>(in8, hist, a.n_in - a.hl + i, a.n_in, a.hl);
+            else ho[i] = in[a.n_in - a.hl + i];
+        }
+        return;
+    }
+    const int UP = a.UP, TMr = a.tm;                            // tm even, Lp even (host)
+    const long long m0 = (long long)blockIdx.x * TMr;
+    const long long n_org = m0 + a.e_max - (a.Lp - 1);           // stream index of local sample 0
+    const unsigned n_tile = (unsigned)TMr + (unsigned)a.Lp;      // X[s] = x[n_org + s]; sample (mi, qt) is X[mi + qt]
+    if constexpr (IN_U8) {
+        for (unsigned s = tid; s < n_tile; s += 256u) X[s] = vload_u8<CPLX>(in8, hist, n_org + s, a.n_in, a.hl);
+    } else if (n_org >= 0 && n_org + n_tile <= a.n_in) {
+        const T *src = in + n_org;                               // uniform; every request before the first is looked at (poly_rt_kernel)
+        T v[NLD];
+#pragma unroll
+        for (int u = 0; u < NLD; u++) {
+            const unsigned i = tid + 256u * u;
+            v[u] = __builtin_nontemporal_load(src + (i < n_tile ? i : n_tile - 1u));
+        }
+#pragma unroll
+        for (int u = 0; u < NLD; u++) {
+            const unsigned i = tid + 256u * u;
+            if (i < n_tile) X[i] = v[u];
+        }
+        for (unsigned i = tid + 256u * NLD; i < n_tile; i += 256u) X[i] = __builtin_nontemporal_load(src + i);
+    } else {
+        for (unsigned s = tid; s < n_tile; s += 256u) X[s] = vload<CPLX>(in, hist, n_org + s, a.n_in, a.hl);
+    }
+    __syncthreads();
+
+    const __attribute__((address_space(4))) float *gt = (const __attribute__((address_space(4))) float *)a.Gt;
+    const P2 *Xp = reinterpret_cast<const P2 *>(X);
+    const bool out16 = CPLX && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+#pragma unroll 1
+    for (int mi0 = 2 * (int)tid; mi0 < TMr; mi0 += 512 * MBP) {
+        T acc[MBP][2][UPM];
+        unsigned cj[MBP];                                        // pair column of pair j relative to pair 0 (a clamped one beyond the tile: not stored)
+#pragma unroll
+        for (int j = 0; j < MBP; j++) {
+            cj[j] = mi0 + 512 * j < TMr ? 256u * j : 0u;
+#pragma unroll
+            for (int r = 0; r < UPM; r++) acc[j][0][r] = acc[j][1][r] = Elem<CPLX>::zero();
+        }
+        const unsigned pc0 = (unsigned)mi0 / 2u;
+        P2 nxt[MBP];
+#pragma unroll
+        for (int j = 0; j < MBP; j++) nxt[j] = Xp[pc0 + cj[j] + (unsigned)a.Lp / 2u];
+#pragma unroll 2
+        for (int sx = a.Lp / 2 - 1; sx >= 0; --sx) {
+            P2 cur[MBP];
+#pragma unroll
+            for (int j = 0; j < MBP; j++) cur[j] = Xp[pc0 + cj[j] + (unsigned)sx];
+            float t1[UPM], t0[UPM];
+#pragma unroll
+            for (int r = 0; r < UPM; r++) {
+                t1[r] = gt[8 * (2 * sx + 1) + r];                 // the two rows are 64 consecutive bytes: scalar loads
+                t0[r] = gt[8 * (2 * sx) + r];
+            }
+#pragma unroll
+            for (int j = 0; j < MBP; j++) {
+#pragma unroll
+                for (int r = 0; r < UPM; r++) {
+                    acc[j][0][r] = mac<EXACT>(acc[j][0][r], t1[r], pair_hi(cur[j]));
+                    acc[j][1][r] = mac<EXACT>(acc[j][1][r], t1[r], pair_lo(nxt[j]));
+                }
+#pragma unroll
+                for (int r = 0; r < UPM; r++) {
+                    acc[j][0][r] = mac<EXACT>(acc[j][0][r], t0[r], pair_lo(cur[j]));
+                    acc[j][1][r] = mac<EXACT>(acc[j][1][r], t0[r], pair_hi(cur[j]));
+                }
+                nxt[j] = cur[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MBP; j++) {
+            const int mi = mi0 + 512 * j;
+            if constexpr (CPLX) {
+                // the wave's 64 pairs of m are 128 UP consecutive outputs: through a region of LDS of the wave's own (rows of
+                // 2 UP + 1 cells) they leave as contiguous kilobytes (poly_rt_kernel has the reasoning)
+                const int mi_w = 2 * (int)(tid & ~63u) + (mi0 - 2 * (int)tid) + 512 * j;
+                const long long kw = (long long)UP * (m0 + mi_w);
+                if (out16 && UP == UPM && a.y_off && mi_w + 128 <= TMr && kw + 128LL * UP <= a.n_out) {       // uniform over the wave
+                    constexpr unsigned RW = 2 * UPM + 1;
+                    v2f *Yw = reinterpret_cast<v2f *>(smem + a.y_off) + (tid >> 6) * (64u * RW);
+                    const unsigned lane = tid & 63u;
+#pragma unroll
+                    for (int h = 0; h < 2; h++)
+#pragma unroll
+                        for (int r = 0; r < UPM; r++) Yw[lane * RW + h * UPM + r] = acc[j][h][r];
+#pragma unroll
+                    for (int i = 0; i < UPM; i++) {
+                        const unsigned o0 = 2u * (lane + 64u * i), o1 = o0 + 1u;
+                        const v2f lo2 = Yw[(o0 / (2 * UPM)) * RW + o0 % (2 * UPM)], hi2 = Yw[(o1 / (2 * UPM)) * RW + o1 % (2 * UPM)];
+                        __builtin_nontemporal_store((v4f){lo2.x, lo2.y, hi2.x, hi2.y}, reinterpret_cast<v4f *>(out + kw + o0));
+                    }
+                    continue;
+                }
+            }
+            if (mi >= TMr) continue;
+            const long long k = (long long)UP * (m0 + mi);      // 2 UP consecutive outputs, 16 UP bytes from a 16-byte boundary
+            if constexpr (CPLX) {
+                if (out16 && UP == UPM && k + 2 * UP <= a.n_out) {
+#pragma unroll
+                    for (int i = 0; i < UPM; i++) {
+                        const v2f lo2 = acc[j][(2 * i) / UPM][(2 * i) % UPM], hi2 = acc[j][(2 * i + 1) / UPM][(2 * i + 1) % UPM];
+                        *reinterpret_cast<v4f *>(out + k + 2 * i) = (v4f){lo2.x, lo2.y, hi2.x, hi2.y};
+                    }
+                    continue;
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int r = 0; r < UPM; r++)
+                    if (r < UP && k + (long long)h * UP + r < a.n_out) out[k + (long long)h * UP + r] = acc[j][h][r];
         }
     }
 }
@@ -934,13 +1114,14 @@ int launch_poly_int(const PolyArgs &a, int data_complex, int /*taps_complex*/, i
     return SFE_OK;
 }
 
-// the eleven compile-time instantiations of poly_tiled_kernel
+// the fourteen compile-time instantiations of poly_tiled_kernel (round 4: 2/3, 3/4 -- UP > SP -- and 4/3)
 static bool poly_tiled_compiled(int SP, int UP, int Lp)
 {
     if (Lp <= 0 || Lp % (2 * SP)) return false;   // whole chunk pairs
     switch (SP * 16 + UP) {
     case 1 * 16 + 1: case 2 * 16 + 1: case 3 * 16 + 1: case 4 * 16 + 1: case 5 * 16 + 1: case 8 * 16 + 1:
     case 10 * 16 + 1: case 5 * 16 + 3: case 3 * 16 + 2: case 5 * 16 + 2: case 5 * 16 + 4:
+    case 2 * 16 + 3: case 3 * 16 + 4: case 4 * 16 + 3:      // round 4: 2/3, 3/4 and 4/3 (the pure interpolators run poly_rt1_kernel)
         break;
     default: return false;
     }
@@ -949,6 +1130,9 @@ static bool poly_tiled_compiled(int SP, int UP, int Lp)
 
 // ---- poly_rt_kernel's tile: m per workgroup and the LDS row pitch --------------------------------
 constexpr int RT_MAX_SP = 64, RT_MAX_UP = 8, RT_LDS_MAX = 60 * 1024;
+#ifndef RT1_MAX_UP
+#define RT1_MAX_UP 3
+#endif
 // tm m per tile so that the larger of the input and the output tile is ~4096 samples: a power of two of 256 .. 2048 m
 // (a thread then runs 1, 2, 4 or 8 m, whole groups of MB), multiples of 64 below
 static int rt_tile_m(int SP, int UP)
@@ -1020,36 +1204,86 @@ static int launch_poly_rt(const PolyTiledPlan &plan, const PolyTiledArgs &a0, in
     a.tiles = (unsigned)tiles;
     if (exact) a.hist_out = nullptr;
     dim3 grid((unsigned)tiles + (a.hist_out ? 1u : 0u), (unsigned)n_channels), block(256);
-    const size_t sh = (size_t)plan.SP * a.rowlen * esz;
+    size_t sh = (size_t)plan.SP * a.rowlen * esz;
+    a.y_off = 0;
+    // + the four waves' output regions (poly_rt_kernel: 64 rows of UP + 1 cells each) where the launch writes at least as much
+    // as it reads; the shapes that mostly read (7/4, 7/3) lose more to the LDS the regions take than the stores gain (-4 %)
+    if (data_complex && plan.UP >= 3 && plan.UP >= plan.SP) {
+        a.y_off = (unsigned)((sh + 15) & ~(size_t)15);
+        sh = a.y_off + (size_t)4 * 64 * (plan.UP + 1) * 8;
+    }
     // m per thread run together: as many as the tile gives a thread, up to 4 (2 for eight phase sums: registers)
     const int per_thread = (a.tm + 255) / 256;
+    // SP = 1, UP >= 2 -- the pure interpolators: pairs of consecutive m per thread (poly_rt1_kernel)
+    // (UP <= 3: from x4 on the launch is bound by its stores -- 32 of every 40 bytes -- and a thread's 2 UP outputs, 16 bytes
+    // per store at a stride of 16 UP, are a worse pattern for them than poly_rt_kernel's UP: x4 2.68 -> 2.96 ms)
+    if (plan.SP == 1 && plan.UP >= 2 && plan.UP <= RT1_MAX_UP && !(plan.Lp & 1) && !(a.tm & 1) && a.tm + plan.Lp <= 2560) {
+        const bool six = a.tm + plan.Lp <= 1536;
+        size_t sh1 = ((size_t)(a.tm + plan.Lp) * esz + 15) & ~(size_t)15;
+        a.y_off = 0;
+        if (data_complex) {                      // + the four waves' output regions: 64 rows of 2 UP + 1 cells
+            a.y_off = (unsigned)sh1;
+            sh1 += (size_t)4 * 64 * (2 * plan.UP + 1) * 8;
+        }
+#define SFE_R1B(C, E, U8, UPMv, MBPv)                                                                \
+    do {                                                                                              \
+        if (six || U8) hipLaunchKernelGGL((poly_rt1_kernel<C, E, U8, UPMv, MBPv, 6>), grid, block, sh1, s, a);          \
+        else hipLaunchKernelGGL((poly_rt1_kernel<C, E, U8 && false, UPMv, MBPv, 10>), grid, block, sh1, s, a);          \
+    } while (0)
+#define SFE_R1(C, E, U8)                                                                              \
+    do {                                                                                              \
+        switch (plan.UP) {                                                                            \
+        case 2: SFE_R1B(C, E, U8, 2, 2); break;                                                       \
+        default: SFE_R1B(C, E, U8, 3, 2); break;                                                      \
+        }                                                                                             \
+    } while (0)
+        if (in_u8) {
+            if (data_complex) SFE_R1(true, false, true); else SFE_R1(false, false, true);
+        } else if (data_complex) {
+            if (exact) SFE_R1(true, true, false); else SFE_R1(true, false, false);
+        } else {
+            if (exact) SFE_R1(false, true, false); else SFE_R1(false, false, false);
+        }
+#undef SFE_R1
+#undef SFE_R1B
+        SFE_HIP(hipGetLastError());
+        return SFE_OK;
+    }
+    const int n_tile = plan.SP * a.tm + plan.Lp;
+    const int rows_ahead = n_tile <= 1536 ? 6 : (n_tile <= 2560 ? 10 : 18);          // rows of 256 requested up front
+#define SFE_RT1(C, E, U8, UPMv, MBv)                                                                 \
+    do {                                                                                              \
+        if (rows_ahead == 6 || U8) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, UPMv, MBv, 6>), grid, block, sh, s, a);   \
+        else if (rows_ahead == 10) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8 && false, UPMv, MBv, 10>), grid, block, sh, s, a);   \
+        else hipLaunchKernelGGL((poly_rt_kernel<C, E, U8 && false, UPMv, MBv, 18>), grid, block, sh, s, a);         \
+    } while (0)
 #define SFE_RT(C, E, U8)                                                                             \
     do {                                                                                              \
         if (plan.UP == 1) {                                                                           \
-            if (per_thread >= 4) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 1, 4>), grid, block, sh, s, a);      \
-            else if (per_thread >= 2) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 1, 2>), grid, block, sh, s, a); \
-            else hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 1, 1>), grid, block, sh, s, a);                      \
+            if (per_thread >= 4) SFE_RT1(C, E, U8, 1, 4);      \
+            else if (per_thread >= 2) SFE_RT1(C, E, U8, 1, 2); \
+            else SFE_RT1(C, E, U8, 1, 1);                      \
         } else if (plan.UP == 2) {                                                                    \
-            if (per_thread >= 4) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 2, 4>), grid, block, sh, s, a);      \
-            else hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 2, 2>), grid, block, sh, s, a);                      \
+            if (per_thread >= 4) SFE_RT1(C, E, U8, 2, 4);      \
+            else SFE_RT1(C, E, U8, 2, 2);                      \
         } else if (plan.UP == 3) {                                                                    \
-            if (per_thread >= 4) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 3, 4>), grid, block, sh, s, a);      \
-            else hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 3, 2>), grid, block, sh, s, a);                      \
+            if (per_thread >= 4) SFE_RT1(C, E, U8, 3, 4);      \
+            else SFE_RT1(C, E, U8, 3, 2);                      \
         } else if (plan.UP == 4) {                                                                    \
-            if (per_thread >= 4) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 4, 4>), grid, block, sh, s, a);      \
-            else hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 4, 2>), grid, block, sh, s, a);                      \
+            if (per_thread >= 4) SFE_RT1(C, E, U8, 4, 4);      \
+            else SFE_RT1(C, E, U8, 4, 2);                      \
         } else if (plan.UP == 5) {                                                                    \
-            if (per_thread >= 4) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 5, 4>), grid, block, sh, s, a);      \
-            else hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 5, 2>), grid, block, sh, s, a);                      \
+            if (per_thread >= 4) SFE_RT1(C, E, U8, 5, 4);      \
+            else SFE_RT1(C, E, U8, 5, 2);                      \
         } else if (plan.UP == 6) {                                                                    \
-            if (per_thread >= 4) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 6, 4>), grid, block, sh, s, a);      \
-            else hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 6, 2>), grid, block, sh, s, a);                      \
+            if (per_thread >= 4) SFE_RT1(C, E, U8, 6, 4);      \
+            else SFE_RT1(C, E, U8, 6, 2);                      \
         } else if (plan.UP == 7) {                                                                    \
-            if (per_thread >= 4) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 7, 4>), grid, block, sh, s, a);      \
-            else hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 7, 2>), grid, block, sh, s, a);                      \
+            if (per_thread >= 4) SFE_RT1(C, E, U8, 7, 4);      \
+            else SFE_RT1(C, E, U8, 7, 2);                      \
         } else {                                                                                      \
-            if (per_thread >= 4) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 8, 4>), grid, block, sh, s, a);      \
-            else hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, 8, 2>), grid, block, sh, s, a);                      \
+            if (per_thread >= 4) SFE_RT1(C, E, U8, 8, 4);      \
+            else SFE_RT1(C, E, U8, 8, 2);                      \
         }                                                                                             \
     } while (0)
     if (in_u8) {
@@ -1059,6 +1293,7 @@ static int launch_poly_rt(const PolyTiledPlan &plan, const PolyTiledArgs &a0, in
     } else {
         if (exact) SFE_RT(false, true, false); else SFE_RT(false, false, false);
     }
+#undef SFE_RT1
 #undef SFE_RT
     SFE_HIP(hipGetLastError());
     return SFE_OK;
@@ -1159,7 +1394,8 @@ int launch_poly_tiled(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int da
     }
 #define SFE_T(SPv, UPv)                                                                               \
     case SPv * 16 + UPv: {                                                                            \
-        const size_t sh = (size_t)SPv * tiled_rowlen(SPv) * esz;                                      \
+        /* the output tile is laid out in the same LDS before it is stored: UP TM elements (more than the input's for UP > SP) */ \
+        const size_t sh = (size_t)(SPv * tiled_rowlen(SPv) > UPv * TM ? SPv * tiled_rowlen(SPv) : UPv * TM) * esz;   \
         if (data_complex) {                                                                           \
             if (exact) hipLaunchKernelGGL((poly_tiled_kernel<SPv, UPv, true, true>), grid, block, sh, s, a);   \
             else hipLaunchKernelGGL((poly_tiled_kernel<SPv, UPv, true, false>), grid, block, sh, s, a);        \
@@ -1171,6 +1407,7 @@ int launch_poly_tiled(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int da
     switch (plan.SP * 16 + plan.UP) {
         SFE_T(1, 1) SFE_T(2, 1) SFE_T(3, 1) SFE_T(4, 1) SFE_T(5, 1) SFE_T(8, 1) SFE_T(10, 1)
         SFE_T(5, 3) SFE_T(3, 2) SFE_T(5, 2) SFE_T(5, 4)
+        SFE_T(2, 3) SFE_T(3, 4) SFE_T(4, 3)
     default: return SFE_ESTATE;
     }
 #undef SFE_T
