@@ -11,6 +11,7 @@ SFE_BENCH_ONE_DEVICE=1 timeout -k 10 500 python3 bench.py --gpus 4 --steps 20 --
 SFE_BENCH_ONE_DEVICE=1 timeout -k 10 300 python3 bench.py --gpus 8 --single-process --steps 20 --warmup 5 > $O/bench_single_process_8_blocks.json 2> $O/bench_single_process.err || exit 1
 timeout -k 10 300 python3 bench.py --gpus 1 --single-process --steps 20 --warmup 5 > $O/bench_single_process_1_block.json 2>> $O/bench_single_process.err || exit 1
 timeout -k 10 300 python3 scripts/time_shapes.py > $O/shapes.txt 2>&1 || exit 1
+timeout -k 10 120 scripts/probes/hbm_mix i > $O/hbm_mix_interpolators.txt 2>&1
 LOG2N=28 timeout -k 10 300 python3 scripts/time_general_rate.py > $O/general_rate.txt 2>&1 || exit 1
 timeout -k 10 200 python3 scripts/time_block_api.py > $O/block_api_latency.txt 2>&1
 timeout -k 10 200 python3 scripts/time_pipe.py > $O/host_pipe.txt 2>&1

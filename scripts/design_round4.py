@@ -36,13 +36,13 @@ def general_block():
     cnt = (f"*Roofline:* HBM nominally (3.36 GB ÷ 8 TB/s = 0.42 ms), but this kernel is bound on the chip — vector-ALU issue and the chain of twenty workgroup "
            f"barriers of one block's four transforms at three workgroups per CU: per launch (`profiles/r04/general_sq_counters.txt`) {c['SQ_INSTS_VALU'] / waves:.0f} vector-ALU, "
            f"{c['SQ_INSTS_LDS'] / waves:.0f} LDS, {c['SQ_INSTS_SALU'] / waves:.0f} scalar and {c['SQ_INSTS_VMEM'] / waves:.0f} vector-memory instructions per wave per block — about half "
-           f"of the vector-ALU work is the four transforms (the FIR kernel: 774 per wave for two), the rest the per-output bookkeeping (the run of each output, the float64 instant, "
-           f"the phase tests of three rounds); `SQ_ACTIVE_INST_VALU` {c['SQ_ACTIVE_INST_VALU']:.3g} of `SQ_WAVE_CYCLES` {c['SQ_WAVE_CYCLES']:.3g}, `SQ_WAIT_INST_LDS` "
+           f"of the vector-ALU work is the four transforms (the FIR kernel: 774 per wave for two), the rest the per-output bookkeeping (the table of step 0, the phase tests "
+           f"of three rounds); `SQ_ACTIVE_INST_VALU` {c['SQ_ACTIVE_INST_VALU']:.3g} of `SQ_WAVE_CYCLES` {c['SQ_WAVE_CYCLES']:.3g}, `SQ_WAIT_INST_LDS` "
            f"{c['SQ_WAIT_INST_LDS']:.3g}, `SQ_LDS_BANK_CONFLICT` {c['SQ_LDS_BANK_CONFLICT']:.3g} against `SQ_LDS_IDX_ACTIVE` {c['SQ_LDS_IDX_ACTIVE']:.3g} (the gather's per-lane reads); "
            f"the vector ALU is issuing ≈ {c['SQ_INSTS_VALU'] * 4 / 1024 / (c['GRBM_GUI_ACTIVE'] / 8) * 100:.0f} % of the kernel's time ({c['SQ_INSTS_VALU']:.3g} instructions × 4 cycles "
            f"over 1024 SIMDs against {c['GRBM_GUI_ACTIVE'] / 8:.3g} cycles per XCD). Memory side: 2 × `FETCH_SIZE` + `WRITE_SIZE` = {hbm / 1e9:.2f} GB = "
-           f"{hbm / 3360776248:.2f} × algorithmic (the 256-sample overlap re-read per 3840 and the spectra). What would move it: a persistent grid (twiddle bases and "
-           f"the first spectrum resident), fewer barriers per transform; not memory.\n")
+           f"{hbm / 3360776248:.2f} × algorithmic (the 128-sample overlap re-read per 3968 and the spectra). What would move it: fewer barriers per transform, or a smaller "
+           f"transform at more workgroups per CU; not memory — and not a persistent grid (below).\n")
     return fig + cnt
 
 

@@ -92,6 +92,25 @@ __global__ __launch_bounds__(256) void k_mix53(const v2f *in, v2f *out, size_t n
     }
 }
 
+// 1 part read, UP parts written (the interpolators' mix, x2 / x4 / x8): a workgroup reads NR x 256 8-byte lanes and writes
+// NR UP / 2 x 256 sixteen-byte lanes, contiguous (what poly_rt_kernel's wave-private output regions produce)
+template <int UP, int NR>
+__global__ __launch_bounds__(256) void k_mix1u(const v2f *in, v4f *out, size_t n_tiles)
+{
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const v2f *p = in + tile * (size_t)(NR * 256) + threadIdx.x;
+        v2f v[NR];
+#pragma unroll
+        for (int u = 0; u < NR; u++) v[u] = __builtin_nontemporal_load(p + 256 * u);
+        v4f *q = out + tile * (size_t)(NR * UP / 2 * 256) + threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < NR * UP / 2; u++) {
+            const v2f a = v[u % NR], b = v[(u + 1) % NR];
+            __builtin_nontemporal_store((v4f){a.x, a.y, b.x, b.y}, q + 256 * u);
+        }
+    }
+}
+
 template <typename F>
 static void timeit(const char *name, double bytes, F launch)
 {
@@ -129,6 +148,13 @@ int main(int argc, char **argv)
         timeit("mix 8:1, tile 4096 samples (16 loads per lane)", 1.125 * bytes, [&] { hipLaunchKernelGGL((k_mix81<16>), dim3((unsigned)(n8 / (16 * 256))), dim3(256), 0, 0, (const v2f *)in, (v2f *)out, n8 / (16 * 256)); });
         timeit("mix 8:1, tile 2048 samples (8 loads per lane)", 1.125 * bytes, [&] { hipLaunchKernelGGL((k_mix81<8>), dim3((unsigned)(n8 / (8 * 256))), dim3(256), 0, 0, (const v2f *)in, (v2f *)out, n8 / (8 * 256)); });
         timeit("mix 8:1, tile 8192 samples (32 loads per lane)", 1.125 * bytes, [&] { hipLaunchKernelGGL((k_mix81<32>), dim3((unsigned)(n8 / (32 * 256))), dim3(256), 0, 0, (const v2f *)in, (v2f *)out, n8 / (32 * 256)); });
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == 'i') {       // the interpolators' mixes: 2^27 / 2^26 / 2^25 samples in so that the output stays 2 GiB
+        printf("-- one workgroup per tile (32 KiB written per workgroup)\n");
+        { const size_t t = (bytes / 2 / 8) / (8 * 256); timeit("mix 1:2, 8 x 8 B loads, 16 x 16 B stores", 1.5 * bytes, [&] { hipLaunchKernelGGL((k_mix1u<2, 8>), dim3((unsigned)t), dim3(256), 0, 0, (const v2f *)in, (v4f *)out, t); }); }
+        { const size_t t = (bytes / 4 / 8) / (4 * 256); timeit("mix 1:4, 4 x 8 B loads, 16 x 16 B stores", 1.25 * bytes, [&] { hipLaunchKernelGGL((k_mix1u<4, 4>), dim3((unsigned)t), dim3(256), 0, 0, (const v2f *)in, (v4f *)out, t); }); }
+        { const size_t t = (bytes / 8 / 8) / (2 * 256); timeit("mix 1:8, 2 x 8 B loads, 16 x 16 B stores", 1.125 * bytes, [&] { hipLaunchKernelGGL((k_mix1u<8, 2>), dim3((unsigned)t), dim3(256), 0, 0, (const v2f *)in, (v4f *)out, t); }); }
         return 0;
     }
     if (argc > 1 && argv[1][0] == '4') {       // the real-data FIR's lane width: 4-byte lanes against 8 and 16 (same bytes, same grid)
