@@ -267,7 +267,9 @@ int sfe_dsp_fir_destroy(sfe_fir_t h);
  *   sfe_dsp_fir_create_per_channel's (then the data are complex).  n_devices <= n_channels.
  * process_stream: d_in[k] / d_out[k] are block k's buffers ON devices[k], channel-major with the
  *   given strides, n samples per channel.  The launches go to every device before anything waits
- *   (asynchronous on the blocks' own streams); sync waits for all of them.
+ *   (asynchronous on the blocks' own streams); sync waits for all of them.  A call that fails after
+ *   some blocks have taken their launch leaves the blocks out of step: further calls return
+ *   SFE_ESTATE until _reset (a failure at the first block -- bad arguments -- has moved nothing).
  * shard: what block k is -- its device, first channel, channel count, the underlying handle (for
  *   sfe_dsp_fir_set_variant / load_history / calibrate ... on it) and its stream (to order the
  *   caller's copies with the block's launches).  Any out pointer may be NULL.

@@ -29,6 +29,9 @@ struct Group {
     uint32_t magic = 0x47525031u;   // 'GRP1'
     int kind = 0;                   // 0 FIR, 1 resample / decimate
     int n_channels = 0;
+    // a group call that failed after some of its shards had taken their launch has left the shards' streams (and, for the
+    // resamplers, their time states) out of step: further calls are refused until _reset puts every shard back to the start
+    bool out_of_step = false;
     std::vector<GroupShard> shards;
 };
 
@@ -167,11 +170,18 @@ int sfe_dsp_fir_group_process_stream(sfe_fir_group_t grp, const void *const *d_i
         set_error("fir_group_process_stream: null argument");
         return SFE_EINVAL;
     }
+    if (g->out_of_step) {
+        set_error("fir_group_process_stream: an earlier call failed part-way: the shards are out of step until sfe_dsp_fir_group_reset");
+        return SFE_ESTATE;
+    }
     // every device gets its launch before anything waits: the calls are asynchronous on the shards' own streams
     for (size_t k = 0; k < g->shards.size(); k++) {
         const GroupShard &s = g->shards[k];
         int rc = sfe_dsp_fir_process_stream(s.h, d_in[k], d_out[k], n, in_stride, out_stride, (sfe_stream_t)s.stream);
-        if (rc != SFE_OK) return rc;
+        if (rc != SFE_OK) {
+            g->out_of_step = k > 0;              // (a failure at the first shard has moved nothing)
+            return rc;
+        }
     }
     return SFE_OK;
 }
@@ -192,6 +202,7 @@ int sfe_dsp_fir_group_reset(sfe_fir_group_t grp)
         int rc = sfe_dsp_fir_reset(s.h);
         if (rc != SFE_OK) return rc;
     }
+    g->out_of_step = false;
     return SFE_OK;
 }
 
@@ -266,13 +277,21 @@ int sfe_dsp_rs_group_process_stream(sfe_rs_group_t grp, const void *const *d_in,
         return SFE_EINVAL;
     }
     *n_out = 0;
+    if (g->out_of_step) {
+        set_error("rs_group_process_stream: an earlier call failed part-way: the shards are out of step until sfe_dsp_rs_group_reset");
+        return SFE_ESTATE;
+    }
     for (size_t k = 0; k < g->shards.size(); k++) {
         const GroupShard &s = g->shards[k];
         size_t got = 0;
         int rc = sfe_dsp_rs_process_stream(s.h, d_in[k], n_in, in_stride, d_out[k], out_cap, out_stride, rate, &got,
                                            (sfe_stream_t)s.stream);
-        if (rc != SFE_OK) return rc;
+        if (rc != SFE_OK) {
+            g->out_of_step = k > 0;
+            return rc;
+        }
         if (k && got != *n_out) {
+            g->out_of_step = true;
             // the shards are fed in lockstep from create / reset on, so their time states agree
             set_error("rs_group_process_stream: shard %zu produced %zu outputs per channel, shard 0 %zu -- the shards' "
                       "time states have diverged (a shard handle was driven on its own?)", k, got, *n_out);
@@ -299,6 +318,7 @@ int sfe_dsp_rs_group_reset(sfe_rs_group_t grp)
         int rc = sfe_dsp_rs_reset(s.h);
         if (rc != SFE_OK) return rc;
     }
+    g->out_of_step = false;
     return SFE_OK;
 }
 

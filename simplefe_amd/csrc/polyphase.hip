@@ -430,8 +430,8 @@ __global__ __launch_bounds__(256) void poly_rt_kernel(PolyTiledArgs a)
         const T *src = in + n_org;                                        // uniform
         // The tile's requests go out before the first is looked at (eight at a time -- the first version -- left a
         // workgroup waiting for memory two or three times over per tile).  NLD rows of 256 are compiled in: 6 or 10 for tiles
-        // of up to 1536 / 2560 samples (the interpolating shapes: their tile is bounded by its OUTPUT), 18 beyond -- SP tm
-        // <= 4096 samples plus arms of up to 32 taps; what is left of a longer tile follows one request at a time.
+        // of up to 1536 / 2560 samples (the interpolating shapes: their tile is bounded by its OUTPUT), 14, 16 or 18 beyond --
+        // SP tm <= 4096 samples plus arms of up to 32 taps; what is left of a longer tile follows one request at a time.
         // (Eighteen for every shape cost the interpolators three waves of occupancy and a dozen redundant requests per
         // thread: x4 2.71 -> 3.14 ms.)  Lanes beyond the tile read its last sample and drop it: straight-line code, no
         // branch around a request (with a uniform guard per row the compiler took the requests apart again).
@@ -1251,11 +1251,15 @@ static int launch_poly_rt(const PolyTiledPlan &plan, const PolyTiledArgs &a0, in
         return SFE_OK;
     }
     const int n_tile = plan.SP * a.tm + plan.Lp;
-    const int rows_ahead = n_tile <= 1536 ? 6 : (n_tile <= 2560 ? 10 : 18);          // rows of 256 requested up front
+    // rows of 256 requested up front: the smallest compiled-in count that covers the tile (a row too many is a redundant
+    // request per thread and two registers; four too many cost /6 a tenth: 0.58 -> 0.64 with fourteen instead of eighteen)
+    const int rows_ahead = n_tile <= 1536 ? 6 : (n_tile <= 2560 ? 10 : (n_tile <= 3584 ? 14 : (n_tile <= 4096 ? 16 : 18)));
 #define SFE_RT1(C, E, U8, UPMv, MBv)                                                                 \
     do {                                                                                              \
         if (rows_ahead == 6 || U8) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8, UPMv, MBv, 6>), grid, block, sh, s, a);   \
         else if (rows_ahead == 10) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8 && false, UPMv, MBv, 10>), grid, block, sh, s, a);   \
+        else if (rows_ahead == 14) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8 && false, UPMv, MBv, 14>), grid, block, sh, s, a);   \
+        else if (rows_ahead == 16) hipLaunchKernelGGL((poly_rt_kernel<C, E, U8 && false, UPMv, MBv, 16>), grid, block, sh, s, a);   \
         else hipLaunchKernelGGL((poly_rt_kernel<C, E, U8 && false, UPMv, MBv, 18>), grid, block, sh, s, a);         \
     } while (0)
 #define SFE_RT(C, E, U8)                                                                             \
