@@ -32,8 +32,9 @@ BEFORE anything touches the GPU and relays rank 0's line.  It never prints an n_
                 timed leg of its own with parity: resample 5/3 (configs[2], in both readings of
                 "127-tap polyphase arm": the 381-tap prototype and the 127-tap prototype), decimate by 8
                 (configs[3]), the 64-channel FIR on one GPU (configs[4] at G = 1; shared filter, and a
-                different filter per channel) and the
-                complex-tap FIR.  They run BEFORE the headline's warm-up; their
+                different filter per channel), the
+                complex-tap FIR, and two rows that are not BASELINE configs: the general
+                (non-integer-step) rate 1.77 and interpolation by 2.  They run BEFORE the headline's warm-up; their
                 parity checks run after all timing.
 `precondition_s` seconds of untimed launches of whichever leg runs first, before any warm-up or timed
                 step: the chip's first ~100 ms of work after idling run 5-6 % slow (DESIGN.md
@@ -465,7 +466,7 @@ def make_rs_leg(ctx, which, log2n, in_fmt="f32", short_proto=False):
     return leg
 
 
-def make_general_rate_leg(ctx, log2n=28, rate=1.77):
+def make_general_rate_leg(ctx, log2n=28, rate=1.77, interpolate=0):
     """the general (non-integer-step) rate at bulk size -- BASELINE cfg3's 381-tap prototype in 3 phases at
     rate 1.77 (the rate of the reference's own driver, libdsp/test/test_decimate.py:24), 2^28 cf32 in.  The library's default
     dispatch takes the transform-domain kernel (poly_gen.hip).  Not a BASELINE config: an other_configs row.
@@ -482,13 +483,22 @@ def make_general_rate_leg(ctx, log2n=28, rate=1.77):
     leg.n, leg.nch, leg.n_gpu = n, 1, n
     leg.workload = "general-rate resample, rate %.2f (non-integer step %.2f), 381-tap prototype in 3 phases, 2^%d cf32 in" % (rate, rate * U, log2n)
     leg.key = "resample_rate1p77_cf32_2p%d" % log2n
+    if interpolate:
+        # the one thing `resample` does and `decimate` refuses (libdsp/resample.cxx:91 against decimate.cxx:75-78): MORE
+        # outputs than inputs.  Interpolation by `interpolate`: rate 1 / U, 32 taps per polyphase arm.
+        U = int(interpolate)
+        taps = synth.lowpass_taps(32 * U, 0.9 / U, gain=float(U))
+        rate = float(np.float32(1.0) / np.float32(U))
+        leg.name = "interpolate_x%d" % U
+        leg.workload = "interpolate x%d (resample at rate 1/%d), %d-tap prototype (32 per arm), 2^%d cf32 in" % (U, U, len(taps), log2n)
+        leg.key = "resample_x%d_cf32_2p%d" % (U, log2n)
     x = torch.empty(n * 2, dtype=torch.float32, device=dev)
     api.check(L.sfe_dsp_synth_fill(x.data_ptr(), 2 * n, synth.SEED, 0, 0, stream))
     out_cap = int(n / rate) + 4096
     leg.x = x
     leg.y = torch.empty(out_cap * 2, dtype=torch.float32, device=dev)
     leg.obj = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=True, n_channels=1, device=ctx["local_rank"])
-    leg.kernel = "poly_gen4096_kernel"
+    leg.kernel = "poly_rt1_kernel" if interpolate in (2, 3) else ("poly_rt_kernel" if interpolate else "poly_gen4096_kernel")
     leg.n_out = 0
     sp, yp = x.data_ptr(), leg.y.data_ptr()
 
@@ -502,7 +512,8 @@ def make_general_rate_leg(ctx, log2n=28, rate=1.77):
         from oracle import binding as orc
         m = 1 << 20
         r = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=True, n_channels=1, device=ctx["local_rank"])
-        r.set_algo(lib.RS_ALGO_FFT)             # the kernel the timed leg's bulk calls take, also at this size
+        if not interpolate:
+            r.set_algo(lib.RS_ALGO_FFT)         # the kernel the timed leg's bulk calls take, also at this size
         y = torch.empty((int(m / rate) + 64) * 2, dtype=torch.float32, device=dev)
         k = r.process_stream(sp, m, y.data_ptr(), y.numel() // 2, rate, stream=stream)
         torch.cuda.synchronize()
@@ -800,6 +811,7 @@ def main():
         makers = [lambda: make_rs_leg(ctx, "resample", 28), lambda: make_rs_leg(ctx, "resample", 28, short_proto=True),
                   lambda: make_rs_leg(ctx, "decimate", 30),
                   lambda: make_general_rate_leg(ctx),
+                  lambda: make_general_rate_leg(ctx, interpolate=2),
                   lambda: make_fir_leg(ctx, "fir_64ch", synth.taps_cfg2(), 1 << 24, 64),
                   lambda: make_fir_leg(ctx, "fir_64ch_pctaps", synth.taps_per_channel(64), 1 << 24, 64, per_channel=True,
                                        x_share=next(l.x for l in others if l.name == "fir_64ch")),
