@@ -498,7 +498,7 @@ def make_general_rate_leg(ctx, log2n=28, rate=1.77, interpolate=0):
     leg.x = x
     leg.y = torch.empty(out_cap * 2, dtype=torch.float32, device=dev)
     leg.obj = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=True, n_channels=1, device=ctx["local_rank"])
-    leg.kernel = "poly_rt1_kernel" if interpolate in (2, 3) else ("poly_rt_kernel" if interpolate else "poly_gen4096_kernel")
+    leg.kernel = "poly_rt1_kernel" if interpolate else "poly_gen4096_kernel"
     leg.n_out = 0
     sp, yp = x.data_ptr(), leg.y.data_ptr()
 

@@ -1132,7 +1132,7 @@ static bool poly_tiled_compiled(int SP, int UP, int Lp)
 // ---- poly_rt_kernel's tile: m per workgroup and the LDS row pitch --------------------------------
 constexpr int RT_MAX_SP = 64, RT_MAX_UP = 8, RT_LDS_MAX = 60 * 1024;
 #ifndef RT1_MAX_UP
-#define RT1_MAX_UP 3
+#define RT1_MAX_UP 8
 #endif
 // tm m per tile so that the larger of the input and the output tile is ~4096 samples: a power of two of 256 .. 2048 m
 // (a thread then runs 1, 2, 4 or 8 m, whole groups of MB), multiples of 64 below
@@ -1216,8 +1216,8 @@ static int launch_poly_rt(const PolyTiledPlan &plan, const PolyTiledArgs &a0, in
     // m per thread run together: as many as the tile gives a thread, up to 4 (2 for eight phase sums: registers)
     const int per_thread = (a.tm + 255) / 256;
     // SP = 1, UP >= 2 -- the pure interpolators: pairs of consecutive m per thread (poly_rt1_kernel)
-    // (UP <= 3: from x4 on the launch is bound by its stores -- 32 of every 40 bytes -- and a thread's 2 UP outputs, 16 bytes
-    // per store at a stride of 16 UP, are a worse pattern for them than poly_rt_kernel's UP: x4 2.68 -> 2.96 ms)
+    // (every UP since the outputs leave through the waves' LDS regions; with a thread's 2 UP outputs stored 16 bytes at a stride
+    // of 16 UP the pairs LOST from x4 on, where the launch is all stores: 2.68 -> 2.96 ms; with the regions x4 2.49 -> 2.16)
     if (plan.SP == 1 && plan.UP >= 2 && plan.UP <= RT1_MAX_UP && !(plan.Lp & 1) && !(a.tm & 1) && a.tm + plan.Lp <= 2560) {
         const bool six = a.tm + plan.Lp <= 1536;
         size_t sh1 = ((size_t)(a.tm + plan.Lp) * esz + 15) & ~(size_t)15;
@@ -1235,7 +1235,12 @@ static int launch_poly_rt(const PolyTiledPlan &plan, const PolyTiledArgs &a0, in
     do {                                                                                              \
         switch (plan.UP) {                                                                            \
         case 2: SFE_R1B(C, E, U8, 2, 2); break;                                                       \
-        default: SFE_R1B(C, E, U8, 3, 2); break;                                                      \
+        case 3: SFE_R1B(C, E, U8, 3, 2); break;                                                       \
+        case 4: SFE_R1B(C, E, U8, 4, 2); break;                                                       \
+        case 5: SFE_R1B(C, E, U8, 5, 1); break;                                                       \
+        case 6: SFE_R1B(C, E, U8, 6, 1); break;                                                       \
+        case 7: SFE_R1B(C, E, U8, 7, 1); break;                                                       \
+        default: SFE_R1B(C, E, U8, 8, 1); break;                                                      \
         }                                                                                             \
     } while (0)
         if (in_u8) {
