@@ -10,11 +10,11 @@ from simplefe_amd import api, synth
 log2n = int(os.environ.get("LOG2N", "24"))
 n = 1 << log2n
 x = api.DeviceArray(2 * n); x.fill_synth(synth.SEED)
-cap = int(n / 1.77) + 8192
+cap = int(n / 0.77) + 131072         # room for the interpolating rate too (0.77: the rate of libdsp/test/test_resample.py:24)
 y = api.DeviceArray(2 * cap)
 # a short filter (31 taps in 4 phases: 8 per dot product) and BASELINE cfg3's (381 taps in 3 phases: 127 per dot product)
 shapes = (("31 taps, U = 4", synth.lowpass_taps(31, 0.18, gain=4.0), 4, (1.77, 2.0)),
-          ("381 taps, U = 3", synth.taps_cfg3(), 3, (1.77,)))
+          ("381 taps, U = 3", synth.taps_cfg3(), 3, (1.77, 0.77)))
 if os.environ.get("GENERAL_ONLY"):         # counter passes: the long filter alone (the transform-domain kernel's shape)
     shapes = shapes[1:]
 timer = api.Timer()

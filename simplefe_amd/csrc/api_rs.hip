@@ -596,11 +596,11 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         r->plan_stream = s;
         sa.segs = r->d_segs;
         sa.chunks = static_cast<const SegChunk *>(r->d_chunks);
-        // Bulk calls of complex streams at rate >= 1 in fused arithmetic: the transform-domain kernel (poly_gen.hip) --
+        // Bulk calls of complex streams in fused arithmetic, at any rate: the transform-domain kernel (poly_gen.hip) --
         // all U phases of every input by one forward and U inverse 4096-point transforms, outputs picked and blended from
         // LDS by the same runs.  sfe_dsp_rs_set_algo(SFE_RS_ALGO_DIRECT) and the exact mode keep poly_seg_kernel.
         rc = SFE_ESTATE;
-        if (!exhausted && !r->exact_stream && r->data_complex && !r->in_u8 && r->fft_mode >= 0 && stepf >= (float)r->U &&
+        if (!exhausted && !r->exact_stream && r->data_complex && !r->in_u8 && r->fft_mode >= 0 &&
             (r->fft_mode > 0 || (n_in >= ((size_t)1 << 16) && r->plen >= 12))) {
             if (!r->gen_tried) {
                 // spectra of the U phase filters (taps[i U + j], i < plen; one zero behind so that the overlap the FIR

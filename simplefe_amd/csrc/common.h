@@ -258,6 +258,7 @@ struct PolyGenArgs {
     const SegChunk *chunks;
     long long   n_in, in_stride, out_stride;
     int         hl, U, plen, ovl, blksize, n_chunks;
+    int         adv;            // input samples a block owns (launcher: 4096 - ovl, fewer for rates below ~1)
     // (the diagnostic persistent form only, diag/poly_gen_persistent.hip: blocks per channel in a launch's list, where the
     // list starts, channels, blocks dealt by a device counter)
     long long   nblk, blk_first;

@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096p_kernel(Po
 }  // namespace
 
 // SFE_ESTATE: the shape is outside what this kernel takes (the caller uses poly_seg_kernel)
-int poly_gen_outputs_per_block(int U, int ovl, float step);
+int poly_gen_outputs_per_block(int U, int adv, float step);
 
 int launch_poly_gen_persistent(const PolyGenArgs &a, int max_runs_two_calls, float step, int n_channels, hipStream_t s, int tickets)
 {
@@ -475,7 +475,7 @@ int launch_poly_gen_persistent(const PolyGenArgs &a, int max_runs_two_calls, flo
         return SFE_ESTATE;
     // the table's fields: 5 bits per phase; a call's positions as 32-bit integers
     if (a.U > 32 || (long long)a.blksize * a.U >= 0x7fffffffLL) return SFE_ESTATE;
-    const int per_block = poly_gen_outputs_per_block(a.U, a.ovl, step);
+    const int per_block = poly_gen_outputs_per_block(a.U, FFT_N - a.ovl, step);
     if (per_block > 256 * 16) return SFE_ESTATE;
     const long long A = FFT_N - a.ovl;
     const long long nblk = (a.n_in + A - 1) / A;

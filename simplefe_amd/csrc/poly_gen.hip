@@ -13,7 +13,7 @@
 //
 // One workgroup = one block of the stream, the FIR kernel's transform (fir_fft.hip: N = 16 x 16 x 16, thread t
 // owns 16 complex values, padded exchange buffer, the same twiddle tables and the same spectrum layout):
-//   block b transforms x[b A - ovl .. b A - ovl + 4096), A = 4096 - ovl, ovl >= plen a multiple of 16 (the outputs are
+//   block b transforms x[b A - ovl .. b A - ovl + 4096), A <= 4096 - ovl (all of it for rates >= ~1), ovl >= plen a multiple of 16 (the outputs are
 //   picked from LDS sample by sample, so the overlap need not be whole rows of 256 as in the FIR kernel), and
 //   OWNS the outputs whose first phase sample is s(p) with floor(p / U) in [b A - 1, (b + 1) A - 1): both
 //   s(p) and s(p + 1) then lie in what the block's inverse transforms produce validly.
@@ -27,7 +27,7 @@
 //   3. the outputs are stored, lanes = consecutive outputs
 // (pos, mu) are the reference's own sequence, bit for bit (the runs reproduce the float32 recurrence);
 // the arithmetic is fused and transform-domain: rel-RMS ~3e-7 against the oracle, the exact mode stays on
-// poly_seg_kernel.  Complex float32 streams, rate >= 1 (at most one output per owned input sample).
+// poly_seg_kernel.  Complex float32 streams, any rate the reference takes (>= 1 / U).
 #include <stdint.h>
 #ifdef SFE_DIAG
 #include <stdlib.h>
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
     const v2f *in = static_cast<const v2f *>(a.in) + (size_t)ch * a.in_stride;
     const v2f *hist = static_cast<const v2f *>(a.hist) + (size_t)ch * a.hl;
     v2f *out = static_cast<v2f *>(a.out) + (size_t)ch * a.out_stride;
-    const int A = FFT_N - a.ovl, U = a.U;
+    const int A = a.adv, U = a.U;                // input samples a block owns: 4096 - ovl, fewer where the outputs would not fit (launcher)
 
     // ---- the block's 16 rows (thread t: samples base + t + 256 r): requested first, they land under step 0
     v2f nx[16];
@@ -342,29 +342,38 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
 int launch_poly_gen_persistent(const PolyGenArgs &a, int max_runs_two_calls, float step, int n_channels, hipStream_t s, int tickets);
 #endif
 
-int poly_gen_outputs_per_block(int U, int ovl, float step)
+int poly_gen_outputs_per_block(int U, int adv, float step)
 {
     // consecutive outputs are >= step (1 - 2^-22) apart on the upsampled grid
-    const double span = (double)U * (FFT_N - ovl);
+    const double span = (double)U * adv;
     return (int)(span / ((double)step * (1.0 - 1.0 / 4194304.0))) + 2;
 }
 
 // SFE_ESTATE: the shape is outside what this kernel takes (the caller uses poly_seg_kernel)
-int launch_poly_gen(const PolyGenArgs &a, int max_runs_two_calls, float step, int n_channels, hipStream_t s)
+int launch_poly_gen(const PolyGenArgs &a0, int max_runs_two_calls, float step, int n_channels, hipStream_t s)
 {
-    if (a.n_chunks <= 0) return SFE_OK;
-    if (a.ovl < a.plen || a.ovl >= FFT_N / 2 || (a.ovl & 15) || a.blksize < FFT_N - a.ovl || max_runs_two_calls > GEN_MAX_RUNS)
-        return SFE_ESTATE;
+    if (a0.n_chunks <= 0) return SFE_OK;
+    PolyGenArgs a = a0;
+    if (a.ovl < a.plen || a.ovl >= FFT_N / 2 || (a.ovl & 15) || max_runs_two_calls > GEN_MAX_RUNS) return SFE_ESTATE;
     // the table's fields: 5 bits per phase; a call's positions as 32-bit integers
     if (a.U > 32 || (long long)a.blksize * a.U >= 0x7fffffffLL) return SFE_ESTATE;
+    // A block owns `adv` input samples: all 4096 - ovl its transform yields validly while their outputs fit the table
+    // (256 x 16), fewer below that -- rates under ~1, MORE outputs than inputs: what `resample` takes and `decimate` refuses,
+    // libdsp/resample.cxx:91 -- down to the reference's own limit rate = 1 / U (step 1: every upsampled position an output).
+    // The transform count per input sample grows as adv shrinks; the direct form's cost grows with the OUTPUT count, faster.
+    a.adv = FFT_N - a.ovl;
+    if (poly_gen_outputs_per_block(a.U, a.adv, step) > 256 * 16) {
+        a.adv = (int)((256.0 * 16 - 2) * (double)step * (1.0 - 1.0 / 4194304.0) / a.U) & ~15;
+        if (a.adv < 512 || poly_gen_outputs_per_block(a.U, a.adv, step) > 256 * 16) return SFE_ESTATE;
+    }
+    if (a.blksize < a.adv) return SFE_ESTATE;                 // a block overlaps at most two reference calls
 #ifdef SFE_DIAG
     // the persistent form with the next block fetched ahead (measured and not kept: diag/poly_gen_persistent.hip)
     if (const char *e = getenv("SFE_GEN_PERSISTENT"))
-        if (atoi(e) > 0) return launch_poly_gen_persistent(a, max_runs_two_calls, step, n_channels, s, atoi(e) > 1);
+        if (atoi(e) > 0 && a.adv == FFT_N - a.ovl) return launch_poly_gen_persistent(a, max_runs_two_calls, step, n_channels, s, atoi(e) > 1);
 #endif
-    const int per_block = poly_gen_outputs_per_block(a.U, a.ovl, step);
-    if (per_block > 256 * 16) return SFE_ESTATE;
-    const long long A = FFT_N - a.ovl;
+    const int per_block = poly_gen_outputs_per_block(a.U, a.adv, step);
+    const long long A = a.adv;
     const long long nblk = (a.n_in + A - 1) / A;
     if (nblk > 0x7fffffffLL) return SFE_ESTATE;
     dim3 grid((unsigned)nblk, (unsigned)n_channels), block(256);

@@ -34,10 +34,12 @@ def _pair(api, L, taps, U, B, cplx=True, nch=1):
     return exact, fast
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", list(range(24)) + list(range(100, 116)))
 def test_transform_domain_general_rate_random_shapes(api, L, seed):
+    """seeds >= 100: rates BELOW 1 -- more outputs than inputs, down to the reference's own limit 1 / U
+    (libdsp/resample.cxx:91): a block then owns fewer input samples than its transform yields, so that its outputs fit."""
     rng = np.random.default_rng(7000 + seed)
-    U = int(rng.choice([1, 2, 3, 4, 5, 8]))
+    U = int(rng.choice([1, 2, 3, 4, 5, 8]) if seed < 100 else rng.choice([2, 3, 4, 5, 8]))
     plen = int(rng.choice([1, 8, 43, 127, 128, 255, 256, 257, 300]))
     n_taps = U * plen - int(rng.integers(0, U))
     B = int(rng.choice([4096, 4096, 5000, 16384, 3840]))          # calls at least one block advance long (shorter: the direct kernel)
@@ -45,6 +47,12 @@ def test_transform_domain_general_rate_random_shapes(api, L, seed):
     rate = float(np.float32(rng.uniform(1.0, 6.0)))
     if seed % 6 == 0:
         rate = float(np.float32(1.0 + rng.uniform(0.0, 0.01)))        # just above 1: close to one output per input sample
+    if seed >= 100:
+        rate = float(np.float32(rng.uniform(1.0 / U, 1.0)))
+        if seed % 4 == 0:
+            rate = float(np.float32(1.0 / U) * np.float32(1.0 + rng.uniform(0.0, 0.003)))       # next to the limit: a step of ~1
+        while float(np.float32(rate) * np.float32(U)) < 1.0 or rate < 1.0 / U:                  # the reference refuses rate < 1 / U
+            rate = float(np.nextafter(np.float32(rate), np.float32(2.0)))
     nch = int(rng.choice([1, 1, 3]))
     n = int(rng.choice([700, 4096, 12345, 40000, 150001]))
     x = np.stack([synth.synth_cf32(n, ch=300 + seed * 4 + c) for c in range(nch)])
@@ -56,7 +64,7 @@ def test_transform_domain_general_rate_random_shapes(api, L, seed):
         m = a1 - a0
         seg = np.ascontiguousarray(x[:, 2 * a0: 2 * a1])
         d_in = api.DeviceArray.from_numpy(seg)
-        cap = int(m / rate) + 16
+        cap = int(m / rate) + 16 + 2 * (m // B + 1)
         de, df = api.DeviceArray(2 * cap * nch), api.DeviceArray(2 * cap * nch)
         ke = exact.process_stream(d_in, m, de, cap, rate)
         kf = fast.process_stream(d_in, m, df, cap, rate)
@@ -88,8 +96,9 @@ def test_transform_domain_general_rate_against_the_oracle(api, L, orc, g4, rate)
 
 
 def test_default_dispatch_takes_the_transform_kernel_for_bulk_calls_only(api, L):
-    """AUTO: bulk complex calls at rate >= 1 in fused arithmetic take the transform-domain kernel; small calls, the
-    exact mode, real streams, rates below 1 and SFE_RS_ALGO_DIRECT keep the direct kernel -- all of them the same law."""
+    """AUTO: bulk complex calls in fused arithmetic take the transform-domain kernel (round 4's second pass: at any rate the
+    reference takes, below 1 too); small calls, the exact mode, real streams and SFE_RS_ALGO_DIRECT keep the direct kernel
+    -- all of them the same law."""
     taps, U, rate = synth.taps_cfg3(), 3, float(np.float32(1.77))
     n = 1 << 18
     x = synth.synth_cf32(n, ch=5)
