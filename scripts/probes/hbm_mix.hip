@@ -150,6 +150,15 @@ int main(int argc, char **argv)
         timeit("mix 8:1, tile 8192 samples (32 loads per lane)", 1.125 * bytes, [&] { hipLaunchKernelGGL((k_mix81<32>), dim3((unsigned)(n8 / (32 * 256))), dim3(256), 0, 0, (const v2f *)in, (v2f *)out, n8 / (32 * 256)); });
         return 0;
     }
+    if (argc > 1 && argv[1][0] == 'p') {       // a copy IN PLACE (every line read, then written back) against the same copy between two buffers
+        for (int g : {2048, 8192, 65536}) {
+            printf("-- grid %d x 256 threads\n", g);
+            timeit("copy   8 B lanes, nt, 16 deep, in -> out", 2.0 * bytes, [&] { hipLaunchKernelGGL((k_copy<v2f, true, true, 16>), dim3(g), dim3(256), 0, 0, (const v2f *)in, (v2f *)out, bytes / 8); });
+            timeit("copy   8 B lanes, nt, 16 deep, in place", 2.0 * bytes, [&] { hipLaunchKernelGGL((k_copy<v2f, true, true, 16>), dim3(g), dim3(256), 0, 0, (const v2f *)in, (v2f *)in, bytes / 8); });
+            timeit("copy  16 B lanes, nt, 8 deep, in place", 2.0 * bytes, [&] { hipLaunchKernelGGL((k_copy<v4f, true, true, 8>), dim3(g), dim3(256), 0, 0, (const v4f *)in, (v4f *)in, bytes / 16); });
+        }
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'i') {       // the interpolators' mixes: 2^27 / 2^26 / 2^25 samples in so that the output stays 2 GiB
         printf("-- one workgroup per tile (32 KiB written per workgroup)\n");
         { const size_t t = (bytes / 2 / 8) / (8 * 256); timeit("mix 1:2, 8 x 8 B loads, 16 x 16 B stores", 1.5 * bytes, [&] { hipLaunchKernelGGL((k_mix1u<2, 8>), dim3((unsigned)t), dim3(256), 0, 0, (const v2f *)in, (v4f *)out, t); }); }
