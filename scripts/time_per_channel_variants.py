@@ -8,7 +8,10 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from simplefe_amd import api, lib, synth  # noqa: E402
+from simplefe_amd import lib  # noqa: E402
+if os.environ.get("SFE_LIB"):                      # a saved build to compare against
+    lib.LIB_PATH = os.environ["SFE_LIB"]
+from simplefe_amd import api, synth  # noqa: E402
 
 nch, n = 64, 1 << 24
 x = api.DeviceArray(2 * n * nch)

@@ -82,6 +82,9 @@ struct FirFftArgs {
                           // draw transforms from; zero between launches
     unsigned    total;    // set by the launcher: transforms over all channels (channel-major tickets)
     unsigned    tgroups;  // set by the launcher: counters in use (workgroup b draws from counter b % tgroups)
+    unsigned    ch_groups; // set by the launcher (per-channel spectra, channels a multiple of tgroups): group g draws the transforms of
+                           // channels g, g + tgroups, ... channel by channel, so that a workgroup changes channel -- reloads its
+                           // spectrum registers -- once per channels / tgroups of the launch instead of every few transforms
     long long   hs_stride; // 0: one spectrum for every channel; else channel c's spectra start c*hs_stride elements after hs (per-channel taps: held in registers like the shared one and reloaded, 16 loads per thread, when the workgroup's next transform belongs to another channel)
     unsigned    tqs;      // set by the launcher: a group draws runs of 2^tqs CONSECUTIVE transforms (their halos meet in its L2)
     unsigned    halo_keep; // set by the launcher: mask of input rows loaded WITHOUT the nontemporal hint (0x8001: the two rows a neighbour re-reads)

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
     char *out_c;
     auto in_of = [&](int c) -> const char * { return static_cast<const char *>(a.in) + (size_t)c * a.in_stride * ISZ; };
     v2f hreg[16];
-    auto set_channel = [&](int c) {
+    auto load_spectrum = [&](int c) {
         if constexpr (HCH) {
 #pragma unroll
             for (int k = 0; k < 16; k++) {
@@ -176,11 +176,14 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
                 asm volatile("" : "+v"(hreg[k]));
             }
         }
+    };
+    auto set_channel = [&](int c) {
         in_c = in_of(c);
         // 10-bit output: the channel's floats (2 per complex sample) in whole groups of 4 -> 5 bytes
         out_c = static_cast<char *>(a.out) + (OUT_TX10 ? (size_t)c * (a.out_stride * (OUT_C ? 2 : 1) / 4) * 5 : (size_t)c * a.out_stride * (OUT_C ? 8 : 4));
         hist_c = static_cast<const char *>(a.hist) + (size_t)c * a.hist_len * (IN_C ? 8 : 4);
     };
+    load_spectrum(ch);
     set_channel(ch);
 
     // Per-thread twiddle bases, resident for the whole launch.  A twiddle with exponent
@@ -216,7 +219,10 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
     // group g owns the runs g, g + tg, ... of Q = 2^tqs consecutive transforms; ticket c of the group is
     // transform ((c / Q) tg + g) Q + c % Q.  The group's share: Q per complete row of tg runs + its part of the last row.
     const unsigned Q = 1u << a.tqs, row = tg << a.tqs, rem = a.total % row;
-    const unsigned mine = (a.total / row << a.tqs) + (rem > grp * Q ? (rem - grp * Q < Q ? rem - grp * Q : Q) : 0u);
+    // (per-channel spectra, FirFftArgs::ch_groups: the group owns whole channels, grp, grp + tg, ...)
+    const bool by_channel = HCH && a.ch_groups;
+    const unsigned mine = by_channel ? (a.total / (unsigned)a.nblk / tg) * (unsigned)a.nblk
+                                     : (a.total / row << a.tqs) + (rem > grp * Q ? (rem - grp * Q < Q ? rem - grp * Q : Q) : 0u);
     const unsigned last_draw = mine + (gridDim.x - grp + tg - 1u) / tg - 1u;
     // a launch with no more transforms than workgroups (the per-block host calls) deals them by
     // blockIdx and leaves the counters alone: two atomic round trips less on a 10 us kernel
@@ -233,6 +239,11 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
     auto draw_finish = [&](unsigned c) -> unsigned {
         if (few) return 0xFFFFFFFFu;
         if (c == last_draw) __hip_atomic_store(my_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (by_channel) {
+            if (c >= mine) return 0xFFFFFFFFu;
+            const unsigned i = c / (unsigned)a.nblk;                     // the group's i-th channel
+            return (grp + tg * i) * (unsigned)a.nblk + (c - i * (unsigned)a.nblk);
+        }
         const unsigned long long k = (((unsigned long long)(c >> a.tqs) * tg + grp) << a.tqs) + (c & (Q - 1u));
         return k < a.total ? (unsigned)k : 0xFFFFFFFFu;
     };
@@ -402,6 +413,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         if (kt >= a.total) return;            // uniform: more workgroups than transforms
         ch = (int)(kt / nblk32);
         blk = kt - (unsigned)ch * nblk32;
+        load_spectrum(ch);
         set_channel(ch);
     } else if (blk >= a.nblk) return;
     if (PREFETCH) load_rows(nx, blk);
@@ -489,6 +501,11 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             nb = blk + gridDim.x;
             more = nb < a.nblk;
         }
+        // per-channel spectra: this transform's has just been multiplied in -- if the next transform belongs to another
+        // channel its sixteen bins are requested HERE, under the two inverse stages and the stores still to come, and in
+        // front of the next transform's rows (round 4; until then they were requested after the stores, at the top of the
+        // next transform: with channel-major tickets every ~6th transform of a workgroup at 64 x 2^24, 3.6-5.7 % of the launch)
+        if (HCH && more && nch != ch) load_spectrum(nch);
         if (PREFETCH && more) load_rows(nx, nb);   // see above
         // ---- I2: gather k1 for (k2=hi, n0=lo)
         fresh_b();
@@ -791,6 +808,10 @@ int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in
     if (const char *e = getenv("SFE_FIR_TGROUPS")) a.tgroups = atoi(e) >= 1 && atoi(e) <= FIR_TICKET_GROUPS_MAX ? atoi(e) : a.tgroups;
 #endif
     if ((long long)a.tgroups > gt) a.tgroups = (unsigned)gt;      // every group needs a workgroup to draw for it
+    a.ch_groups = a.hs_stride != 0 && a.tgroups == FIR_TICKET_GROUPS && n_channels >= (int)a.tgroups && n_channels % (int)a.tgroups == 0;
+#ifdef SFE_DIAG
+    if (const char *e = getenv("SFE_FIR_CH_GROUPS")) a.ch_groups = a.ch_groups && atoi(e) != 0;      // A/B: 0 = tickets across the channels as for a shared filter
+#endif
     // runs of 8: seven of eight 2 KiB halos are re-read on the XCD whose L2 has just seen them
     // (FETCH_SIZE per launch 4.446 -> see profiles/r02; -1.5 % kernel time, `X` against `X^3`)
     a.tqs = 3;
