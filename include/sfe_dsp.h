@@ -325,12 +325,12 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
  * 64 : 8, the runtime-shape one).  DIRECT: never a transform-domain kernel.  FFT: the
  * transform-domain kernel wherever the shape is instantiated.  MFMA: the f32 matrix-pipe form of the
  * direct kernel (measured slower, kept as evidence: DESIGN.md 4.2b).
- * Any other step (the general rate) -- AUTO: complex float32 calls of >= 65536 samples with >= 12
- * taps per phase take the 4096-point transform kernel (all phases of every input
- * sample by one forward and `upsample` inverse transforms, blended by the reference's own (pos, mu)
- * sequence), at any rate the class accepts -- below 1 too, down to 1 / upsample; FFT: at any size;
- * DIRECT, the exact mode, real or u8 streams: the direct kernel.  The number of outputs per call is
- * the reference's in every case.
+ * Any other step (the general rate) -- AUTO: float32 calls (complex or real) of >= 65536 samples
+ * with >= 12 taps per phase take the 4096-point transform kernel (all phases of every
+ * input sample by one forward and `upsample` inverse transforms, blended by the reference's own
+ * (pos, mu) sequence; a real stream's transforms carry two blocks each), at any rate the class
+ * accepts -- below 1 too, down to 1 / upsample; FFT: at any size; DIRECT, the exact mode and u8
+ * streams: the direct kernel.  The number of outputs per call is the reference's in every case.
  * The library reads no environment variable. */
 #define SFE_RS_ALGO_AUTO    0
 #define SFE_RS_ALGO_DIRECT  1

@@ -13,6 +13,7 @@ timeout -k 10 300 python3 bench.py --gpus 1 --single-process --steps 20 --warmup
 timeout -k 10 300 python3 scripts/time_shapes.py > $O/shapes.txt 2>&1 || exit 1
 timeout -k 10 120 scripts/probes/hbm_mix i > $O/hbm_mix_interpolators.txt 2>&1
 LOG2N=28 timeout -k 10 300 python3 scripts/time_general_rate.py > $O/general_rate.txt 2>&1 || exit 1
+timeout -k 10 200 python3 scripts/time_real_general.py > $O/general_rate_real.txt 2>&1
 timeout -k 10 200 python3 scripts/time_block_api.py > $O/block_api_latency.txt 2>&1
 timeout -k 10 200 python3 scripts/time_pipe.py > $O/host_pipe.txt 2>&1
 echo collected

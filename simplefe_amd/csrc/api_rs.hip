@@ -596,11 +596,11 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         r->plan_stream = s;
         sa.segs = r->d_segs;
         sa.chunks = static_cast<const SegChunk *>(r->d_chunks);
-        // Bulk calls of complex streams in fused arithmetic, at any rate: the transform-domain kernel (poly_gen.hip) --
+        // Bulk calls of float32 streams (complex or real) in fused arithmetic, at any rate: the transform-domain kernel (poly_gen.hip) --
         // all U phases of every input by one forward and U inverse 4096-point transforms, outputs picked and blended from
         // LDS by the same runs.  sfe_dsp_rs_set_algo(SFE_RS_ALGO_DIRECT) and the exact mode keep poly_seg_kernel.
         rc = SFE_ESTATE;
-        if (!exhausted && !r->exact_stream && r->data_complex && !r->in_u8 && r->fft_mode >= 0 &&
+        if (!exhausted && !r->exact_stream && !r->in_u8 && r->fft_mode >= 0 &&
             (r->fft_mode > 0 || (n_in >= ((size_t)1 << 16) && r->plen >= 12))) {
             if (!r->gen_tried) {
                 // spectra of the U phase filters (taps[i U + j], i < plen; one zero behind so that the overlap the FIR
@@ -638,10 +638,12 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
                 ga.ovl = (r->plen + 15) & ~15;              // >= plen; the spectra do not depend on it
                 ga.blksize = r->blksize;
                 ga.n_chunks = (int)chunks.size();
-                int max_runs = 0;
+                ga.real = r->data_complex ? 0 : 1;
+                int max_runs = 0;              // over any two (a real stream's pairs of blocks: three) consecutive calls
                 for (size_t i = 0; i < chunks.size(); i++) {
-                    const int two = chunks[i].n_seg + (i + 1 < chunks.size() ? chunks[i + 1].n_seg : 0);
-                    max_runs = two > max_runs ? two : max_runs;
+                    int sum = chunks[i].n_seg + (i + 1 < chunks.size() ? chunks[i + 1].n_seg : 0);
+                    if (ga.real && i + 2 < chunks.size()) sum += chunks[i + 2].n_seg;
+                    max_runs = sum > max_runs ? sum : max_runs;
                 }
                 rc = launch_poly_gen(ga, max_runs, stepf, r->n_channels, s);
             }

@@ -262,13 +262,14 @@ struct PolyGenArgs {
     long long   n_in, in_stride, out_stride;
     int         hl, U, plen, ovl, blksize, n_chunks;
     int         adv;            // input samples a block owns (launcher: 4096 - ovl, fewer for rates below ~1)
+    int         real;           // a real float32 stream: two consecutive blocks per transform (poly_gen.hip: REAL)
     // (the diagnostic persistent form only, diag/poly_gen_persistent.hip: blocks per channel in a launch's list, where the
     // list starts, channels, blocks dealt by a device counter)
     long long   nblk, blk_first;
     int         n_channels, tickets;
 };
 // SFE_ESTATE: outside what the kernel takes (caller: launch_poly_seg)
-int launch_poly_gen(const PolyGenArgs &a, int max_runs_two_calls, float step, int n_channels, hipStream_t s);
+int launch_poly_gen(const PolyGenArgs &a, int max_runs, float step, int n_channels, hipStream_t s);
 
 // new_hist[i] = virtual[n_in - hl + i], virtual = old_hist ++ in  (per channel)
 int launch_history_update(const void *in, long long n_in, long long in_stride,

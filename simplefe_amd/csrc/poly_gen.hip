@@ -27,8 +27,10 @@
 //   3. the outputs are stored, lanes = consecutive outputs
 // (pos, mu) are the reference's own sequence, bit for bit (the runs reproduce the float32 recurrence);
 // the arithmetic is fused and transform-domain: rel-RMS ~3e-7 against the oracle, the exact mode stays on
-// poly_seg_kernel.  Complex float32 streams, any rate the reference takes (>= 1 / U).
+// poly_seg_kernel.  Complex and real float32 streams (REAL below), any rate the reference takes (>= 1 / U).
 #include <stdint.h>
+
+#include <type_traits>
 #ifdef SFE_DIAG
 #include <stdlib.h>
 #endif
@@ -53,42 +55,69 @@ constexpr int GEN_MAX_RUNS = 1024;       // runs of the (at most two) calls a bl
 // Registers: X (32) + the transform's working set (32) + the spectrum loads in flight + KPT accumulators is what fits three
 // workgroups per CU (<= 168 VGPRs); so the twiddle bases are re-read from L2 where a stage needs them (24 VGPRs) and each
 // thread's (position, mu) table sits in LDS behind the exchange buffer, [q][thread] (2 KPT VGPRs).
-template <int KPT>
+// REAL: a real float32 stream -- libdsp's native type (the reference's classes take float*).  The taps are real, so ONE
+// complex transform carries TWO consecutive blocks, z = x_A + j x_B: Re(IFFT(Z H_j)) is block A's phase j, Im block B's.  A
+// workgroup then owns the 2 A input samples of the pair -- one contiguous range of positions, up to three reference calls --
+// and each table entry says which half its two samples are read from; twice the outputs per transform, KPT up to 22
+// (two workgroups per CU).  The direct kernel ran such a stream at 0.05 of the roofline (2^29 samples, rate 1.77, 381 taps
+// in 3 phases: 8.65 ms).
+template <int KPT, bool REAL>
 __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(PolyGenArgs a)
 {
+    constexpr int NC = REAL ? 3 : 2;             // reference calls a block (pair) can overlap: its span <= (REAL ? 2 : 1) x blksize
+    typedef typename std::conditional<REAL, float, v2f>::type E;      // a sample
     __shared__ v2f lds[FFT_ROWS * LDS_K2_STRIDE];
     __shared__ unsigned tab_pos[KPT * 256];
     __shared__ float tab_mu[KPT * 256];
+    __shared__ int s_bound[2 * NC], s_run[NC];
     const unsigned t = threadIdx.x, lo = t & 15u, hi = t >> 4;
     const int ch = blockIdx.y;
-    const long long blk = blockIdx.x;
-    const v2f *in = static_cast<const v2f *>(a.in) + (size_t)ch * a.in_stride;
-    const v2f *hist = static_cast<const v2f *>(a.hist) + (size_t)ch * a.hl;
-    v2f *out = static_cast<v2f *>(a.out) + (size_t)ch * a.out_stride;
+    const long long blk = (REAL ? 2 : 1) * (long long)blockIdx.x;      // REAL: the pair's first block
+    const E *in = static_cast<const E *>(a.in) + (size_t)ch * a.in_stride;
+    const E *hist = static_cast<const E *>(a.hist) + (size_t)ch * a.hl;
+    E *out = static_cast<E *>(a.out) + (size_t)ch * a.out_stride;
     const int A = a.adv, U = a.U;                // input samples a block owns: 4096 - ovl, fewer where the outputs would not fit (launcher)
 
     // ---- the block's 16 rows (thread t: samples base + t + 256 r): requested first, they land under step 0
     v2f nx[16];
     const long long base = blk * A - a.ovl;
-    if (base >= 0 && base + FFT_N <= a.n_in) {
+    if constexpr (!REAL) {
+        if (base >= 0 && base + FFT_N <= a.n_in) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) nx[r] = __builtin_nontemporal_load(in + base + 256 * r + t);
+            for (int r = 0; r < 16; r++) nx[r] = __builtin_nontemporal_load(in + base + 256 * r + t);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const long long i = base + 256 * r + (long long)t;
+                if (i >= 0) nx[r] = i < a.n_in ? in[i] : (v2f){0.0f, 0.0f};
+                else nx[r] = i >= -(long long)a.hl ? hist[a.hl + i] : (v2f){0.0f, 0.0f};
+            }
+        }
     } else {
+        if (base >= 0 && base + A + FFT_N <= a.n_in) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const long long i = base + 256 * r + (long long)t;
-            if (i >= 0) nx[r] = i < a.n_in ? in[i] : (v2f){0.0f, 0.0f};
-            else nx[r] = i >= -(long long)a.hl ? hist[a.hl + i] : (v2f){0.0f, 0.0f};
+            for (int r = 0; r < 16; r++)
+                nx[r] = (v2f){__builtin_nontemporal_load(in + base + 256 * r + t), __builtin_nontemporal_load(in + base + A + 256 * r + t)};
+        } else {
+            auto at = [&](long long i) -> float {
+                if (i >= 0) return i < a.n_in ? in[i] : 0.0f;
+                return i >= -(long long)a.hl ? hist[a.hl + i] : 0.0f;
+            };
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const long long i = base + 256 * r + (long long)t;
+                nx[r] = (v2f){at(i), at(i + A)};
+            }
         }
     }
 
-    // ---- 0. which outputs are this block's, and where each of this thread's sits
+    // ---- 0. which outputs are this block's, and where each of them sits
     // positions on the upsampled grid, absolute (relative to the launch's first input sample):
-    // P = in_off U + floor(t); the block owns Plo <= P < Phi.  Call c emitted the outputs with
+    // P = in_off U + floor(t); the block (pair) owns Plo <= P < Phi.  Call c emitted the outputs with
     // c B U - 1 <= P < (c + 1) B U - 1 (its leftover output sits at relative position -1).
-    const long long Plo = (long long)U * (blk * A - 1), Phi = Plo + (long long)U * A;
+    const long long Plo = (long long)U * (blk * A - 1), Phi = Plo + (long long)(REAL ? 2 : 1) * U * A;
     const long long BU = (long long)a.blksize * U;
-    // c0 = floor((Plo + 1) / BU), c1 = floor(Phi / BU): by a double-precision quotient and one correction either way (the
+    // floor((Plo + 1) / BU), floor(Phi / BU): by a double-precision quotient and one correction either way (the
     // 64-bit integer divisions were ~300 scalar instructions per wave)
     auto fdiv = [&](long long x) -> long long {
         if (x < 0) return 0;                                      // block 0: Plo + 1 = 1 - U
@@ -97,18 +126,28 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
         if ((c + 1) * BU <= x) c++;
         return c;
     };
-    long long c0 = fdiv(Plo + 1), c1 = fdiv(Phi);
-    if (c1 >= a.n_chunks) c1 = a.n_chunks - 1;
-    if (c0 > c1) c0 = c1;
-    const SegChunk ca = a.chunks[c0], cb = a.chunks[c1];
+    long long c_first = fdiv(Plo + 1), c_last = fdiv(Phi);
+    if (c_last >= a.n_chunks) c_last = a.n_chunks - 1;
+    if (c_first > c_last) c_first = c_last;
+    if (c_last > c_first + NC - 1) c_last = c_first + NC - 1;      // (cannot happen: blksize >= adv, launcher)
+    const int ncalls = (int)(c_last - c_first) + 1;
+    SegChunk cc[NC];
+    int nsg[NC], rbase[NC + 1];
+    rbase[0] = 0;
+#pragma unroll
+    for (int i = 0; i < NC; i++) {
+        cc[i] = a.chunks[c_first + (i < ncalls ? i : 0)];
+        nsg[i] = i < ncalls ? cc[i].n_seg : 0;                    // host guarantees their sum <= GEN_MAX_RUNS
+        rbase[i + 1] = rbase[i] + nsg[i];
+    }
     RunLds *runs = reinterpret_cast<RunLds *>(lds);
-    const int na = ca.n_seg, nb = c1 > c0 ? cb.n_seg : 0;         // host guarantees na + nb <= GEN_MAX_RUNS
     {
-        const unsigned long long *ga = reinterpret_cast<const unsigned long long *>(static_cast<const RunLds *>(a.segs) + ca.seg_first);
-        const unsigned long long *gb = reinterpret_cast<const unsigned long long *>(static_cast<const RunLds *>(a.segs) + cb.seg_first);
         unsigned long long *ws = reinterpret_cast<unsigned long long *>(lds);
-        for (int i = (int)t; i < 3 * na; i += 256) ws[i] = ga[i];
-        for (int i = (int)t; i < 3 * nb; i += 256) ws[3 * na + i] = gb[i];
+#pragma unroll
+        for (int i = 0; i < NC; i++) {
+            const unsigned long long *g = reinterpret_cast<const unsigned long long *>(static_cast<const RunLds *>(a.segs) + cc[i].seg_first);
+            for (int j = (int)t; j < 3 * nsg[i]; j += 256) ws[3 * rbase[i] + j] = g[j];
+        }
     }
     lds_barrier();
     // outputs of a call whose relative position is < bound (uniform: every thread runs the same search); *run: the run that
@@ -136,52 +175,66 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
         const int k = g.k0 + (int)i;
         return k < n_out ? k : n_out;
     };
-    const RunLds *ra = runs, *rb = runs + na;
-    const long long offa = ca.in_off * U, offb = cb.in_off * U;
-    // four bounds, four waves: wave w finds ONE of them (the search is uniform inside a wave: every lane of all four waves
-    // running all four searches was a seventh of the kernel's vector instructions) and lane 0 publishes it
-    __shared__ int s_bound[8];
+    // 2 NC bounds (each call's first and last owned output), four waves: wave w finds bounds w, w + 4 (the search is uniform
+    // inside a wave: every lane of all four waves running all the searches was a seventh of the kernel's vector
+    // instructions) and lane 0 publishes them
     const unsigned w = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63u;
-    {
-        const bool in_b = w >= 2u;
-        int run = 0;
-        const int r = (in_b && c1 == c0) ? 0
-                                         : count_below(in_b ? rb : ra, in_b ? nb : na, in_b ? cb.n_out : ca.n_out,
-                                                       ((w & 1u) ? Phi : Plo) - (in_b ? offb : offa), &run);
-        if (lane == 0) {
-            s_bound[w] = r;
-            s_bound[4 + w] = run;
+#pragma unroll
+    for (int sx = 0; sx < 2 * NC; sx += 4) {
+        const int sb = sx + (int)w;              // bound sb: call sb / 2, its lower (even) or upper (odd) end
+        if (sb < 2 * NC) {
+            int run = 0, r = 0;
+#pragma unroll
+            for (int i = 0; i < NC; i++)
+                if (i == (sb >> 1) && i < ncalls)
+                    r = count_below(runs + rbase[i], nsg[i], cc[i].n_out, ((sb & 1) ? Phi : Plo) - cc[i].in_off * U, &run);
+            if (lane == 0) {
+                s_bound[sb] = r;
+                if (!(sb & 1)) s_run[sb >> 1] = run;
+            }
         }
     }
     lds_barrier();
-    const int ka_lo = __builtin_amdgcn_readfirstlane(s_bound[0]), ka_hi = __builtin_amdgcn_readfirstlane(s_bound[1]);
-    const int kb_lo = __builtin_amdgcn_readfirstlane(s_bound[2]), kb_hi = __builtin_amdgcn_readfirstlane(s_bound[3]);
-    const int ra_lo = __builtin_amdgcn_readfirstlane(s_bound[4]), rb_lo = __builtin_amdgcn_readfirstlane(s_bound[6]);
-    const int Ta = ka_hi - ka_lo, T = Ta + (kb_hi - kb_lo);        // T <= 256 KPT (launcher)
-    const long long k_first = Ta > 0 || c1 == c0 ? ca.k_first + ka_lo : cb.k_first + kb_lo;   // the block's outputs are consecutive
+    int k_lo[NC], n_part[NC], idx_base[NC + 1], run_lo[NC];
+    idx_base[0] = 0;
+    long long k_first = cc[0].k_first + __builtin_amdgcn_readfirstlane(s_bound[0]);
+    bool have_first = false;
+#pragma unroll
+    for (int i = 0; i < NC; i++) {
+        k_lo[i] = __builtin_amdgcn_readfirstlane(s_bound[2 * i]);
+        n_part[i] = __builtin_amdgcn_readfirstlane(s_bound[2 * i + 1]) - k_lo[i];
+        run_lo[i] = __builtin_amdgcn_readfirstlane(s_run[i]);
+        idx_base[i + 1] = idx_base[i] + n_part[i];
+        if (!have_first && n_part[i] > 0) {      // the block's outputs are consecutive: they start in the first call that has any
+            k_first = cc[i].k_first + k_lo[i];
+            have_first = true;
+        }
+    }
+    const int T = idx_base[NC];                  // <= 256 KPT (launcher)
 
-    // The table, [output of the block]: the byte address in the exchange buffer of the output's first phase sample << 16 |
+    // The table, [output of the block]: the byte address in the exchange buffer of the output's first phase sample << 19 |
     // (cells to its second one: 0 the next phase of the same input sample, 1 / 17 phase 0 of the next one) << 10 | the
-    // second sample's phase << 5 | the first one's; and mu.  Filled 64 consecutive outputs of ONE call at a time (wave w:
-    // every fourth such piece), so that what a piece needs to know about its call is uniform and scalar: the run of its first
-    // output is found by walking on from the wave's previous piece, each lane then walks on to its own (pieces hold one to
-    // a few runs, except where a call starts: there a dozen binades pass in as many outputs).  Round 4's first version
-    // searched and walked per output, with 64-bit positions: 850 of the block's 2 900 vector instructions per wave.
-    const unsigned Uu = (unsigned)U, Minv = Uu > 1u ? 0xFFFFFFFFu / Uu + 1u : 0u;      // floor(x / U) = mulhi(x, Minv), x < U A
-    const unsigned e0 = (unsigned)a.ovl - 1u;    // transform element of the block's first owned input sample
-#pragma unroll 1
-    for (int part = 0; part < 2; part++) {
-        const RunLds *rs = part ? rb : ra;
-        const int ns = part ? nb : na, k_lo = part ? kb_lo : ka_lo, n_part = part ? T - Ta : Ta, idx_base = part ? Ta : 0;
-        const unsigned off32 = (unsigned)((part ? offb : offa) - Plo);       // + floor(t) (|.| < 2^31, launcher): < U A, mod 2^32
-        int lu = part ? rb_lo : ra_lo;
+    // second sample's phase << 5 | the first one's (REAL: | the half, bit 15); and mu.  Filled 64 consecutive outputs of ONE
+    // call at a time (wave w: every fourth such piece), so that what a piece needs to know about its call is uniform and
+    // scalar: the run of its first output is found by walking on from the wave's previous piece, each lane then walks on to
+    // its own (pieces hold one to a few runs, except where a call starts: there a dozen binades pass in as many outputs).
+    // Round 4's first version searched and walked per output, with 64-bit positions: 850 of the block's 2 900 vector
+    // instructions per wave.
+    const unsigned Uu = (unsigned)U, Minv = Uu > 1u ? 0xFFFFFFFFu / Uu + 1u : 0u;      // floor(x / U) = mulhi(x, Minv), x < 2 U A
+    const unsigned e0 = (unsigned)a.ovl - 1u;    // transform element of a block's first owned input sample
+#pragma unroll
+    for (int part = 0; part < NC; part++) {
+        const RunLds *rs = runs + rbase[part];
+        const int ns = nsg[part];
+        const unsigned off32 = (unsigned)(cc[part].in_off * U - Plo);       // + floor(t) (|.| < 2^31, launcher): < 2 U A, mod 2^32
+        int lu = run_lo[part];
         if (lu > ns - 1) lu = ns - 1;
 #pragma unroll 1
-        for (int c = (int)w; 64 * c < n_part; c += 4) {
-            const int kk0 = k_lo + 64 * c;
+        for (int c = (int)w; 64 * c < n_part[part]; c += 4) {
+            const int kk0 = k_lo[part] + 64 * c;
             while (lu + 1 < ns && __builtin_amdgcn_readfirstlane(rs[lu].k0 + rs[lu].count) <= kk0) lu++;
             const int i_part = 64 * c + (int)lane;
-            if (i_part < n_part) {
+            if (i_part < n_part[part]) {
                 const int kk = kk0 + (int)lane;
                 int l = lu;
                 while (rs[l].k0 + rs[l].count <= kk) l++;
@@ -189,14 +242,20 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
                 const double tt = g.t0 + (double)(kk - g.k0) * (double)g.d;      // exact (timelaw.h)
                 const double fl = floor(tt);
                 const float mu = (float)(tt - fl);
-                const unsigned pl = off32 + (unsigned)(int)fl;                  // position inside the block, < U A
-                const unsigned n = Uu > 1u ? __umulhi(pl, Minv) : pl;
-                const unsigned ph = pl - n * Uu, e = e0 + n;
+                const unsigned pl = off32 + (unsigned)(int)fl;                  // position inside the block (pair)
+                unsigned n = Uu > 1u ? __umulhi(pl, Minv) : pl;
+                const unsigned ph = pl - n * Uu;
+                unsigned half = 0u;
+                if (REAL && n >= (unsigned)A) {                                 // the pair's second block: the transform's imaginary part
+                    n -= (unsigned)A;
+                    half = 1u;
+                }
+                const unsigned e = e0 + n;
                 const bool wrap = ph + 1u == Uu;
                 const unsigned cell = (e >> 8) * LDS_K2_STRIDE + (e & 255u);
                 const unsigned dcell = wrap ? ((e & 255u) == 255u ? LDS_K2_STRIDE - 255u : 1u) : 0u;
-                tab_pos[idx_base + i_part] = (cell << 19) | (dcell << 10) | ((wrap ? 0u : ph + 1u) << 5) | ph;
-                tab_mu[idx_base + i_part] = mu;
+                tab_pos[idx_base[part] + i_part] = (cell << 19) | (half << 15) | (dcell << 10) | ((wrap ? 0u : ph + 1u) << 5) | ph;
+                tab_mu[idx_base[part] + i_part] = mu;
             }
         }
     }
@@ -269,9 +328,9 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
     dft16<-1>(X);                                // bin k sits in X[P16(k)]
 
     // ---- 2. phase by phase
-    v2f acc[KPT];
+    E acc[KPT];
 #pragma unroll
-    for (int q = 0; q < KPT; q++) acc[q] = (v2f){0.0f, 0.0f};
+    for (int q = 0; q < KPT; q++) acc[q] = E{};
 #pragma unroll 1
     for (int j = 0; j < U; j++) {
         lds_barrier();                           // (j > 0: every thread is done reading S_{j-1})
@@ -318,15 +377,27 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
             if ((int)t + 256 * q >= T) continue;
             const unsigned pw = tab_pos[256 * q + t];
             const float mu_q = tab_mu[256 * q + t];
-            const unsigned a0 = pw >> 16;                                      // byte address of the first sample
-            if ((pw & 31u) == ju) {
-                const v2f s0 = *reinterpret_cast<const v2f *>(lb + a0);
-                const float om = 1.0f - mu_q;                      // resample.cxx:147
-                acc[q] = __builtin_elementwise_fma((v2f){om, om}, s0, acc[q]);
-            }
-            if (((pw >> 5) & 31u) == ju) {
-                const v2f s1 = *reinterpret_cast<const v2f *>(lb + a0 + (((pw >> 10) & 31u) << 3));
-                acc[q] = __builtin_elementwise_fma((v2f){mu_q, mu_q}, s1, acc[q]);
+            if constexpr (!REAL) {
+                const unsigned a0 = pw >> 16;                                  // byte address of the first sample
+                if ((pw & 31u) == ju) {
+                    const v2f s0 = *reinterpret_cast<const v2f *>(lb + a0);
+                    const float om = 1.0f - mu_q;                  // resample.cxx:147
+                    acc[q] = __builtin_elementwise_fma((v2f){om, om}, s0, acc[q]);
+                }
+                if (((pw >> 5) & 31u) == ju) {
+                    const v2f s1 = *reinterpret_cast<const v2f *>(lb + a0 + (((pw >> 10) & 31u) << 3));
+                    acc[q] = __builtin_elementwise_fma((v2f){mu_q, mu_q}, s1, acc[q]);
+                }
+            } else {
+                const unsigned a0 = (pw >> 16) + ((pw >> 13) & 4u);            // ... of the half the output belongs to: + 4 bytes for the imaginary part
+                if ((pw & 31u) == ju) {
+                    const float s0 = *reinterpret_cast<const float *>(lb + a0);
+                    acc[q] = __builtin_fmaf(1.0f - mu_q, s0, acc[q]);
+                }
+                if (((pw >> 5) & 31u) == ju) {
+                    const float s1 = *reinterpret_cast<const float *>(lb + a0 + (((pw >> 10) & 31u) << 3));
+                    acc[q] = __builtin_fmaf(mu_q, s1, acc[q]);
+                }
             }
         }
     }
@@ -350,38 +421,47 @@ int poly_gen_outputs_per_block(int U, int adv, float step)
 }
 
 // SFE_ESTATE: the shape is outside what this kernel takes (the caller uses poly_seg_kernel)
-int launch_poly_gen(const PolyGenArgs &a0, int max_runs_two_calls, float step, int n_channels, hipStream_t s)
+// max_runs: the most runs any two (complex) / three (real) consecutive reference calls of the launch have between them
+int launch_poly_gen(const PolyGenArgs &a0, int max_runs, float step, int n_channels, hipStream_t s)
 {
     if (a0.n_chunks <= 0) return SFE_OK;
     PolyGenArgs a = a0;
-    if (a.ovl < a.plen || a.ovl >= FFT_N / 2 || (a.ovl & 15) || max_runs_two_calls > GEN_MAX_RUNS) return SFE_ESTATE;
+    if (a.ovl < a.plen || a.ovl >= FFT_N / 2 || (a.ovl & 15) || max_runs > GEN_MAX_RUNS) return SFE_ESTATE;
     // the table's fields: 5 bits per phase; a call's positions as 32-bit integers
     if (a.U > 32 || (long long)a.blksize * a.U >= 0x7fffffffLL) return SFE_ESTATE;
     // A block owns `adv` input samples: all 4096 - ovl its transform yields validly while their outputs fit the table
-    // (256 x 16), fewer below that -- rates under ~1, MORE outputs than inputs: what `resample` takes and `decimate` refuses,
-    // libdsp/resample.cxx:91 -- down to the reference's own limit rate = 1 / U (step 1: every upsampled position an output).
-    // The transform count per input sample grows as adv shrinks; the direct form's cost grows with the OUTPUT count, faster.
+    // (256 x 16; a real stream's pair of blocks: 256 x 22), fewer below that -- rates under ~1, MORE outputs than inputs: what
+    // `resample` takes and `decimate` refuses, libdsp/resample.cxx:91 -- down to the reference's own limit rate = 1 / U (step 1:
+    // every upsampled position an output).  The transform count per input sample grows as adv shrinks; the direct form's
+    // cost grows with the OUTPUT count, faster.
+    const int per_wg = a.real ? 2 : 1, kpt_max = a.real ? 22 : 16;
     a.adv = FFT_N - a.ovl;
-    if (poly_gen_outputs_per_block(a.U, a.adv, step) > 256 * 16) {
-        a.adv = (int)((256.0 * 16 - 2) * (double)step * (1.0 - 1.0 / 4194304.0) / a.U) & ~15;
-        if (a.adv < 512 || poly_gen_outputs_per_block(a.U, a.adv, step) > 256 * 16) return SFE_ESTATE;
+    if (poly_gen_outputs_per_block(a.U, per_wg * a.adv, step) > 256 * kpt_max) {
+        a.adv = (int)((256.0 * kpt_max - 2) * (double)step * (1.0 - 1.0 / 4194304.0) / (a.U * per_wg)) & ~15;
+        if (a.adv < 512 || poly_gen_outputs_per_block(a.U, per_wg * a.adv, step) > 256 * kpt_max) return SFE_ESTATE;
     }
-    if (a.blksize < a.adv) return SFE_ESTATE;                 // a block overlaps at most two reference calls
+    if (a.blksize < a.adv) return SFE_ESTATE;                 // a block overlaps at most two reference calls, a pair three
 #ifdef SFE_DIAG
     // the persistent form with the next block fetched ahead (measured and not kept: diag/poly_gen_persistent.hip)
     if (const char *e = getenv("SFE_GEN_PERSISTENT"))
-        if (atoi(e) > 0 && a.adv == FFT_N - a.ovl) return launch_poly_gen_persistent(a, max_runs_two_calls, step, n_channels, s, atoi(e) > 1);
+        if (atoi(e) > 0 && !a.real && a.adv == FFT_N - a.ovl) return launch_poly_gen_persistent(a, max_runs, step, n_channels, s, atoi(e) > 1);
 #endif
-    const int per_block = poly_gen_outputs_per_block(a.U, a.adv, step);
+    const int per_block = poly_gen_outputs_per_block(a.U, per_wg * a.adv, step);
     const long long A = a.adv;
-    const long long nblk = (a.n_in + A - 1) / A;
+    const long long nblk = ((a.n_in + A - 1) / A + per_wg - 1) / per_wg;
     if (nblk > 0x7fffffffLL) return SFE_ESTATE;
     dim3 grid((unsigned)nblk, (unsigned)n_channels), block(256);
     const int kpt = (per_block + 255) / 256;
-    if (kpt <= 6) hipLaunchKernelGGL((poly_gen4096_kernel<6>), grid, block, 0, s, a);
-    else if (kpt <= 9) hipLaunchKernelGGL((poly_gen4096_kernel<9>), grid, block, 0, s, a);
-    else if (kpt <= 12) hipLaunchKernelGGL((poly_gen4096_kernel<12>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((poly_gen4096_kernel<16>), grid, block, 0, s, a);
+    if (a.real) {
+        if (kpt <= 12) hipLaunchKernelGGL((poly_gen4096_kernel<12, true>), grid, block, 0, s, a);
+        else if (kpt <= 18) hipLaunchKernelGGL((poly_gen4096_kernel<18, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((poly_gen4096_kernel<22, true>), grid, block, 0, s, a);
+    } else {
+        if (kpt <= 6) hipLaunchKernelGGL((poly_gen4096_kernel<6, false>), grid, block, 0, s, a);
+        else if (kpt <= 9) hipLaunchKernelGGL((poly_gen4096_kernel<9, false>), grid, block, 0, s, a);
+        else if (kpt <= 12) hipLaunchKernelGGL((poly_gen4096_kernel<12, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((poly_gen4096_kernel<16, false>), grid, block, 0, s, a);
+    }
     SFE_HIP(hipGetLastError());
     return SFE_OK;
 }

@@ -34,12 +34,16 @@ def _pair(api, L, taps, U, B, cplx=True, nch=1):
     return exact, fast
 
 
-@pytest.mark.parametrize("seed", list(range(24)) + list(range(100, 116)))
+@pytest.mark.parametrize("seed", list(range(24)) + list(range(100, 116)) + list(range(200, 224)))
 def test_transform_domain_general_rate_random_shapes(api, L, seed):
-    """seeds >= 100: rates BELOW 1 -- more outputs than inputs, down to the reference's own limit 1 / U
-    (libdsp/resample.cxx:91): a block then owns fewer input samples than its transform yields, so that its outputs fit."""
+    """seeds 100-115: rates BELOW 1 -- more outputs than inputs, down to the reference's own limit 1 / U
+    (libdsp/resample.cxx:91): a block then owns fewer input samples than its transform yields, so that its outputs fit.
+    seeds >= 200: REAL float32 streams (libdsp's native type): two consecutive blocks per transform; every third of them
+    at a rate below 1."""
     rng = np.random.default_rng(7000 + seed)
-    U = int(rng.choice([1, 2, 3, 4, 5, 8]) if seed < 100 else rng.choice([2, 3, 4, 5, 8]))
+    cplx = seed < 200
+    below = 100 <= seed < 200 or (seed >= 200 and seed % 3 == 0)
+    U = int(rng.choice([1, 2, 3, 4, 5, 8]) if not below else rng.choice([2, 3, 4, 5, 8]))
     plen = int(rng.choice([1, 8, 43, 127, 128, 255, 256, 257, 300]))
     n_taps = U * plen - int(rng.integers(0, U))
     B = int(rng.choice([4096, 4096, 5000, 16384, 3840]))          # calls at least one block advance long (shorter: the direct kernel)
@@ -47,7 +51,7 @@ def test_transform_domain_general_rate_random_shapes(api, L, seed):
     rate = float(np.float32(rng.uniform(1.0, 6.0)))
     if seed % 6 == 0:
         rate = float(np.float32(1.0 + rng.uniform(0.0, 0.01)))        # just above 1: close to one output per input sample
-    if seed >= 100:
+    if below:
         rate = float(np.float32(rng.uniform(1.0 / U, 1.0)))
         if seed % 4 == 0:
             rate = float(np.float32(1.0 / U) * np.float32(1.0 + rng.uniform(0.0, 0.003)))       # next to the limit: a step of ~1
@@ -55,24 +59,25 @@ def test_transform_domain_general_rate_random_shapes(api, L, seed):
             rate = float(np.nextafter(np.float32(rate), np.float32(2.0)))
     nch = int(rng.choice([1, 1, 3]))
     n = int(rng.choice([700, 4096, 12345, 40000, 150001]))
-    x = np.stack([synth.synth_cf32(n, ch=300 + seed * 4 + c) for c in range(nch)])
-    exact, fast = _pair(api, L, taps, U, B, nch=nch)
+    w = 2 if cplx else 1                                                            # floats per sample
+    x = np.stack([(synth.synth_cf32 if cplx else synth.synth_f32)(n, ch=300 + seed * 4 + c) for c in range(nch)])
+    exact, fast = _pair(api, L, taps, U, B, cplx=cplx, nch=nch)
     cuts = sorted(set([0, n] + [int(v) // B * B for v in rng.integers(1, n, size=2)]))     # whole reference calls per piece
     for a0, a1 in zip(cuts[:-1], cuts[1:]):
         if a1 == a0:
             continue
         m = a1 - a0
-        seg = np.ascontiguousarray(x[:, 2 * a0: 2 * a1])
+        seg = np.ascontiguousarray(x[:, w * a0: w * a1])
         d_in = api.DeviceArray.from_numpy(seg)
         cap = int(m / rate) + 16 + 2 * (m // B + 1)
-        de, df = api.DeviceArray(2 * cap * nch), api.DeviceArray(2 * cap * nch)
+        de, df = api.DeviceArray(w * cap * nch), api.DeviceArray(w * cap * nch)
         ke = exact.process_stream(d_in, m, de, cap, rate)
         kf = fast.process_stream(d_in, m, df, cap, rate)
         assert ke == kf, (seed, U, plen, rate, n, a0, ke, kf)
         if ke == 0:
             continue
-        ye = de.to_numpy().reshape(nch, 2 * cap)[:, : 2 * ke]
-        yf = df.to_numpy().reshape(nch, 2 * cap)[:, : 2 * kf]
+        ye = de.to_numpy().reshape(nch, w * cap)[:, : w * ke]
+        yf = df.to_numpy().reshape(nch, w * cap)[:, : w * kf]
         for c in range(nch):
             assert synth.rel_rms(yf[c], ye[c]) <= TOL, (seed, U, plen, rate, n, a0, c, synth.rel_rms(yf[c], ye[c]))
             assert np.abs(yf[c] - ye[c]).max() <= 2e-5 * max(1.0, float(np.abs(ye[c]).max())), (seed, U, plen, rate)
