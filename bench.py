@@ -28,6 +28,10 @@ BEFORE anything touches the GPU and relays rank 0's line.  It never prints an n_
                 median of the K steps beside the mean); `traffic` is the PMC-measured HBM bytes
                 per launch from profiles/ -- null if no pass was recorded, and null with
                 `traffic_stale: true` if simplefe_amd/csrc/ has changed since that pass.
+buffers         every leg's output buffer is the fastest of --screen (default 4) candidates against the leg's input in a
+                bare read + write mix (sfe_dsp_probe_pair), chosen OUTSIDE the timed region and reported (`buffers`): what a
+                pair of allocations gives a streaming kernel is fixed when the memory is handed out.
+                --screen 1: plain allocations.
 `other_configs` (N = 1, default workload) the other BASELINE.json configs at G = 1, each a short
                 timed leg of its own with parity: resample 5/3 (configs[2], in both readings of
                 "127-tap polyphase arm": the 381-tap prototype and the 127-tap prototype), decimate by 8
@@ -81,6 +85,9 @@ def parse():
                     help="tx10: the FIR writes the 10-bit transmit wire format (fused TX converter, N2)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-others", action="store_true", help="skip the other_configs legs")
+    ap.add_argument("--screen", type=int, default=4,
+                    help="output buffers allocated per leg, the one that runs fastest against the input in a bare read + write mix kept "
+                         "(sfe_dsp_probe_pair; DESIGN.md 4.2: what a pair of allocations gives is fixed when the memory is handed out). 1: no screening")
     ap.add_argument("--no-calibrate", action="store_true",
                     help="do not call sfe_dsp_fir_calibrate before the headline leg (run the default variant)")
     ap.add_argument("--single-process", action="store_true",
@@ -243,6 +250,37 @@ def _p2(v):
     return "2^%d" % (v.bit_length() - 1) if v > 0 and v & (v - 1) == 0 else str(v)
 
 
+def screened_output(ctx, leg, src, numel, dtype):
+    """The leg's output buffer: ctx["screen"] candidates, each timed against the input `src` with the library's bare read +
+    write mix (sfe_dsp_probe_pair), the fastest kept.  What a PAIR of allocations gives a kernel that reads one while it
+    writes the other is fixed when the memory is handed out -- two classes of allocation, ~8 % between a pair from one class
+    and a pair from two for the decimator's mix, while each stream alone runs the same -- so a caller that
+    cares allocates its pair this way (sfe_dsp_malloc_pair is the same thing behind the C ABI).  Outside the timed region;
+    what was probed is reported in the row ("buffers")."""
+    import ctypes as C
+    torch, L, dev = ctx["torch"], ctx["L"], ctx["dev"]
+    tries = max(1, int(ctx.get("screen", 1)))
+    cands, ms = [], []
+    for _ in range(tries):
+        try:
+            y = torch.empty(numel, dtype=dtype, device=dev)
+        except RuntimeError:                      # out of memory further on: choose among what there is
+            break
+        cands.append(y)
+        t = C.c_float(0.0)
+        if tries > 1 and src.numel() * src.element_size() >= 32768 and y.numel() * y.element_size() >= 4096:
+            torch.cuda.synchronize()
+            ctx["api"].check(L.sfe_dsp_probe_pair(src.data_ptr(), src.numel() * src.element_size(), y.data_ptr(),
+                                                 y.numel() * y.element_size(), C.byref(t)))
+        ms.append(float(t.value))
+    if not cands:
+        raise RuntimeError("no memory for the output buffer")
+    best = int(np.argmin(ms))
+    if tries > 1:
+        leg.buffers = {"output_candidates": len(cands), "probe_ms": [round(v, 4) for v in ms], "kept": best}
+    return cands[best]
+
+
 def make_fir_leg(ctx, name, taps, n, nch, ch0=0, algo="auto", in_fmt="f32", out_fmt="f32", x_share=None, per_channel=False,
                  y_share=None, calibrate=False):
     """n samples per channel, nch channels on THIS rank, the first of them global channel ch0 (its
@@ -293,9 +331,9 @@ def make_fir_leg(ctx, name, taps, n, nch, ch0=0, algo="auto", in_fmt="f32", out_
         out_bytes = 2.5
         leg.key += "_tx10"
         leg.workload += ", 10-bit packed transmit wire format out"
-        leg.y = torch.empty(nch * (n * 2 // 4) * 5 + 64, dtype=torch.uint8, device=dev)
+        leg.y = screened_output(ctx, leg, src, nch * (n * 2 // 4) * 5 + 64, torch.uint8)
     else:
-        leg.y = y_share if y_share is not None else torch.empty(nch * n * 2, dtype=torch.float32, device=dev)
+        leg.y = y_share if y_share is not None else screened_output(ctx, leg, src, nch * n * 2, torch.float32)
     leg.out_fmt = out_fmt
     leg.bytes_per_launch = (in_bytes + out_bytes) * n_gpu       # 8 B read + 8 B written per sample
     leg.kernel = "fir_fft4096_kernel" if algo != "direct" else "poly_tiled_kernel"
@@ -411,7 +449,7 @@ def make_rs_leg(ctx, which, log2n, in_fmt="f32", short_proto=False):
         leg.workload += ", u8 (I,Q) wire-format input converted on load"
     leg.x, leg._src = x, src
     out_cap = n * U // S + 8
-    leg.y = torch.empty(out_cap * 2, dtype=torch.float32, device=dev)
+    leg.y = screened_output(ctx, leg, src, out_cap * 2, torch.float32)
     leg.obj = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE if which == "resample" else lib.RS_DECIMATE,
                      data_complex=True, n_channels=1, device=ctx["local_rank"])
     if in_fmt == "u8":
@@ -496,7 +534,7 @@ def make_general_rate_leg(ctx, log2n=28, rate=1.77, interpolate=0):
     api.check(L.sfe_dsp_synth_fill(x.data_ptr(), 2 * n, synth.SEED, 0, 0, stream))
     out_cap = int(n / rate) + 4096
     leg.x = x
-    leg.y = torch.empty(out_cap * 2, dtype=torch.float32, device=dev)
+    leg.y = screened_output(ctx, leg, x, out_cap * 2, torch.float32)
     leg.obj = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=True, n_channels=1, device=ctx["local_rank"])
     leg.kernel = "poly_rt1_kernel" if interpolate else "poly_gen4096_kernel"
     leg.n_out = 0
@@ -776,7 +814,7 @@ def main():
 
     ctx = {"torch": torch, "api": api, "lib": lib, "synth": synth, "shard": shard, "L": L, "dev": dev,
            "red_dev": red_dev, "stream": torch.cuda.current_stream().cuda_stream, "rank": rank,
-           "local_rank": local_rank, "world": world, "barrier": barrier}
+           "local_rank": local_rank, "world": world, "barrier": barrier, "screen": args.screen}
     ctx_red = red_dev       # where the control-plane reductions live: the GPU under RCCL, the host under gloo
 
     wl = args.workload
@@ -844,6 +882,8 @@ def main():
                "frac": leg.bytes_per_launch / (kmean * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if getattr(leg, "variant", None):
             row["variant"] = leg.variant["ran"]
+        if getattr(leg, "buffers", None):
+            row["buffers"] = leg.buffers
         if leg.name == "decimate":
             # this launch runs in one of two modes ~6 % apart that belong to how the process's 8 GiB + 1 GiB buffers
             # happen to be backed physically, not to the kernel (profiles/r04/decimate_modes_*.txt):
@@ -909,6 +949,9 @@ def main():
     }
     if getattr(head, "variant", None):
         out["roofline"]["variant"] = head.variant     # which data-movement variant this device's measurement picked
+    if getattr(head, "buffers", None):
+        out["config"]["buffers"] = dict(head.buffers, note="output buffer: the fastest of the candidates against the input in a bare read + "
+                                        "write mix (sfe_dsp_probe_pair, outside the timed region; DESIGN.md 4.2); --screen 1 disables")
     if traffic_stale:
         out["roofline"]["traffic_stale"] = True      # simplefe_amd/csrc changed since the PMC pass in profiles/
     if world > 1:

@@ -66,6 +66,17 @@ int sfe_dsp_get_device(int *device);
 int sfe_dsp_sync(sfe_stream_t stream);                       /* hipStreamSynchronize */
 int sfe_dsp_malloc(void **dptr, size_t bytes);               /* device memory */
 int sfe_dsp_free(void *dptr);
+/* A PAIR of device buffers for a stream call that reads one while it writes the other.  What such a pair gives is fixed
+ * when the memory is handed out ("the two modes": two classes of allocation; a read stream and a write
+ * stream from the same class run ~8 % slower together than a pair from different classes, each alone the same in both --
+ * a property of the platform's memory, seen by any streaming kernel, the bare copy included).
+ * probe_pair: the median time of five launches of the bare mix over (d_in, d_out) -- every 32 KiB read, the output
+ *   written in proportion -- on the null stream, synchronous; the output's contents are overwritten.
+ * malloc_pair: the input, then up to `tries` (1 .. 16) candidates for the output, each probed against it; the fastest is
+ *   kept, the others freed (all stay allocated until the choice is made).  tries = 1: two plain allocations.  ms_kept /
+ *   ms_worst (may be NULL): the probe times of the kept and of the slowest candidate.  Free both with sfe_dsp_free. */
+int sfe_dsp_probe_pair(const void *d_in, size_t in_bytes, void *d_out, size_t out_bytes, float *ms);
+int sfe_dsp_malloc_pair(size_t in_bytes, size_t out_bytes, int tries, void **d_in, void **d_out, float *ms_kept, float *ms_worst);
 int sfe_dsp_host_alloc(void **hptr, size_t bytes);           /* pinned host memory */
 int sfe_dsp_host_free(void *hptr);
 int sfe_dsp_memcpy_h2d(void *dptr, const void *hptr, size_t bytes, sfe_stream_t stream);

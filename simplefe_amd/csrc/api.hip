@@ -109,6 +109,90 @@ int sfe_dsp_free(void *dptr)
     if (dptr) SFE_HIP(hipFree(dptr));
     return SFE_OK;
 }
+// median time of the bare read + write mix over the pair (util.hip: pair_probe_kernel), on the null stream
+static int probe_pair_ms(const void *d_in, size_t in_bytes, void *d_out, size_t out_bytes, float *ms)
+{
+    hipEvent_t e0, e1;
+    SFE_HIP(hipEventCreate(&e0));
+    SFE_HIP(hipEventCreate(&e1));
+    int rc = SFE_OK;
+    float v[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 3 && rc == SFE_OK; i++) rc = launch_pair_probe(d_in, in_bytes, d_out, out_bytes, nullptr);
+    for (int i = 0; i < 5 && rc == SFE_OK; i++) {
+        hipError_t e = hipEventRecord(e0, nullptr);
+        if (e == hipSuccess) rc = launch_pair_probe(d_in, in_bytes, d_out, out_bytes, nullptr);
+        if (e == hipSuccess && rc == SFE_OK) e = hipEventRecord(e1, nullptr);
+        if (e == hipSuccess && rc == SFE_OK) e = hipEventSynchronize(e1);
+        if (e == hipSuccess && rc == SFE_OK) e = hipEventElapsedTime(&v[i], e0, e1);
+        if (e != hipSuccess) rc = hip_fail(e, "probe_pair");
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != SFE_OK) return rc;
+    for (int i = 1; i < 5; i++)          // insertion sort of five
+        for (int j = i; j > 0 && v[j] < v[j - 1]; j--) {
+            const float t = v[j];
+            v[j] = v[j - 1];
+            v[j - 1] = t;
+        }
+    *ms = v[2];
+    return SFE_OK;
+}
+
+int sfe_dsp_probe_pair(const void *d_in, size_t in_bytes, void *d_out, size_t out_bytes, float *ms)
+{
+    if (!d_in || !d_out || !ms || in_bytes < 32768 || out_bytes < 4096 || (reinterpret_cast<uintptr_t>(d_in) & 7) ||
+        (reinterpret_cast<uintptr_t>(d_out) & 15)) {
+        set_error("probe_pair: needs an input of >= 32 KiB (8-byte aligned) and an output of >= 4 KiB (16-byte aligned)");
+        return SFE_EINVAL;
+    }
+    return probe_pair_ms(d_in, in_bytes, d_out, out_bytes, ms);
+}
+
+int sfe_dsp_malloc_pair(size_t in_bytes, size_t out_bytes, int tries, void **d_in, void **d_out, float *ms_kept, float *ms_worst)
+{
+    if (!d_in || !d_out || tries < 1 || tries > 16) {
+        set_error("malloc_pair: null argument or tries outside 1 .. 16");
+        return SFE_EINVAL;
+    }
+    *d_in = *d_out = nullptr;
+    void *in = nullptr, *cand[16] = {nullptr};
+    float ms[16];
+    SFE_HIP(hipMalloc(&in, in_bytes ? in_bytes : 16));
+    int n = 0, rc = SFE_OK, best = 0;
+    const bool probe = in_bytes >= 32768 && out_bytes >= 4096;
+    // every candidate stays allocated until the choice is made: a freed one's pages would come straight back
+    for (; n < (probe ? tries : 1); n++) {
+        const hipError_t e = hipMalloc(&cand[n], out_bytes ? out_bytes : 16);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (n == 0) rc = hip_fail(e, "malloc_pair");
+            break;                                             // out of memory further on: choose among what there is
+        }
+        ms[n] = 0.0f;
+        if (probe) rc = probe_pair_ms(in, in_bytes, cand[n], out_bytes, &ms[n]);
+        if (rc != SFE_OK) {
+            n++;
+            break;
+        }
+        if (ms[n] < ms[best]) best = n;
+    }
+    float worst = 0.0f;
+    for (int i = 0; i < n; i++) {
+        if (ms[i] > worst) worst = ms[i];
+        if (rc != SFE_OK || i != best) (void)hipFree(cand[i]);
+    }
+    if (rc != SFE_OK) {
+        (void)hipFree(in);
+        return rc;
+    }
+    *d_in = in;
+    *d_out = cand[best];
+    if (ms_kept) *ms_kept = ms[best];
+    if (ms_worst) *ms_worst = worst;
+    return SFE_OK;
+}
+
 int sfe_dsp_host_alloc(void **hptr, size_t bytes)
 {
     if (!hptr) return SFE_EINVAL;

@@ -283,5 +283,6 @@ int launch_synth_fill(float *d, uint64_t n, uint32_t seed, uint32_t ch, uint64_t
                       hipStream_t s);
 int launch_rx_u8_to_f32(const uint8_t *src, float *dst, size_t n, hipStream_t s);
 int launch_tx_f32_to_10bit(const float *src, uint8_t *dst, size_t n_floats, hipStream_t s);
+int launch_pair_probe(const void *in, size_t in_bytes, void *out, size_t out_bytes, hipStream_t s);
 
 }  // namespace sfe

@@ -1258,3 +1258,24 @@ def test_stream_entry_points_reject_bad_buffers(api, L):
     assert b"overlap" in lib.sfe_dsp_last_error() or b"aligned" in lib.sfe_dsp_last_error()
     assert lib.sfe_dsp_fir_process_stream(f._h, base, base + (1 << 17), 4096, 4096, 4096, None) == L.SFE_OK
     api.sync()
+
+
+def test_malloc_pair_and_probe_pair(L):
+    """sfe_dsp_malloc_pair / sfe_dsp_probe_pair (include/sfe_dsp.h): a pair of buffers screened for the read + write
+    interaction of DESIGN.md 4.2.  The kept candidate is the fastest of those probed; bad arguments are refused."""
+    import ctypes as C
+    lib = L.load()
+    d_in, d_out, kept, worst = C.c_void_p(), C.c_void_p(), C.c_float(), C.c_float()
+    rc = lib.sfe_dsp_malloc_pair(1 << 28, 1 << 25, 4, C.byref(d_in), C.byref(d_out), C.byref(kept), C.byref(worst))
+    assert rc == 0 and d_in.value and d_out.value
+    assert 0.0 < kept.value <= worst.value
+    ms = C.c_float()
+    assert lib.sfe_dsp_probe_pair(d_in, 1 << 28, d_out, 1 << 25, C.byref(ms)) == 0 and ms.value > 0.0
+    # 256 MiB read + 32 MiB written cannot take longer than a millisecond on this device (~0.05 ms at 6 TB/s)
+    assert ms.value < 1.0
+    assert lib.sfe_dsp_probe_pair(d_in, 100, d_out, 1 << 25, C.byref(ms)) != 0            # too short to probe
+    assert lib.sfe_dsp_malloc_pair(1 << 20, 1 << 20, 0, C.byref(d_in), C.byref(d_out), None, None) != 0
+    assert lib.sfe_dsp_free(d_in) == 0 and lib.sfe_dsp_free(d_out) == 0
+    # tries = 1, tiny sizes: two plain allocations, nothing probed
+    assert lib.sfe_dsp_malloc_pair(64, 64, 1, C.byref(d_in), C.byref(d_out), C.byref(kept), None) == 0
+    assert lib.sfe_dsp_free(d_in) == 0 and lib.sfe_dsp_free(d_out) == 0
