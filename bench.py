@@ -86,7 +86,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-others", action="store_true", help="skip the other_configs legs")
     ap.add_argument("--screen", type=int, default=4,
-                    help="output buffers allocated per leg, the one that runs fastest against the input in a bare read + write mix kept "
+                    help="output buffers allocated per leg (twice as many where these show no spread), the one that runs fastest against the input in a bare read + write mix kept "
                          "(sfe_dsp_probe_pair; DESIGN.md 4.2: what a pair of allocations gives is fixed when the memory is handed out). 1: no screening")
     ap.add_argument("--no-calibrate", action="store_true",
                     help="do not call sfe_dsp_fir_calibrate before the headline leg (run the default variant)")
@@ -261,7 +261,10 @@ def screened_output(ctx, leg, src, numel, dtype):
     torch, L, dev = ctx["torch"], ctx["L"], ctx["dev"]
     tries = max(1, int(ctx.get("screen", 1)))
     cands, ms = [], []
-    for _ in range(tries):
+    for k in range(2 * tries if tries > 1 else 1):
+        # (twice as many where the first `tries` show no spread: all of one class -- the input's, one time in eight -- or all of the other)
+        if k >= tries and (min(ms) <= 0 or min(ms) < 0.96 * max(ms)):
+            break
         try:
             y = torch.empty(numel, dtype=dtype, device=dev)
         except RuntimeError:                      # out of memory further on: choose among what there is
