@@ -67,13 +67,20 @@ def modes_block():
     e1 = [o for o in a["other_configs"] if "decimate" in o.get("workload", "")][0]["ms"]
     e2 = [o for o in b["other_configs"] if "decimate" in o.get("workload", "")][0]["ms"]
     mode = lambda ms: "fast" if ms <= 1.53 else "slow"
+    b1 = [o for o in drv["other_configs"] if "decimate" in o.get("workload", "")][0].get("buffers", {})
+    b2 = [o for o in dfl["other_configs"] if "decimate" in o.get("workload", "")][0].get("buffers", {})
+    hb = drv["config"].get("buffers", {})
+    pr = lambda v: " / ".join("%.4f" % x for x in v.get("probe_ms", []))
     return (f"The three columns come from two `gpurun` calls: the counters and kernel stats from one, the bench lines from the next (they had to wait for "
-            f"the counter summaries to be in the tree to carry `traffic`). The decimate row shows §4.2's two modes: the profiled process ran in the {mode(prof)} one "
-            f"({prof:.4f} ms, `profiles/r04/decimate_kernel_stats.csv`), the two line processes {('both in the ' + mode(d1)) if mode(d1) == mode(d2) else ('in the ' + mode(d1) + ' and the ' + mode(d2))} one ({d1:.4f} and {d2:.4f} ms, "
-            f"`profiles/r04/bench_driver_shape.json`, `profiles/r04/bench_default.json`); an earlier collection of the round had them the other way round — its "
-            f"profiled process slow at 1.58 ms, its own lines, made minutes later on the same box and kept under `earlier/` (without `traffic`), at {e1:.4f} and "
-            f"{e2:.4f} ms (`profiles/r04/earlier/c1_bench_driver_shape.json`, `profiles/r04/earlier/c1_bench_default.json`): the mode is the process's, not the "
-            f"box's. The FIR and the resampler differ between the calls by the boxes' usual 2–3 %.\n")
+            f"the counter summaries to be in the tree to carry `traffic`). Since the end of round 4 every leg's output buffer is SCREENED (§4.2: `bench.py --screen 4`, "
+            f"the fastest of the candidates against the input in a bare read + write mix, outside the timed region): the decimate rows ran in the {mode(prof)} mode in the "
+            f"profiled process ({prof:.4f} ms, `profiles/r04/decimate_kernel_stats.csv`) and {('in the ' + mode(d1) + ' one in both') if mode(d1) == mode(d2) else ('in the ' + mode(d1) + ' and the ' + mode(d2) + ' one in the two')} line processes "
+            f"({d1:.4f} and {d2:.4f} ms, `profiles/r04/bench_driver_shape.json`, `profiles/r04/bench_default.json`), whose candidates probed {pr(b1)} and {pr(b2)} ms — "
+            f"both classes among them each time; the headline FIR's candidates probed {pr(hb)} ms (`profiles/r04/bench_driver_shape.json`: `config.buffers`). Before the "
+            f"screening the mode was the process's luck: an earlier collection of the round had its profiled process slow at 1.58 ms and its own lines, made minutes later on "
+            f"the same box and kept under `earlier/` (without `traffic`), at {e1:.4f} and {e2:.4f} ms (`profiles/r04/earlier/c1_bench_driver_shape.json`, "
+            f"`profiles/r04/earlier/c1_bench_default.json`), and the collection before this one, unscreened, read `frac` 0.67 for the headline "
+            f"(`profiles/r04/earlier/c2_bench_driver_shape.json`). The resampler differs between the calls by the boxes' usual 2–3 %.\n")
 
 
 path = os.path.join(ROOT, "DESIGN.md")
