@@ -580,7 +580,7 @@ def group_leg(ctx, taps, total_channels, n_ch, devices, steps, warmup):
     from oracle import binding as orc
     grp = api.FirGroup(taps, total_channels, devices)
     sh = grp.shards()
-    xs, ys = [], []
+    xs, ys, probes = [], [], []
     for d, f, c, _, _ in sh:
         with torch.cuda.device(d):
             x = torch.empty(c * n_ch * 2, dtype=torch.float32, device="cuda:%d" % d)
@@ -588,7 +588,10 @@ def group_leg(ctx, taps, total_channels, n_ch, devices, steps, warmup):
                 api.check(L.sfe_dsp_synth_fill(x.data_ptr() + k * n_ch * 8, 2 * n_ch, synth.SEED, f + k, 0, None))
             torch.cuda.synchronize(d)
             xs.append(x)
-            ys.append(torch.empty_like(x))
+            # the shard's output: screened against its input like every leg's (screened_output)
+            shard_leg = Leg()
+            ys.append(screened_output(dict(ctx, dev="cuda:%d" % d), shard_leg, x, x.numel(), torch.float32))
+            probes.append(getattr(shard_leg, "buffers", None))
     pin, pout = [x.data_ptr() for x in xs], [y.data_ptr() for y in ys]
     for _ in range(max(2, warmup)):
         grp.process_stream(pin, pout, n_ch)
@@ -626,6 +629,7 @@ def group_leg(ctx, taps, total_channels, n_ch, devices, steps, warmup):
             "devices": list(devices), "shards": [[d, f, c] for d, f, c, _, _ in sh],
             "parity": {"rel_rms_max": worst, "windows": count, "window_len": W, "tol": TOL, "ok": bool(worst <= TOL)},
             "checksum": {"samples": csum[0], "sum_re": csum[1], "sum_im": csum[2], "sum_abs2": csum[3]},
+            "buffers": probes if any(probes) else None,
             "timed": "wall clock around %d sfe_dsp_fir_group_process_stream calls + one sfe_dsp_fir_group_sync" % steps}
 
 
@@ -641,7 +645,7 @@ def main_single_process(args):
     if torch.cuda.device_count() < args.gpus and not one_dev:
         raise SystemExit(f"--gpus {args.gpus} but this node shows {torch.cuda.device_count()} GPU(s)")
     devices = [0] * args.gpus if one_dev else list(range(args.gpus))
-    ctx = {"torch": torch, "api": api, "lib": lib, "synth": synth, "shard": shard, "L": lib.load()}
+    ctx = {"torch": torch, "api": api, "lib": lib, "synth": synth, "shard": shard, "L": lib.load(), "screen": args.screen}
     total_channels = args.channels or 64
     log2n = args.log2n or 30
     n_ch = (1 << log2n) // total_channels

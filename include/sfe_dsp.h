@@ -340,8 +340,10 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
  * with >= 12 taps per phase take the 4096-point transform kernel (all phases of every
  * input sample by one forward and `upsample` inverse transforms, blended by the reference's own
  * (pos, mu) sequence; a real stream's transforms carry two blocks each), at any rate the class
- * accepts -- below 1 too, down to 1 / upsample; FFT: at any size; DIRECT, the exact mode and u8
- * streams: the direct kernel.  The number of outputs per call is the reference's in every case.
+ * accepts -- below 1 too, down to 1 / upsample; FFT: at any size; DIRECT and the exact mode: the
+ * direct kernel.  u8 streams (SFE_FMT_U8) at such a step ALWAYS take the transform kernel, which
+ * converts on load (the direct kernels have no u8 form: the exact mode and DIRECT return
+ * SFE_ESTATE for them).  The number of outputs per call is the reference's in every case.
  * The library reads no environment variable. */
 #define SFE_RS_ALGO_AUTO    0
 #define SFE_RS_ALGO_DIRECT  1

@@ -449,8 +449,10 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         r->ts.mu = 0.0f;
         *n_out = (size_t)K;
     } else {
-        if (r->in_u8) {
-            set_error("rs_process_stream: u8 input is supported for integer-valued steps only");
+        // u8 input at a general rate: the transform-domain kernel converts on load (poly_gen.hip: IN_U8); the direct kernels
+        // (exact mode, SFE_RS_ALGO_DIRECT) have no u8 form
+        if (r->in_u8 && (r->exact_stream || r->fft_mode < 0)) {
+            set_error("rs_process_stream: u8 input at a non-integer step runs the transform-domain kernel only (not the exact mode, not SFE_RS_ALGO_DIRECT)");
             return SFE_ESTATE;
         }
         // Replay the float32 recurrence call by call (blksize samples each), as the reference
@@ -596,12 +598,12 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
         r->plan_stream = s;
         sa.segs = r->d_segs;
         sa.chunks = static_cast<const SegChunk *>(r->d_chunks);
-        // Bulk calls of float32 streams (complex or real) in fused arithmetic, at any rate: the transform-domain kernel (poly_gen.hip) --
+        // Bulk calls (complex or real, float32 or u8) in fused arithmetic, at any rate: the transform-domain kernel (poly_gen.hip) --
         // all U phases of every input by one forward and U inverse 4096-point transforms, outputs picked and blended from
         // LDS by the same runs.  sfe_dsp_rs_set_algo(SFE_RS_ALGO_DIRECT) and the exact mode keep poly_seg_kernel.
         rc = SFE_ESTATE;
-        if (!exhausted && !r->exact_stream && !r->in_u8 && r->fft_mode >= 0 &&
-            (r->fft_mode > 0 || (n_in >= ((size_t)1 << 16) && r->plen >= 12))) {
+        if (!exhausted && !r->exact_stream && r->fft_mode >= 0 &&
+            (r->fft_mode > 0 || r->in_u8 || (n_in >= ((size_t)1 << 16) && r->plen >= 12))) {
             if (!r->gen_tried) {
                 // spectra of the U phase filters (taps[i U + j], i < plen; one zero behind so that the overlap the FIR
                 // planner picks covers plen samples, not plen - 1) through fir_build_tables: one "channel" per phase
@@ -639,6 +641,7 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
                 ga.blksize = r->blksize;
                 ga.n_chunks = (int)chunks.size();
                 ga.real = r->data_complex ? 0 : 1;
+                ga.in_u8 = r->in_u8 ? 1 : 0;
                 int max_runs = 0;              // over any two (a real stream's pairs of blocks: three) consecutive calls
                 for (size_t i = 0; i < chunks.size(); i++) {
                     int sum = chunks[i].n_seg + (i + 1 < chunks.size() ? chunks[i + 1].n_seg : 0);
@@ -647,6 +650,12 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
                 }
                 rc = launch_poly_gen(ga, max_runs, stepf, r->n_channels, s);
             }
+        }
+        if (rc == SFE_ESTATE && r->in_u8) {
+            set_error("rs_process_stream: u8 input at a non-integer step: this call is outside what the transform-domain kernel takes "
+                      "(more than 2032 taps per phase, more than 32 phases, blksize below a block's advance, or a call in the "
+                      "reference's out_len-exhausted state)");
+            return SFE_ESTATE;
         }
         if (rc == SFE_ESTATE) rc = launch_poly_seg(sa, r->data_complex, r->exact_stream, r->n_channels, s);
         if (rc == SFE_ESTATE) {

@@ -263,6 +263,7 @@ struct PolyGenArgs {
     int         hl, U, plen, ovl, blksize, n_chunks;
     int         adv;            // input samples a block owns (launcher: 4096 - ovl, fewer for rates below ~1)
     int         real;           // a real float32 stream: two consecutive blocks per transform (poly_gen.hip: REAL)
+    int         in_u8;          // the stream is u8 offset binary, converted on load (poly_gen.hip: IN_U8)
     // (the diagnostic persistent form only, diag/poly_gen_persistent.hip: blocks per channel in a launch's list, where the
     // list starts, channels, blocks dealt by a device counter)
     long long   nblk, blk_first;

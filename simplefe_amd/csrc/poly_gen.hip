@@ -27,7 +27,8 @@
 //   3. the outputs are stored, lanes = consecutive outputs
 // (pos, mu) are the reference's own sequence, bit for bit (the runs reproduce the float32 recurrence);
 // the arithmetic is fused and transform-domain: rel-RMS ~3e-7 against the oracle, the exact mode stays on
-// poly_seg_kernel.  Complex and real float32 streams (REAL below), any rate the reference takes (>= 1 / U).
+// poly_seg_kernel.  Complex and real streams (REAL below), float32 or the u8 wire format (IN_U8), any rate the reference
+// takes (>= 1 / U).
 #include <stdint.h>
 
 #include <type_traits>
@@ -61,7 +62,10 @@ constexpr int GEN_MAX_RUNS = 1024;       // runs of the (at most two) calls a bl
 // and each table entry says which half its two samples are read from; twice the outputs per transform, KPT up to 22
 // (two workgroups per CU).  The direct kernel ran such a stream at 0.05 of the roofline (2^29 samples, rate 1.77, 381 taps
 // in 3 phases: 8.65 ms).
-template <int KPT, bool REAL>
+// IN_U8: the stream is the device's receive wire format, u8 offset binary ((I, Q) byte pairs; REAL: one byte per sample),
+// converted as the rows are loaded -- (b - 128) / 127, the reference's converter (gr-simplefe/lib/source_c_impl.cc:121-132):
+// the same bits as the float32 path fed the converted samples.  The carried history is float32 either way.
+template <int KPT, bool REAL, bool IN_U8>
 __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(PolyGenArgs a)
 {
     constexpr int NC = REAL ? 3 : 2;             // reference calls a block (pair) can overlap: its span <= (REAL ? 2 : 1) x blksize
@@ -81,7 +85,23 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
     // ---- the block's 16 rows (thread t: samples base + t + 256 r): requested first, they land under step 0
     v2f nx[16];
     const long long base = blk * A - a.ovl;
-    if constexpr (!REAL) {
+    if constexpr (IN_U8) {
+        const unsigned char *in8 = static_cast<const unsigned char *>(a.in) + (size_t)ch * a.in_stride * (REAL ? 1 : 2);
+        auto at = [&](long long i) -> E {
+            if (i >= 0) {
+                if (i >= a.n_in) return E{};
+                if constexpr (REAL) return u8_to_f32(in8[i]);
+                else return (v2f){u8_to_f32(in8[2 * i]), u8_to_f32(in8[2 * i + 1])};
+            }
+            return i >= -(long long)a.hl ? hist[a.hl + i] : E{};
+        };
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const long long i = base + 256 * r + (long long)t;
+            if constexpr (REAL) nx[r] = (v2f){at(i), at(i + A)};
+            else nx[r] = at(i);
+        }
+    } else if constexpr (!REAL) {
         if (base >= 0 && base + FFT_N <= a.n_in) {
 #pragma unroll
             for (int r = 0; r < 16; r++) nx[r] = __builtin_nontemporal_load(in + base + 256 * r + t);
@@ -452,16 +472,22 @@ int launch_poly_gen(const PolyGenArgs &a0, int max_runs, float step, int n_chann
     if (nblk > 0x7fffffffLL) return SFE_ESTATE;
     dim3 grid((unsigned)nblk, (unsigned)n_channels), block(256);
     const int kpt = (per_block + 255) / 256;
+#define SFE_GEN(KPTv, REALv)                                                                           \
+    do {                                                                                              \
+        if (a.in_u8) hipLaunchKernelGGL((poly_gen4096_kernel<KPTv, REALv, true>), grid, block, 0, s, a);      \
+        else hipLaunchKernelGGL((poly_gen4096_kernel<KPTv, REALv, false>), grid, block, 0, s, a);            \
+    } while (0)
     if (a.real) {
-        if (kpt <= 12) hipLaunchKernelGGL((poly_gen4096_kernel<12, true>), grid, block, 0, s, a);
-        else if (kpt <= 18) hipLaunchKernelGGL((poly_gen4096_kernel<18, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((poly_gen4096_kernel<22, true>), grid, block, 0, s, a);
+        if (kpt <= 12) SFE_GEN(12, true);
+        else if (kpt <= 18) SFE_GEN(18, true);
+        else SFE_GEN(22, true);
     } else {
-        if (kpt <= 6) hipLaunchKernelGGL((poly_gen4096_kernel<6, false>), grid, block, 0, s, a);
-        else if (kpt <= 9) hipLaunchKernelGGL((poly_gen4096_kernel<9, false>), grid, block, 0, s, a);
-        else if (kpt <= 12) hipLaunchKernelGGL((poly_gen4096_kernel<12, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((poly_gen4096_kernel<16, false>), grid, block, 0, s, a);
+        if (kpt <= 6) SFE_GEN(6, false);
+        else if (kpt <= 9) SFE_GEN(9, false);
+        else if (kpt <= 12) SFE_GEN(12, false);
+        else SFE_GEN(16, false);
     }
+#undef SFE_GEN
     SFE_HIP(hipGetLastError());
     return SFE_OK;
 }

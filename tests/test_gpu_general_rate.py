@@ -121,3 +121,35 @@ def test_default_dispatch_takes_the_transform_kernel_for_bulk_calls_only(api, L)
     e.set_exact(True)
     a, b = r.resample_array(x[: 2 << 16], below)[0], e.resample_array(x[: 2 << 16], below)[0]
     assert len(a) == len(b) and synth.rel_rms(a, b) <= TOL
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+@pytest.mark.parametrize("rate", [1.77, 0.77])
+def test_transform_domain_general_rate_u8_input(api, L, orc, cplx, rate):
+    """The transform kernel reading the receive wire format (u8 offset binary) converts on load: the same bits as the
+    same kernel fed the converted float32 samples in the same calls, and within tolerance of converter -> oracle."""
+    taps, U = synth.taps_cfg3(), 3
+    rate = float(np.float32(rate))
+    n, B, w = 70000, 4096, 2 if cplx else 1
+    b = np.random.default_rng(31).integers(0, 256, size=w * n, dtype=np.uint8)
+    xf = orc.rx_u8_to_f32(b)
+    outs = {}
+    for fmt in ("f32", "u8"):
+        r = api.Rs(taps, U, B, mode=L.RS_RESAMPLE, data_complex=cplx)
+        r.set_algo(L.RS_ALGO_FFT)
+        if fmt == "u8":
+            r.set_input_format(L.FMT_U8)
+        got = []
+        for a0, a1 in ((0, 8 * B), (8 * B, 13 * B), (13 * B, n)):
+            m = a1 - a0
+            d_in = api.DeviceArray.from_bytes(b[w * a0:w * a1]) if fmt == "u8" else api.DeviceArray.from_numpy(xf[w * a0:w * a1])
+            cap = int(m / rate) + 64
+            d_out = api.DeviceArray(w * cap)
+            k = r.process_stream(d_in, m, d_out, cap, rate)
+            got.append(d_out.to_numpy(w * k))
+        outs[fmt] = np.concatenate(got)
+    assert np.array_equal(outs["u8"], outs["f32"])
+    for part in range(w):
+        ref, _ = orc.Resample(taps, U, B).stream(np.ascontiguousarray(xf[part::w]), rate)
+        got = outs["u8"][part::w]
+        assert len(ref) - len(got) in (0, 1) and synth.rel_rms(got, ref[: len(got)]) <= TOL
