@@ -185,8 +185,37 @@ static int copy_pairs()
     return 0;
 }
 
+// `big`: ONE arena of 192 GiB: the input at its start, the output at 8 GiB steps across all of it -- if a class were a high
+// physical-address bit (>= 2^35), a contiguous arena this large would show both classes at some offset
+static int big()
+{
+    const size_t N = (size_t)1 << 30, G = (size_t)1 << 30;
+    char *arena = nullptr;
+    size_t total = 192;
+    while (total >= 64 && hipMalloc(&arena, total * G) != hipSuccess) {
+        (void)hipGetLastError();
+        total -= 32;
+    }
+    if (!arena) return 1;
+    printf("arena %p, %zu GiB\n", arena, total);
+    CK(hipMemset(arena, 1, 8 * G));
+    const unsigned tiles = (unsigned)(N / 4096);
+    auto mix = [&](size_t in_off, size_t out_off) {
+        return med([&] { hipLaunchKernelGGL(k_mix, dim3(tiles), dim3(256), 0, 0, (const v2f *)(arena + in_off), (v4f *)(arena + out_off)); });
+    };
+    for (int i = 0; i < 40; i++) hipLaunchKernelGGL(k_mix, dim3(tiles), dim3(256), 0, 0, (const v2f *)arena, (v4f *)(arena + 8 * G));
+    for (size_t o = 8; o + 1 <= total; o += 8) printf("input at 0, output at %3zu GiB: mix %.4f ms\n", o, mix(0, o * G));
+    // and a second allocation beside the arena, for the other class if it exists at all in this process
+    void *other = nullptr;
+    CK(hipMalloc(&other, 2 * G));
+    const double t = med([&] { hipLaunchKernelGGL(k_mix, dim3(tiles), dim3(256), 0, 0, (const v2f *)arena, (v4f *)other); });
+    printf("input at 0 of the arena, output in ANOTHER allocation: mix %.4f ms\n", t);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc > 1 && argv[1][0] == 'b') return big();
     if (argc > 1 && argv[1][0] == 'c') return copy_pairs();
     if (argc > 1 && argv[1][0] == 's') return sweep();
     if (argc > 1 && argv[1][0] == 'p') return pairs();
