@@ -1279,3 +1279,25 @@ def test_malloc_pair_and_probe_pair(L):
     # tries = 1, tiny sizes: two plain allocations, nothing probed
     assert lib.sfe_dsp_malloc_pair(64, 64, 1, C.byref(d_in), C.byref(d_out), C.byref(kept), None) == 0
     assert lib.sfe_dsp_free(d_in) == 0 and lib.sfe_dsp_free(d_out) == 0
+
+
+def test_fir_per_channel_taps_ticket_groups_by_channel(api, L):
+    """Sixteen channels (a multiple of the eight ticket groups) with more transforms than resident workgroups: the launch
+    deals each group whole channels (FirFftArgs::ch_groups, DESIGN.md 4.1) -- every channel against a single-channel handle
+    with that channel's taps (the same transform arithmetic: identical bits), two calls, state carried."""
+    rng = np.random.default_rng(16)
+    nch, n = 16, 330000                     # 86 transforms per channel: 1376 tickets for ~1024 workgroups
+    taps = rng.standard_normal((nch, 256)).astype(np.float32) / 16.0
+    x = np.stack([synth.synth_cf32(n, ch=40 + c) for c in range(nch)])
+    d_in = api.DeviceArray.from_numpy(x)
+    d_out = api.DeviceArray(nch * 2 * n)
+    f = api.Fir(taps, per_channel=True)
+    cut = 200000
+    f.process_stream(d_in, d_out, cut, in_stride=n, out_stride=n)
+    f.process_stream(d_in.ptr + 8 * cut, d_out.ptr + 8 * cut, n - cut, in_stride=n, out_stride=n)
+    y = d_out.to_numpy().reshape(nch, 2 * n)
+    for c in range(nch):
+        one = api.Fir(taps[c], data_complex=True, algo=L.FIR_ALGO_FFT)
+        a = one.filter(x[c, : 2 * cut])[0]
+        b = one.filter(x[c, 2 * cut:])[0]
+        assert np.array_equal(y[c], np.concatenate([a, b])), c
