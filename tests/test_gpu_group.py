@@ -97,3 +97,27 @@ def test_group_argument_checks(api, L):
     with pytest.raises(api.SfeError) as e:
         api.FirGroup(synth.taps_cfg2(), 4, [0, 99])            # no such device
     assert e.value.code == L.SFE_ENODEV
+
+
+def test_group_call_that_fails_part_way_is_refused_until_reset(api, L):
+    """A group call that fails after some shards have taken their launch leaves the shards out of step (for the resamplers:
+    their time states): further calls return SFE_ESTATE until _reset (include/sfe_dsp.h).  A failure at the FIRST shard has
+    moved nothing and leaves the group usable."""
+    from simplefe_amd.lib import SfeError
+    nch, n = 4, 8192
+    grp = api.FirGroup(synth.taps_cfg2(), nch, [0, 0])
+    x = _streams(api, nch, n)
+    ys = [api.DeviceArray(2 * n * 2), api.DeviceArray(2 * n * 2)]
+    good_in = [x.ptr, x.ptr + 8 * n * 2]
+    with pytest.raises(SfeError):                                   # shard 0 refuses: nothing has moved
+        grp.process_stream([0, good_in[1]], ys, n)
+    grp.process_stream(good_in, ys, n)
+    with pytest.raises(SfeError):                                   # shard 1 refuses after shard 0 has run
+        grp.process_stream([good_in[0], 0], ys, n)
+    with pytest.raises(SfeError) as e:
+        grp.process_stream(good_in, ys, n)
+    assert e.value.code == L.SFE_ESTATE and "out of step" in str(e.value)
+    grp.reset()
+    grp.process_stream(good_in, ys, n)
+    grp.sync()
+    grp.close()
