@@ -260,11 +260,18 @@ def screened_output(ctx, leg, src, numel, dtype):
     import ctypes as C
     torch, L, dev = ctx["torch"], ctx["L"], ctx["dev"]
     tries = max(1, int(ctx.get("screen", 1)))
-    cands, ms = [], []
+    cands, ms, spacers = [], [], []
     for k in range(2 * tries if tries > 1 else 1):
-        # (twice as many where the first `tries` show no spread: all of one class -- the input's, one time in eight -- or all of the other)
+        # twice as many where the first `tries` show no spread (all of one class): the further ones from OTHER stretches of the
+        # memory -- the classes run in stretches of tens of GiB and a fresh process tends to be handed what
+        # the last one freed -- by way of a 32 GiB spacer in front of each pair of them, held until the choice is made
         if k >= tries and (min(ms) <= 0 or min(ms) < 0.96 * max(ms)):
             break
+        if k >= tries and (k - tries) % 2 == 0:
+            try:
+                spacers.append(torch.empty(32 << 30, dtype=torch.uint8, device=dev))
+            except RuntimeError:
+                pass
         try:
             y = torch.empty(numel, dtype=dtype, device=dev)
         except RuntimeError:                      # out of memory further on: choose among what there is
@@ -281,7 +288,12 @@ def screened_output(ctx, leg, src, numel, dtype):
     best = int(np.argmin(ms))
     if tries > 1:
         leg.buffers = {"output_candidates": len(cands), "probe_ms": [round(v, 4) for v in ms], "kept": best}
-    return cands[best]
+        if spacers:
+            leg.buffers["spacers_gib"] = 32 * len(spacers)
+    y = cands[best]
+    del cands, spacers
+    torch.cuda.empty_cache()                      # the losers and the spacers go back to the driver, not into torch's cache
+    return y
 
 
 def screened_input(ctx, leg, src, y):
@@ -294,10 +306,16 @@ def screened_input(ctx, leg, src, y):
     b = getattr(leg, "buffers", None)
     if not b or len(b["probe_ms"]) < 2 or min(b["probe_ms"]) < 0.96 * max(b["probe_ms"]):
         return src
+    spacer = None
+    try:
+        spacer = torch.empty(32 << 30, dtype=torch.uint8, device=src.device)      # (another stretch of the memory: screened_output)
+    except RuntimeError:
+        pass
     try:
         alt = torch.empty_like(src)
     except RuntimeError:
         return src
+    del spacer
     t = C.c_float(0.0)
     torch.cuda.synchronize()
     ctx["api"].check(L.sfe_dsp_probe_pair(alt.data_ptr(), alt.numel() * alt.element_size(), y.data_ptr(), y.numel() * y.element_size(), C.byref(t)))

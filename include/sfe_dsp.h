@@ -72,9 +72,11 @@ int sfe_dsp_free(void *dptr);
  * a property of the platform's memory, seen by any streaming kernel, the bare copy included).
  * probe_pair: the median time of five launches of the bare mix over (d_in, d_out) -- every 32 KiB read, the output
  *   written in proportion -- on the null stream, synchronous; the output's contents are overwritten.
- * malloc_pair: the input, then up to `tries` (1 .. 16) candidates for the output, each probed against it; the fastest is
- *   kept, the others freed (all stay allocated until the choice is made); where the candidates show no spread (within 4 %)
- *   one more allocation for the input is probed and kept if it is faster.  tries = 1: two plain allocations.  ms_kept /
+ * malloc_pair: the input, then up to `tries` (1 .. 8) candidates for the output, each probed against it; the fastest is
+ *   kept, the others freed (all stay allocated until the choice is made).  While the candidates show no spread (within
+ *   4 %: all of one class) up to as many again are tried, each pair of them behind a 32 GiB spacer that is freed with the
+ *   losers (the classes run in stretches of tens of GiB and a fresh process tends to be handed what the last one freed),
+ *   and in the end one more allocation for the input.  tries = 1: two plain allocations.  ms_kept /
  *   ms_worst (may be NULL): the probe times of the kept and of the slowest candidate.  Free both with sfe_dsp_free. */
 int sfe_dsp_probe_pair(const void *d_in, size_t in_bytes, void *d_out, size_t out_bytes, float *ms);
 int sfe_dsp_malloc_pair(size_t in_bytes, size_t out_bytes, int tries, void **d_in, void **d_out, float *ms_kept, float *ms_worst);

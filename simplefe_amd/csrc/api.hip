@@ -151,18 +151,31 @@ int sfe_dsp_probe_pair(const void *d_in, size_t in_bytes, void *d_out, size_t ou
 
 int sfe_dsp_malloc_pair(size_t in_bytes, size_t out_bytes, int tries, void **d_in, void **d_out, float *ms_kept, float *ms_worst)
 {
-    if (!d_in || !d_out || tries < 1 || tries > 16) {
-        set_error("malloc_pair: null argument or tries outside 1 .. 16");
+    if (!d_in || !d_out || tries < 1 || tries > 8) {
+        set_error("malloc_pair: null argument or tries outside 1 .. 8");
         return SFE_EINVAL;
     }
     *d_in = *d_out = nullptr;
-    void *in = nullptr, *cand[16] = {nullptr};
+    void *in = nullptr, *cand[16] = {nullptr}, *spacer[4] = {nullptr};
     float ms[16];
     SFE_HIP(hipMalloc(&in, in_bytes ? in_bytes : 16));
-    int n = 0, rc = SFE_OK, best = 0;
-    const bool probe = in_bytes >= 32768 && out_bytes >= 4096;
-    // every candidate stays allocated until the choice is made: a freed one's pages would come straight back
-    for (; n < (probe ? tries : 1); n++) {
+    int n = 0, rc = SFE_OK, best = 0, n_spacers = 0;
+    float worst = 0.0f;
+    const bool probe = tries > 1 && in_bytes >= 32768 && out_bytes >= 4096;
+    const size_t SPACER = (size_t)32 << 30;
+    auto spaced = [&]() {                        // the classes run in stretches of tens of GiB: step over one
+        size_t free_b = 0, total_b = 0;
+        if (n_spacers < 4 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > SPACER + 2 * out_bytes + in_bytes) {
+            if (hipMalloc(&spacer[n_spacers], SPACER) == hipSuccess) n_spacers++;
+            else (void)hipGetLastError();
+        }
+    };
+    // every candidate stays allocated until the choice is made: a freed one's pages would come straight back.  Up to `tries`
+    // candidates; twice as many, each pair of the further ones behind a 32 GiB spacer, while they show no spread (within 4 %:
+    // all of one class -- a fresh process tends to be handed what the last one freed)
+    for (; n < (probe ? 2 * tries : 1); n++) {
+        if (n >= tries && ms[best] < 0.96f * worst) break;
+        if (n >= tries && (n - tries) % 2 == 0) spaced();
         const hipError_t e = hipMalloc(&cand[n], out_bytes ? out_bytes : 16);
         if (e != hipSuccess) {
             (void)hipGetLastError();
@@ -176,13 +189,12 @@ int sfe_dsp_malloc_pair(size_t in_bytes, size_t out_bytes, int tries, void **d_i
             break;
         }
         if (ms[n] < ms[best]) best = n;
+        if (ms[n] > worst) worst = ms[n];
     }
-    float worst = 0.0f;
-    for (int i = 0; i < n; i++)
-        if (ms[i] > worst) worst = ms[i];
-    // no spread among the outputs -- all of the input's class, or all of the other (the class of a pair is an exclusive-or of
-    // its two allocations'): one more allocation for the INPUT, kept if the pair is at least 4 % faster
+    // still no spread: the class of a pair is an exclusive-or of its two allocations' -- one more allocation for the INPUT,
+    // from another stretch, kept if the pair is at least 4 % faster
     if (rc == SFE_OK && probe && n >= 2 && ms[best] >= 0.96f * worst) {
+        spaced();
         void *alt = nullptr;
         if (hipMalloc(&alt, in_bytes) == hipSuccess) {
             float t = 0.0f;
@@ -199,6 +211,7 @@ int sfe_dsp_malloc_pair(size_t in_bytes, size_t out_bytes, int tries, void **d_i
     }
     for (int i = 0; i < n; i++)
         if (rc != SFE_OK || i != best) (void)hipFree(cand[i]);
+    for (int i = 0; i < n_spacers; i++) (void)hipFree(spacer[i]);
     if (rc != SFE_OK) {
         (void)hipFree(in);
         return rc;
