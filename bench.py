@@ -296,6 +296,38 @@ def screened_output(ctx, leg, src, numel, dtype):
     return y
 
 
+class _DevMem:
+    """A library allocation as a torch tensor's storage (__cuda_array_interface__)."""
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def built_pair(ctx, leg, n_in_f32, numel_out, dtype_out):
+    """The leg's input and output as a pair BUILT by the library (sfe_dsp_malloc_pair: 1 GiB physical chunks classified with
+    the bare mix, the input mapped from one class and the output from another) -- for the legs whose input is
+    4 GiB and more, where what a plain pair gives is a lottery worth 8 % (decimate) to 18 % (8 GiB : 8 GiB in the bare mix).
+    Returns (x, y) float32 / dtype_out tensors over that memory, or None (--screen 1, or the library fell back and could
+    not do better than plain allocations: the caller then screens plain tensors).  Outside the timed region; reported."""
+    import ctypes as C
+    torch, L, dev = ctx["torch"], ctx["L"], ctx["dev"]
+    if int(ctx.get("screen", 1)) <= 1 or 4 * n_in_f32 < (4 << 30):
+        return None
+    esz = torch.empty(0, dtype=dtype_out).element_size()
+    a, b, kept, worst = C.c_void_p(), C.c_void_p(), C.c_float(), C.c_float()
+    t0 = time.perf_counter()
+    torch.cuda.synchronize()
+    rc = L.sfe_dsp_malloc_pair(4 * n_in_f32, esz * numel_out, int(ctx["screen"]), C.byref(a), C.byref(b), C.byref(kept), C.byref(worst))
+    if rc != 0:
+        return None
+    typestr = {torch.float32: "<f4", torch.uint8: "|u1"}[dtype_out]
+    x = torch.as_tensor(_DevMem(a.value, n_in_f32, "<f4"), device=dev)
+    y = torch.as_tensor(_DevMem(b.value, numel_out, typestr), device=dev)
+    ctx.setdefault("_library_memory", []).append((a, b))          # (lives as long as the process)
+    leg.buffers = {"pair": "sfe_dsp_malloc_pair", "probe_ms": [round(float(kept.value), 4)], "kept": 0,
+                   "same_class_probe_ms": round(float(worst.value), 4), "seconds": round(time.perf_counter() - t0, 2)}
+    return x, y
+
+
 def screened_input(ctx, leg, src, y):
     """Where the output candidates showed NO spread against `src` -- all of the input's class, or all of the other -- one
     more allocation for the INPUT is probed against the kept output; if that pair is at least 4 % faster the samples are copied
@@ -339,10 +371,13 @@ def make_fir_leg(ctx, name, taps, n, nch, ch0=0, algo="auto", in_fmt="f32", out_
     n_gpu = n * nch
     leg.n, leg.nch, leg.n_gpu = n, nch, n_gpu
     leg.seeds = [ch0 + c for c in range(nch)]                  # global channel id = its seed
+    pair = None
     if x_share is not None:
         x = x_share
     else:
-        x = torch.empty(nch * n * 2, dtype=torch.float32, device=dev)
+        if in_fmt == "f32" and out_fmt == "f32" and y_share is None:
+            pair = built_pair(ctx, leg, nch * n * 2, nch * n * 2, torch.float32)
+        x = pair[0] if pair else torch.empty(nch * n * 2, dtype=torch.float32, device=dev)
         for c in range(nch):
             api.check(L.sfe_dsp_synth_fill(x.data_ptr() + c * n * 8, 2 * n, synth.SEED, leg.seeds[c], 0, stream))
     in_bytes, out_bytes = 8.0, 8.0
@@ -380,7 +415,7 @@ def make_fir_leg(ctx, name, taps, n, nch, ch0=0, algo="auto", in_fmt="f32", out_
         leg.workload += ", 10-bit packed transmit wire format out"
         leg.y = screened_output(ctx, leg, src, nch * (n * 2 // 4) * 5 + 64, torch.uint8)
     else:
-        leg.y = y_share if y_share is not None else screened_output(ctx, leg, src, nch * n * 2, torch.float32)
+        leg.y = y_share if y_share is not None else (pair[1] if pair else screened_output(ctx, leg, src, nch * n * 2, torch.float32))
     leg.out_fmt = out_fmt
     leg.bytes_per_launch = (in_bytes + out_bytes) * n_gpu       # 8 B read + 8 B written per sample
     leg.kernel = "fir_fft4096_kernel" if algo != "direct" else "poly_tiled_kernel"
@@ -485,7 +520,8 @@ def make_rs_leg(ctx, which, log2n, in_fmt="f32", short_proto=False):
         leg.key = "decimate8_cf32_2p%d" % log2n
     rate = float(np.float32(S) / np.float32(U))
     leg.taps, leg.U, leg.S, leg.rate = taps, U, S, rate
-    x = torch.empty(n * 2, dtype=torch.float32, device=dev)
+    pair = built_pair(ctx, leg, n * 2, (n * U // S + 8) * 2, torch.float32) if in_fmt != "u8" else None
+    x = pair[0] if pair else torch.empty(n * 2, dtype=torch.float32, device=dev)
     api.check(L.sfe_dsp_synth_fill(x.data_ptr(), 2 * n, synth.SEED, 0, 0, stream))
     src, in_bytes = x, 8.0
     if in_fmt == "u8":
@@ -496,12 +532,15 @@ def make_rs_leg(ctx, which, log2n, in_fmt="f32", short_proto=False):
         leg.workload += ", u8 (I,Q) wire-format input converted on load"
     leg.x, leg._src = x, src
     out_cap = n * U // S + 8
-    leg.y = screened_output(ctx, leg, src, out_cap * 2, torch.float32)
-    moved = screened_input(ctx, leg, src, leg.y)
-    if moved is not src:
-        if x is src:
-            x = leg.x = moved
-        src = leg._src = moved
+    if pair:
+        leg.y = pair[1]
+    else:
+        leg.y = screened_output(ctx, leg, src, out_cap * 2, torch.float32)
+        moved = screened_input(ctx, leg, src, leg.y)
+        if moved is not src:
+            if x is src:
+                x = leg.x = moved
+            src = leg._src = moved
     leg.obj = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE if which == "resample" else lib.RS_DECIMATE,
                      data_complex=True, n_channels=1, device=ctx["local_rank"])
     if in_fmt == "u8":

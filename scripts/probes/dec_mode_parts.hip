@@ -213,8 +213,73 @@ static int big()
     return 0;
 }
 
+// `vmm`: can a pair be BUILT?  64 physical chunks of 1 GiB (hipMemCreate), each classified against chunk 0 with the bare 1 : 1
+// copy; then an 8 GiB input stitched from chunks of one class and a 1 GiB output from the other (hipMemMap into contiguous
+// virtual ranges), against an input and an output both from one class: the 8 : 1 mix and the decimator on both pairs.
+static int vmm()
+{
+    const size_t G = (size_t)1 << 30, N = (size_t)1 << 30;
+    const int NCH = 64;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    std::vector<hipMemGenericAllocationHandle_t> h(NCH);
+    char *va = nullptr;
+    CK(hipMemAddressReserve((void **)&va, NCH * G, G, nullptr, 0));
+    int got = 0;
+    for (; got < NCH; got++) {
+        if (hipMemCreate(&h[got], G, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
+        CK(hipMemMap(va + got * G, G, 0, h[got], 0));
+    }
+    CK(hipMemSetAccess(va, got * G, &acc, 1));
+    CK(hipMemset(va, 1, got * G));
+    // classify: copy chunk 0 -> chunk c (1 GiB : 1 GiB)
+    const unsigned tiles1 = (unsigned)(G / 8 / 4096);
+    std::vector<double> t(got, 0.0);
+    for (int c = 1; c < got; c++)
+        t[c] = med([&] { hipLaunchKernelGGL(k_copy11, dim3(tiles1), dim3(256), 0, 0, (const v2f *)va, (v2f *)(va + c * G)); });
+    double lo = 1e9, hi = 0;
+    for (int c = 1; c < got; c++) { lo = std::min(lo, t[c]); hi = std::max(hi, t[c]); }
+    printf("%d chunks; copy chunk 0 -> chunk c: min %.4f max %.4f ms\n  ", got, lo, hi);
+    for (int c = 1; c < got; c++) printf("%.3f ", t[c]);
+    printf("\n");
+    std::vector<int> same, other;            // same class as chunk 0 = the slow copies
+    same.push_back(0);
+    for (int c = 1; c < got; c++) (t[c] > 0.5 * (lo + hi) ? same : other).push_back(c);
+    printf("class of chunk 0: %zu chunks, other class: %zu chunks\n  ", same.size(), other.size());
+    for (int c = 1; c < got; c++) printf("%c", t[c] > 0.5 * (lo + hi) ? 'S' : 'o');
+    printf("\n");
+    if (hi < 1.04 * lo || same.size() < 9 || other.size() < 9) { printf("no two classes with nine chunks each here\n"); return 0; }
+    // stitch: input A = 8 chunks of `same`, output X = 1 chunk of `other` (different classes), output Y = 1 chunk of `same`
+    char *vin = nullptr, *vx = nullptr, *vy = nullptr, *vin2 = nullptr;
+    CK(hipMemAddressReserve((void **)&vin, 8 * G, G, nullptr, 0));
+    CK(hipMemAddressReserve((void **)&vin2, 8 * G, G, nullptr, 0));
+    CK(hipMemAddressReserve((void **)&vx, 2 * G, G, nullptr, 0));
+    CK(hipMemAddressReserve((void **)&vy, 2 * G, G, nullptr, 0));
+    for (int i = 0; i < 8; i++) CK(hipMemMap(vin + i * G, G, 0, h[same[i]], 0));            // (a chunk may be mapped twice)
+    for (int i = 0; i < 8; i++) CK(hipMemMap(vin2 + i * G, G, 0, h[other[i]], 0));
+    for (int i = 0; i < 2; i++) CK(hipMemMap(vx + i * G, G, 0, h[other[8 + i - (other.size() < 10 ? 1 : 0) * i]], 0));
+    for (int i = 0; i < 2; i++) CK(hipMemMap(vy + i * G, G, 0, h[same[8 + i - (same.size() < 10 ? 1 : 0) * i]], 0));
+    CK(hipMemSetAccess(vin, 8 * G, &acc, 1));
+    CK(hipMemSetAccess(vin2, 8 * G, &acc, 1));
+    CK(hipMemSetAccess(vx, 2 * G, &acc, 1));
+    CK(hipMemSetAccess(vy, 2 * G, &acc, 1));
+    const unsigned tiles = (unsigned)(N / 4096);
+    auto mix = [&](const char *i, char *o) { return med([&] { hipLaunchKernelGGL(k_mix, dim3(tiles), dim3(256), 0, 0, (const v2f *)i, (v4f *)o); }); };
+    printf("input of class 0, output of class 1: mix %.4f ms\n", mix(vin, vx));
+    printf("input of class 0, output of class 0: mix %.4f ms\n", mix(vin, vy));
+    printf("input of class 1, output of class 0: mix %.4f ms\n", mix(vin2, vy));
+    printf("input of class 1, output of class 1: mix %.4f ms\n", mix(vin2, vx));
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc > 1 && argv[1][0] == 'v') return vmm();
     if (argc > 1 && argv[1][0] == 'b') return big();
     if (argc > 1 && argv[1][0] == 'c') return copy_pairs();
     if (argc > 1 && argv[1][0] == 's') return sweep();

@@ -23,7 +23,7 @@ ARCH = "gfx950"
 EXACT_SOURCES = ("polyphase.hip", "util.hip")
 TICKET_SOURCES = ("fir_fft.hip", "poly_fft.hip")
 # host side only (handles, plans, launch choices, device groups): not part of the kernel-source hash
-HOST_SOURCES = ("api.hip", "api_plans.hip", "api_fir.hip", "api_rs.hip", "api_pipe.hip", "group.hip", "host.h")
+HOST_SOURCES = ("api.hip", "api_plans.hip", "api_fir.hip", "api_rs.hip", "api_pipe.hip", "group.hip", "alloc.hip", "host.h")
 
 
 def sources(diag=False):

@@ -104,125 +104,7 @@ int sfe_dsp_malloc(void **dptr, size_t bytes)
     SFE_HIP(hipMalloc(dptr, bytes ? bytes : 16));
     return SFE_OK;
 }
-int sfe_dsp_free(void *dptr)
-{
-    if (dptr) SFE_HIP(hipFree(dptr));
-    return SFE_OK;
-}
-// median time of the bare read + write mix over the pair (util.hip: pair_probe_kernel), on the null stream
-static int probe_pair_ms(const void *d_in, size_t in_bytes, void *d_out, size_t out_bytes, float *ms)
-{
-    hipEvent_t e0, e1;
-    SFE_HIP(hipEventCreate(&e0));
-    SFE_HIP(hipEventCreate(&e1));
-    int rc = SFE_OK;
-    float v[5] = {0, 0, 0, 0, 0};
-    for (int i = 0; i < 3 && rc == SFE_OK; i++) rc = launch_pair_probe(d_in, in_bytes, d_out, out_bytes, nullptr);
-    for (int i = 0; i < 5 && rc == SFE_OK; i++) {
-        hipError_t e = hipEventRecord(e0, nullptr);
-        if (e == hipSuccess) rc = launch_pair_probe(d_in, in_bytes, d_out, out_bytes, nullptr);
-        if (e == hipSuccess && rc == SFE_OK) e = hipEventRecord(e1, nullptr);
-        if (e == hipSuccess && rc == SFE_OK) e = hipEventSynchronize(e1);
-        if (e == hipSuccess && rc == SFE_OK) e = hipEventElapsedTime(&v[i], e0, e1);
-        if (e != hipSuccess) rc = hip_fail(e, "probe_pair");
-    }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    if (rc != SFE_OK) return rc;
-    for (int i = 1; i < 5; i++)          // insertion sort of five
-        for (int j = i; j > 0 && v[j] < v[j - 1]; j--) {
-            const float t = v[j];
-            v[j] = v[j - 1];
-            v[j - 1] = t;
-        }
-    *ms = v[2];
-    return SFE_OK;
-}
-
-int sfe_dsp_probe_pair(const void *d_in, size_t in_bytes, void *d_out, size_t out_bytes, float *ms)
-{
-    if (!d_in || !d_out || !ms || in_bytes < 32768 || out_bytes < 4096 || (reinterpret_cast<uintptr_t>(d_in) & 7) ||
-        (reinterpret_cast<uintptr_t>(d_out) & 15)) {
-        set_error("probe_pair: needs an input of >= 32 KiB (8-byte aligned) and an output of >= 4 KiB (16-byte aligned)");
-        return SFE_EINVAL;
-    }
-    return probe_pair_ms(d_in, in_bytes, d_out, out_bytes, ms);
-}
-
-int sfe_dsp_malloc_pair(size_t in_bytes, size_t out_bytes, int tries, void **d_in, void **d_out, float *ms_kept, float *ms_worst)
-{
-    if (!d_in || !d_out || tries < 1 || tries > 8) {
-        set_error("malloc_pair: null argument or tries outside 1 .. 8");
-        return SFE_EINVAL;
-    }
-    *d_in = *d_out = nullptr;
-    void *in = nullptr, *cand[16] = {nullptr}, *spacer[4] = {nullptr};
-    float ms[16];
-    SFE_HIP(hipMalloc(&in, in_bytes ? in_bytes : 16));
-    int n = 0, rc = SFE_OK, best = 0, n_spacers = 0;
-    float worst = 0.0f;
-    const bool probe = tries > 1 && in_bytes >= 32768 && out_bytes >= 4096;
-    const size_t SPACER = (size_t)32 << 30;
-    auto spaced = [&]() {                        // the classes run in stretches of tens of GiB: step over one
-        size_t free_b = 0, total_b = 0;
-        if (n_spacers < 4 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > SPACER + 2 * out_bytes + in_bytes) {
-            if (hipMalloc(&spacer[n_spacers], SPACER) == hipSuccess) n_spacers++;
-            else (void)hipGetLastError();
-        }
-    };
-    // every candidate stays allocated until the choice is made: a freed one's pages would come straight back.  Up to `tries`
-    // candidates; twice as many, each pair of the further ones behind a 32 GiB spacer, while they show no spread (within 4 %:
-    // all of one class -- a fresh process tends to be handed what the last one freed)
-    for (; n < (probe ? 2 * tries : 1); n++) {
-        if (n >= tries && ms[best] < 0.96f * worst) break;
-        if (n >= tries && (n - tries) % 2 == 0) spaced();
-        const hipError_t e = hipMalloc(&cand[n], out_bytes ? out_bytes : 16);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            if (n == 0) rc = hip_fail(e, "malloc_pair");
-            break;                                             // out of memory further on: choose among what there is
-        }
-        ms[n] = 0.0f;
-        if (probe) rc = probe_pair_ms(in, in_bytes, cand[n], out_bytes, &ms[n]);
-        if (rc != SFE_OK) {
-            n++;
-            break;
-        }
-        if (ms[n] < ms[best]) best = n;
-        if (ms[n] > worst) worst = ms[n];
-    }
-    // still no spread: the class of a pair is an exclusive-or of its two allocations' -- one more allocation for the INPUT,
-    // from another stretch, kept if the pair is at least 4 % faster
-    if (rc == SFE_OK && probe && n >= 2 && ms[best] >= 0.96f * worst) {
-        spaced();
-        void *alt = nullptr;
-        if (hipMalloc(&alt, in_bytes) == hipSuccess) {
-            float t = 0.0f;
-            if (probe_pair_ms(alt, in_bytes, cand[best], out_bytes, &t) == SFE_OK && t < 0.96f * ms[best]) {
-                (void)hipFree(in);
-                in = alt;
-                ms[best] = t;
-            } else {
-                (void)hipFree(alt);
-            }
-        } else {
-            (void)hipGetLastError();
-        }
-    }
-    for (int i = 0; i < n; i++)
-        if (rc != SFE_OK || i != best) (void)hipFree(cand[i]);
-    for (int i = 0; i < n_spacers; i++) (void)hipFree(spacer[i]);
-    if (rc != SFE_OK) {
-        (void)hipFree(in);
-        return rc;
-    }
-    *d_in = in;
-    *d_out = cand[best];
-    if (ms_kept) *ms_kept = ms[best];
-    if (ms_worst) *ms_worst = worst;
-    return SFE_OK;
-}
-
+// (sfe_dsp_free, sfe_dsp_malloc_pair, sfe_dsp_probe_pair: alloc.hip)
 int sfe_dsp_host_alloc(void **hptr, size_t bytes)
 {
     if (!hptr) return SFE_EINVAL;

@@ -38,6 +38,8 @@ SIGNATURES = {
     "sfe_dsp_free": (i32, [vp]),
     "sfe_dsp_probe_pair": (i32, [vp, sz, vp, sz, C.POINTER(C.c_float)]),
     "sfe_dsp_malloc_pair": (i32, [sz, sz, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "sfe_dsp_malloc_pair_screened": (i32, [sz, sz, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "sfe_dsp_mem_kind": (i32, [vp, C.POINTER(C.c_int)]),
     "sfe_dsp_host_alloc": (i32, [C.POINTER(vp), sz]),
     "sfe_dsp_host_free": (i32, [vp]),
     "sfe_dsp_memcpy_h2d": (i32, [vp, vp, sz, vp]),

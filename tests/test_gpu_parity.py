@@ -1301,3 +1301,35 @@ def test_fir_per_channel_taps_ticket_groups_by_channel(api, L):
         a = one.filter(x[c, : 2 * cut])[0]
         b = one.filter(x[c, 2 * cut:])[0]
         assert np.array_equal(y[c], np.concatenate([a, b])), c
+
+
+def test_malloc_pair_builds_a_pair_from_chunks(L):
+    """Streams of a GiB and more: sfe_dsp_malloc_pair builds the pair from 1 GiB physical chunks mapped into two contiguous
+    ranges (or falls back to screening plain allocations).  Either way the memory is ordinary device memory -- the library's
+    own calls and kernels work on it across chunk boundaries -- and sfe_dsp_free releases it."""
+    import ctypes as C
+    lib = L.load()
+    d_in, d_out, kept, worst = C.c_void_p(), C.c_void_p(), C.c_float(), C.c_float()
+    n_in, n_out = (2 << 30) + 4096, (1 << 30) + (1 << 20)     # not whole chunks
+    assert lib.sfe_dsp_malloc_pair(n_in, n_out, 2, C.byref(d_in), C.byref(d_out), C.byref(kept), C.byref(worst)) == 0
+    assert d_in.value and d_out.value and kept.value > 0.0
+    # a stream call that crosses a chunk boundary of both buffers: synth fill, FIR, read back
+    from simplefe_amd import api, synth
+    n = (n_in // 8) & ~1
+    assert lib.sfe_dsp_synth_fill(d_in, 2 * n, synth.SEED, 0, 0, None) == 0
+    m = min(n, n_out // 8)
+    f = api.Fir(synth.taps_cfg2(), data_complex=True)
+    f.process_stream(d_in.value, d_out.value, m)
+    ref_in, ref_out = api.DeviceArray(2 * m), api.DeviceArray(2 * m)
+    ref_in.fill_synth(synth.SEED)
+    g = api.Fir(synth.taps_cfg2(), data_complex=True)
+    g.process_stream(ref_in, ref_out, m)
+    api.sync()
+    lo = (1 << 30) // 8 - 2048                               # a window across the output's first chunk boundary
+    got = np.empty(8192, np.float32)
+    assert lib.sfe_dsp_memcpy_d2h(got.ctypes.data, C.c_void_p(d_out.value + 8 * lo), got.nbytes, None) == 0
+    api.sync()
+    assert np.array_equal(got, ref_out.to_numpy(8192, offset=2 * lo))
+    kind = C.c_int(-1)
+    assert lib.sfe_dsp_mem_kind(d_out, C.byref(kind)) == 0 and kind.value in (0, 1)          # built, or the screened fallback
+    assert lib.sfe_dsp_free(d_in) == 0 and lib.sfe_dsp_free(d_out) == 0
