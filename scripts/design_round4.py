@@ -71,6 +71,12 @@ def modes_block():
     b2 = [o for o in dfl["other_configs"] if "decimate" in o.get("workload", "")][0].get("buffers", {})
     hb = drv["config"].get("buffers", {})
     pr = lambda v: " / ".join("%.4f" % x for x in v.get("probe_ms", []))
+    def pairs(x, y):
+        if x.get("pair") and y.get("pair"):
+            return ("whose buffers `sfe_dsp_malloc_pair` built: bare mix %.4f and %.4f ms against %.4f and %.4f ms for the same inputs with an output of their own class"
+                    % (x["probe_ms"][0], y["probe_ms"][0], x["same_class_probe_ms"], y["same_class_probe_ms"]))
+        return "whose candidates probed %s and %s ms — %s" % (pr(x), pr(y), spread(x, y))
+
     def spread(*bs):
         both = [min(b.get("probe_ms", [1])) < 0.96 * max(b.get("probe_ms", [1])) for b in bs]
         if all(both):
@@ -80,11 +86,10 @@ def modes_block():
                     "process comes from one stretch\")")
         return "both classes among the candidates of one process, one class only in the other"
     return (f"The three columns come from two `gpurun` calls: the counters and kernel stats from one, the bench lines from the next (they had to wait for "
-            f"the counter summaries to be in the tree to carry `traffic`). Since the end of round 4 every leg's output buffer is SCREENED (§4.2: `bench.py --screen 4`, "
-            f"the fastest of the candidates against the input in a bare read + write mix, outside the timed region): the decimate rows ran in the {mode(prof)} mode in the "
+            f"the counter summaries to be in the tree to carry `traffic`). Since the end of round 4 the legs' buffers are chosen as PAIRS (§4.2, outside the timed region: the legs of 4 GiB and more take theirs from "
+            f"`sfe_dsp_malloc_pair`, the others screen four candidates for the output, `bench.py --screen 4`): the decimate rows ran in the {mode(prof)} mode in the "
             f"profiled process ({prof:.4f} ms, `profiles/r04/decimate_kernel_stats.csv`) and {('in the ' + mode(d1) + ' one in both') if mode(d1) == mode(d2) else ('in the ' + mode(d1) + ' and the ' + mode(d2) + ' one in the two')} line processes "
-            f"({d1:.4f} and {d2:.4f} ms, `profiles/r04/bench_driver_shape.json`, `profiles/r04/bench_default.json`), whose candidates probed {pr(b1)} and {pr(b2)} ms — "
-            f"{spread(b1, b2)}; the headline FIR's candidates probed {pr(hb)} ms (`profiles/r04/bench_driver_shape.json`: `config.buffers`). Before the "
+            f"({d1:.4f} and {d2:.4f} ms, `profiles/r04/bench_driver_shape.json`, `profiles/r04/bench_default.json`), {pairs(b1, b2)}; the headline FIR's candidates probed {pr(hb)} ms (`profiles/r04/bench_driver_shape.json`: `config.buffers`). Before the "
             f"screening the mode was the process's luck: an earlier collection of the round had its profiled process slow at 1.58 ms and its own lines, made minutes later on "
             f"the same box and kept under `earlier/` (without `traffic`), at {e1:.4f} and {e2:.4f} ms (`profiles/r04/earlier/c1_bench_driver_shape.json`, "
             f"`profiles/r04/earlier/c1_bench_default.json`), and the collection before this one, unscreened, read `frac` 0.67 for the headline "
