@@ -305,12 +305,12 @@ class _DevMem:
 def built_pair(ctx, leg, n_in_f32, numel_out, dtype_out):
     """The leg's input and output as a pair BUILT by the library (sfe_dsp_malloc_pair: 1 GiB physical chunks classified with
     the bare mix, the input mapped from one class and the output from another) -- for the legs whose input is
-    4 GiB and more, where what a plain pair gives is a lottery worth 8 % (decimate) to 18 % (8 GiB : 8 GiB in the bare mix).
+    2 GiB and more, where what a plain pair gives is a lottery worth 8 % (decimate) to 18 % (8 GiB : 8 GiB in the bare mix).
     Returns (x, y) float32 / dtype_out tensors over that memory, or None (--screen 1, or the library fell back and could
     not do better than plain allocations: the caller then screens plain tensors).  Outside the timed region; reported."""
     import ctypes as C
     torch, L, dev = ctx["torch"], ctx["L"], ctx["dev"]
-    if int(ctx.get("screen", 1)) <= 1 or 4 * n_in_f32 < (4 << 30):
+    if int(ctx.get("screen", 1)) <= 1 or 4 * n_in_f32 < (2 << 30):
         return None
     esz = torch.empty(0, dtype=dtype_out).element_size()
     a, b, kept, worst = C.c_void_p(), C.c_void_p(), C.c_float(), C.c_float()
