@@ -1085,8 +1085,12 @@ def main():
     if getattr(head, "variant", None):
         out["roofline"]["variant"] = head.variant     # which data-movement variant this device's measurement picked
     if getattr(head, "buffers", None):
-        out["config"]["buffers"] = dict(head.buffers, note="output buffer: the fastest of the candidates against the input in a bare read + "
-                                        "write mix (sfe_dsp_probe_pair, outside the timed region; DESIGN.md 4.2); --screen 1 disables")
+        lib = head.buffers.get("pair") == "sfe_dsp_malloc_pair"
+        out["config"]["buffers"] = dict(head.buffers, note=(
+            "input and output from sfe_dsp_malloc_pair (built from physical chunks of different classes); of up to three such pairs the "
+            "one this leg's own launch ran fastest on is kept, all outside the timed region (DESIGN.md 4.2); --screen 1 disables" if lib else
+            "output buffer: the fastest of the candidates against the input in a bare read + write mix (sfe_dsp_probe_pair, outside the "
+            "timed region; DESIGN.md 4.2); --screen 1 disables"))
     if traffic_stale:
         out["roofline"]["traffic_stale"] = True      # simplefe_amd/csrc changed since the PMC pass in profiles/
     if world > 1:

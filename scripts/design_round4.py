@@ -77,6 +77,14 @@ def modes_block():
                     % (x["probe_ms"][0], y["probe_ms"][0], x["same_class_probe_ms"], y["same_class_probe_ms"]))
         return "whose candidates probed %s and %s ms — %s" % (pr(x), pr(y), spread(x, y))
 
+    def head_sentence(h):
+        own = h.get("pairs_timed_with_the_legs_own_kernel_ms")
+        if own:
+            return ("the headline FIR timed its own launch on %d pairs from the library, %s ms, and kept the fastest — all in the FIR's %s mode "
+                    "(§4.2: a property of the process that no choice among the pairs a process can get has moved)"
+                    % (len(own), " / ".join("%.4f" % v for v in own), "slow" if min(own) > 0.75 else "fast"))
+        return "the headline FIR's candidates probed %s ms" % pr(h)
+
     def spread(*bs):
         both = [min(b.get("probe_ms", [1])) < 0.96 * max(b.get("probe_ms", [1])) for b in bs]
         if all(both):
@@ -89,7 +97,7 @@ def modes_block():
             f"the counter summaries to be in the tree to carry `traffic`). Since the end of round 4 the legs' buffers are chosen as PAIRS (§4.2, outside the timed region: the legs of 4 GiB and more take theirs from "
             f"`sfe_dsp_malloc_pair`, the others screen four candidates for the output, `bench.py --screen 4`): the decimate rows ran in the {mode(prof)} mode in the "
             f"profiled process ({prof:.4f} ms, `profiles/r04/decimate_kernel_stats.csv`) and {('in the ' + mode(d1) + ' one in both') if mode(d1) == mode(d2) else ('in the ' + mode(d1) + ' and the ' + mode(d2) + ' one in the two')} line processes "
-            f"({d1:.4f} and {d2:.4f} ms, `profiles/r04/bench_driver_shape.json`, `profiles/r04/bench_default.json`), {pairs(b1, b2)}; the headline FIR's candidates probed {pr(hb)} ms (`profiles/r04/bench_driver_shape.json`: `config.buffers`). Before the "
+            f"({d1:.4f} and {d2:.4f} ms, `profiles/r04/bench_driver_shape.json`, `profiles/r04/bench_default.json`), {pairs(b1, b2)}; {head_sentence(hb)} (`profiles/r04/bench_driver_shape.json`: `config.buffers`). Before the "
             f"screening the mode was the process's luck: an earlier collection of the round had its profiled process slow at 1.58 ms and its own lines, made minutes later on "
             f"the same box and kept under `earlier/` (without `traffic`), at {e1:.4f} and {e2:.4f} ms (`profiles/r04/earlier/c1_bench_driver_shape.json`, "
             f"`profiles/r04/earlier/c1_bench_default.json`), and the collection before this one, unscreened, read `frac` 0.67 for the headline "
