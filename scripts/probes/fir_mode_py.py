@@ -1,0 +1,72 @@
+"""The FIR's two modes from a Python process WITHOUT torch: the library through ctypes only, bench.py's order
+of events (the pair from sfe_dsp_malloc_pair first, the object after).  One line per process."""
+import ctypes as C
+import math
+import os
+import sys
+
+if "torch" in sys.argv:                          # torch first, as bench.py has it: its bundled HIP runtime is then the process's
+    import torch
+    torch.cuda.init()
+    torch.zeros(16, device="cuda:0")
+here = os.path.dirname(os.path.abspath(__file__))
+L = C.CDLL(os.path.join(here, "..", "..", "simplefe_amd", "libsfe_dsp.so"))
+L.sfe_dsp_last_error.restype = C.c_char_p
+
+
+def ck(rc):
+    if rc != 0:
+        raise RuntimeError(L.sfe_dsp_last_error().decode())
+
+
+n = 1 << 28
+din, dout = C.c_void_p(), C.c_void_p()
+kept, worst = C.c_float(), C.c_float()
+ck(L.sfe_dsp_malloc_pair(C.c_size_t(n * 8), C.c_size_t(n * 8), 4, C.byref(din), C.byref(dout), C.byref(kept), C.byref(worst)))
+ck(L.sfe_dsp_synth_fill(din, C.c_uint64(2 * n), C.c_uint32(20240601), C.c_uint32(0), C.c_uint64(0), None))
+taps = (C.c_float * 256)()
+for i in range(256):
+    x = 0.2 * (i - 127.5)
+    taps[i] = math.sin(math.pi * x) / (math.pi * x) * (0.54 - 0.46 * math.cos(2 * math.pi * i / 255.0)) * 0.2
+f = C.c_void_p()
+ck(L.sfe_dsp_fir_create(taps, 256, 0, 1, 1, 0, 0, C.byref(f)))
+tm = C.c_void_p()
+ck(L.sfe_dsp_timer_create(C.byref(tm)))
+if "calibrate" in sys.argv:
+    ck(L.sfe_dsp_fir_calibrate(f, din, dout, C.c_size_t(n), C.c_size_t(n), C.c_size_t(n), None, None))
+for _ in range(40):
+    ck(L.sfe_dsp_fir_process_stream(f, din, dout, C.c_size_t(n), C.c_size_t(n), C.c_size_t(n), None))
+out = []
+for r in range(3):
+    ck(L.sfe_dsp_timer_start(tm, None))
+    for _ in range(50):
+        ck(L.sfe_dsp_fir_process_stream(f, din, dout, C.c_size_t(n), C.c_size_t(n), C.c_size_t(n), None))
+    ck(L.sfe_dsp_timer_stop(tm, None))
+    ms = C.c_float()
+    ck(L.sfe_dsp_timer_elapsed_ms(tm, C.byref(ms)))
+    out.append(ms.value / 50)
+if "two" in sys.argv:
+    # does the mode follow the OBJECT (its spectrum, twiddle tables and ticket counters: small allocations made after the pool
+    # went back) or the PAIR?  a second object, made now; a second pair, built now; all four combinations
+    def run(obj, a, b):
+        for _ in range(10):
+            ck(L.sfe_dsp_fir_process_stream(obj, a, b, C.c_size_t(n), C.c_size_t(n), C.c_size_t(n), None))
+        ck(L.sfe_dsp_timer_start(tm, None))
+        for _ in range(50):
+            ck(L.sfe_dsp_fir_process_stream(obj, a, b, C.c_size_t(n), C.c_size_t(n), C.c_size_t(n), None))
+        ck(L.sfe_dsp_timer_stop(tm, None))
+        ms = C.c_float()
+        ck(L.sfe_dsp_timer_elapsed_ms(tm, C.byref(ms)))
+        return ms.value / 50
+    f2 = C.c_void_p()
+    ck(L.sfe_dsp_fir_create(taps, 256, 0, 1, 1, 0, 0, C.byref(f2)))
+    din2, dout2 = C.c_void_p(), C.c_void_p()
+    ck(L.sfe_dsp_malloc_pair(C.c_size_t(n * 8), C.c_size_t(n * 8), 4, C.byref(din2), C.byref(dout2), None, None))
+    ck(L.sfe_dsp_synth_fill(din2, C.c_uint64(2 * n), C.c_uint32(20240601), C.c_uint32(0), C.c_uint64(0), None))
+    f3 = C.c_void_p()
+    ck(L.sfe_dsp_fir_create(taps, 256, 0, 1, 1, 0, 0, C.byref(f3)))
+    print("  object 1 / 2 / 3 on pair 1: %.4f %.4f %.4f   on pair 2: %.4f %.4f %.4f   crossed (in 1 -> out 2, in 2 -> out 1), object 1: %.4f %.4f" % (
+        run(f, din, dout), run(f2, din, dout), run(f3, din, dout), run(f, din2, dout2), run(f2, din2, dout2), run(f3, din2, dout2),
+        run(f, din, dout2), run(f, din2, dout)))
+print("python %s: FIR %.4f %.4f %.4f ms   bare mix %.4f (own class %.4f)" % (
+    " + ".join(sys.argv[1:]) or "(ctypes only)", out[0], out[1], out[2], kept.value, worst.value))
