@@ -27,6 +27,135 @@ int main(int argc, char **argv)
     const size_t CHUNK = (size_t)1 << 30;
     const int P = argc > 1 ? atoi(argv[1]) : 24;
     const bool singles = argc > 2 && argv[2][0] == 's';
+    if (argc > 2 && (argv[2][0] == 'y' || argv[2][0] == 'z')) {
+        // the library's order of events by hand: all chunks created first, mapped as one range, ~1000 bare-mix launches over
+        // it, unmapped; then buffers put together from RANDOM chunks (no classification).  y: 40 trials, the pool kept;
+        // z: one trial, the rest of the pool released first (what sfe_dsp_malloc_pair does).  The object is made after the
+        // first buffers exist.
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = 0;
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        CK(hipSetDevice(0));
+        CK(hipFree(nullptr));                    // the runtime up before the first virtual-memory call
+        size_t gran = 0;
+        CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+        std::vector<hipMemGenericAllocationHandle_t> h(P);
+        for (int i = 0; i < P; i++) CK(hipMemCreate(&h[i], CHUNK, &prop, 0));
+        void *all = nullptr;
+        CK(hipMemAddressReserve(&all, P * CHUNK, CHUNK, nullptr, 0));
+        for (int i = 0; i < P; i++) CK(hipMemMap((char *)all + i * CHUNK, CHUNK, 0, h[i], 0));
+        CK(hipMemSetAccess(all, P * CHUNK, &acc, 1));
+        float dummy = 0;
+        for (int i = 0; i < 130; i++) SK(sfe_dsp_probe_pair(all, CHUNK, (char *)all + (1 + i % (P - 1)) * CHUNK, CHUNK, &dummy));
+        CK(hipDeviceSynchronize());
+        CK(hipMemUnmap(all, P * CHUNK));
+        CK(hipMemAddressFree(all, P * CHUNK));
+        unsigned rng = argc > 3 ? (unsigned)atoi(argv[3]) : 12345u;
+        auto next = [&]() { rng = rng * 1664525u + 1013904223u; return (int)((rng >> 8) % (unsigned)P); };
+        const size_t n = (size_t)1 << 28;
+        sfe_fir_t f = nullptr;
+        sfe_timer_t tm;
+        SK(sfe_dsp_timer_create(&tm));
+        std::vector<float> taps(256);
+        for (int i = 0; i < 256; i++) {
+            const double k = i - 127.5, x = 0.2 * k;
+            taps[i] = (float)((fabs(x) < 1e-9 ? 1.0 : sin(M_PI * x) / (M_PI * x)) * (0.54 - 0.46 * cos(2 * M_PI * i / 255.0)) * 0.2);
+        }
+        const int trials = argv[2][0] == 'y' ? 40 : 1;
+        for (int trial = 0; trial < trials; trial++) {
+            int c[4];
+            for (int i = 0; i < 4; i++) {
+                bool again;
+                do {
+                    c[i] = next();
+                    again = false;
+                    for (int j = 0; j < i; j++) again |= c[j] == c[i];
+                } while (again);
+            }
+            if (argv[2][0] == 'z')
+                for (int i = 0; i < P; i++)
+                    if (i != c[0] && i != c[1] && i != c[2] && i != c[3]) CK(hipMemRelease(h[i]));
+            void *bi = nullptr, *bo = nullptr;
+            CK(hipMemAddressReserve(&bi, 2 * CHUNK, CHUNK, nullptr, 0));
+            CK(hipMemAddressReserve(&bo, 2 * CHUNK, CHUNK, nullptr, 0));
+            CK(hipMemMap(bi, CHUNK, 0, h[c[0]], 0));
+            CK(hipMemMap((char *)bi + CHUNK, CHUNK, 0, h[c[1]], 0));
+            CK(hipMemMap(bo, CHUNK, 0, h[c[2]], 0));
+            CK(hipMemMap((char *)bo + CHUNK, CHUNK, 0, h[c[3]], 0));
+            CK(hipMemSetAccess(bi, 2 * CHUNK, &acc, 1));
+            CK(hipMemSetAccess(bo, 2 * CHUNK, &acc, 1));
+            SK(sfe_dsp_synth_fill(bi, 2 * n, 20240601u, 0, 0, nullptr));
+            if (!f) SK(sfe_dsp_fir_create(taps.data(), 256, 0, 1, 1, 0, 0, &f));
+            for (int k = 0; k < (trial ? 10 : 40); k++) SK(sfe_dsp_fir_process_stream(f, bi, bo, n, n, n, nullptr));
+            SK(sfe_dsp_timer_start(tm, nullptr));
+            for (int k = 0; k < 20; k++) SK(sfe_dsp_fir_process_stream(f, bi, bo, n, n, n, nullptr));
+            SK(sfe_dsp_timer_stop(tm, nullptr));
+            float ms = 0, mix = 0;
+            SK(sfe_dsp_timer_elapsed_ms(tm, &ms));
+            SK(sfe_dsp_probe_pair(bi, 2 * CHUNK, bo, 2 * CHUNK, &mix));
+            printf("%c: in (%2d,%2d) out (%2d,%2d)  FIR %.4f ms  bare mix %.4f\n", argv[2][0], c[0], c[1], c[2], c[3], ms / 20, mix);
+            fflush(stdout);
+            CK(hipDeviceSynchronize());
+            CK(hipMemUnmap(bi, 2 * CHUNK));
+            CK(hipMemUnmap(bo, 2 * CHUNK));
+            CK(hipMemAddressFree(bi, 2 * CHUNK));
+            CK(hipMemAddressFree(bo, 2 * CHUNK));
+        }
+        return 0;
+    }
+    if (argc > 2 && argv[2][0] == 'c') {
+        // every chunk of a fresh process's pool as the FIR's INPUT, one at a time (2^27 samples = 1 GiB; the output a fixed
+        // distance away): are there chunks the FIR reads faster, and how many?
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = 0;
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        CK(hipSetDevice(0));
+        CK(hipFree(nullptr));
+        std::vector<hipMemGenericAllocationHandle_t> h(P);
+        for (int i = 0; i < P; i++) CK(hipMemCreate(&h[i], CHUNK, &prop, 0));
+        void *all = nullptr;
+        CK(hipMemAddressReserve(&all, P * CHUNK, CHUNK, nullptr, 0));
+        for (int i = 0; i < P; i++) CK(hipMemMap((char *)all + i * CHUNK, CHUNK, 0, h[i], 0));
+        CK(hipMemSetAccess(all, P * CHUNK, &acc, 1));
+        char *va = (char *)all;
+        SK(sfe_dsp_synth_fill(va, P * CHUNK / 4, 20240601u, 0, 0, nullptr));
+        std::vector<float> taps(256);
+        for (int i = 0; i < 256; i++) {
+            const double k = i - 127.5, x = 0.2 * k;
+            taps[i] = (float)((fabs(x) < 1e-9 ? 1.0 : sin(M_PI * x) / (M_PI * x)) * (0.54 - 0.46 * cos(2 * M_PI * i / 255.0)) * 0.2);
+        }
+        sfe_fir_t f;
+        SK(sfe_dsp_fir_create(taps.data(), 256, 0, 1, 1, 0, 0, &f));
+        sfe_timer_t tm;
+        SK(sfe_dsp_timer_create(&tm));
+        const size_t n = (size_t)1 << 27;
+        for (int k = 0; k < 200; k++) SK(sfe_dsp_fir_process_stream(f, va, va + (P / 2) * CHUNK, n, n, n, nullptr));
+        for (int pass = 0; pass < 2; pass++) {
+            printf("pass %d, input chunk 0..%d -> output chunk (i + %d) %% %d, ms:", pass, P - 1, pass ? P / 3 : P / 2, P);
+            for (int i = 0; i < P; i++) {
+                const void *in = va + i * CHUNK;
+                void *out = va + ((i + (pass ? P / 3 : P / 2)) % P) * CHUNK;
+                for (int k = 0; k < 5; k++) SK(sfe_dsp_fir_process_stream(f, in, out, n, n, n, nullptr));
+                SK(sfe_dsp_timer_start(tm, nullptr));
+                for (int k = 0; k < 10; k++) SK(sfe_dsp_fir_process_stream(f, in, out, n, n, n, nullptr));
+                SK(sfe_dsp_timer_stop(tm, nullptr));
+                float ms = 0;
+                SK(sfe_dsp_timer_elapsed_ms(tm, &ms));
+                printf(" %.3f", ms / 10);
+            }
+            printf("\n");
+        }
+        fflush(stdout);
+        return 0;
+    }
     if (argc > 2 && argv[2][0] == 'L') {
         // bench.py's order of events: the library's pair is the FIRST device memory the process asks for, the object comes after
         const size_t n = (size_t)1 << 28;

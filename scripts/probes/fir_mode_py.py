@@ -34,17 +34,34 @@ tm = C.c_void_p()
 ck(L.sfe_dsp_timer_create(C.byref(tm)))
 if "calibrate" in sys.argv:
     ck(L.sfe_dsp_fir_calibrate(f, din, dout, C.c_size_t(n), C.c_size_t(n), C.c_size_t(n), None, None))
-for _ in range(40):
+for _ in range(8 if "pmc" in sys.argv else 40):
     ck(L.sfe_dsp_fir_process_stream(f, din, dout, C.c_size_t(n), C.c_size_t(n), C.c_size_t(n), None))
 out = []
 for r in range(3):
     ck(L.sfe_dsp_timer_start(tm, None))
-    for _ in range(50):
+    for _ in range(4 if "pmc" in sys.argv else 50):
         ck(L.sfe_dsp_fir_process_stream(f, din, dout, C.c_size_t(n), C.c_size_t(n), C.c_size_t(n), None))
     ck(L.sfe_dsp_timer_stop(tm, None))
     ms = C.c_float()
     ck(L.sfe_dsp_timer_elapsed_ms(tm, C.byref(ms)))
-    out.append(ms.value / 50)
+    out.append(ms.value / (4 if "pmc" in sys.argv else 50))
+if "pmc" in sys.argv:
+    # under rocprofv3 --pmc: a second pair, then the LAST 16 launches of the process are 4 x (in1 -> out1), 4 x (in2 -> out2),
+    # 4 x (in1 -> out2), 4 x (in2 -> out1): scripts/probes/fir_mode_pmc.sh reads their counters by position
+    din2, dout2 = C.c_void_p(), C.c_void_p()
+    ck(L.sfe_dsp_malloc_pair(C.c_size_t(n * 8), C.c_size_t(n * 8), 4, C.byref(din2), C.byref(dout2), None, None))
+    ck(L.sfe_dsp_synth_fill(din2, C.c_uint64(2 * n), C.c_uint32(20240601), C.c_uint32(0), C.c_uint64(0), None))
+    res = []
+    for a, b in ((din, dout), (din2, dout2), (din, dout2), (din2, dout)):
+        ck(L.sfe_dsp_timer_start(tm, None))
+        for _ in range(4):
+            ck(L.sfe_dsp_fir_process_stream(f, a, b, C.c_size_t(n), C.c_size_t(n), C.c_size_t(n), None))
+        ck(L.sfe_dsp_timer_stop(tm, None))
+        ms = C.c_float()
+        ck(L.sfe_dsp_timer_elapsed_ms(tm, C.byref(ms)))
+        res.append(ms.value / 4)
+    print("pmc order: in1->out1 %.4f  in2->out2 %.4f  in1->out2 %.4f  in2->out1 %.4f (events around 4 launches, profiler attached)" % tuple(res))
+    sys.exit(0)
 if "two" in sys.argv:
     # does the mode follow the OBJECT (its spectrum, twiddle tables and ticket counters: small allocations made after the pool
     # went back) or the PAIR?  a second object, made now; a second pair, built now; all four combinations

@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <mutex>
@@ -194,6 +196,17 @@ int build_pair(size_t in_bytes, size_t out_bytes, int tries, void **d_in, void *
     for (size_t i = 0; i < n_in; i++) { min.chunks.push_back(h[gin[i]]); used[gin[i]] = 1; }
     for (size_t i = 0; i < n_out; i++) { mout.chunks.push_back(h[gout[i]]); used[gout[i]] = 1; }
     for (size_t i = 0; i < n_out; i++) mcheck.chunks.push_back(h[gin[n_in + i]]);
+#ifdef SFE_DIAG
+    if (getenv("SFE_PAIR_DEBUG")) {              // diagnostics (libsfe_dsp_diag.so only): which chunks of the pool (in creation order) went where
+        fprintf(stderr, "build_pair: pool %zu, spread %.3f, same-class %zu other %zu; in <-", n, best_spread, same.size(), other.size());
+        for (size_t i = 0; i < n_in; i++) fprintf(stderr, " %zu (%.3f)", gin[i], best_t[gin[i]]);
+        fprintf(stderr, "; out <-");
+        for (size_t i = 0; i < n_out; i++) fprintf(stderr, " %zu (%.3f)", gout[i], best_t[gout[i]]);
+        fprintf(stderr, "\n  t:");
+        for (size_t c = 0; c < n; c++) fprintf(stderr, " %.3f", best_t[c]);
+        fprintf(stderr, "\n");
+    }
+#endif
     void *pin = map_chunks(min.chunks, device), *pout = pin ? map_chunks(mout.chunks, device) : nullptr;
     void *pchk = pout ? map_chunks(mcheck.chunks, device) : nullptr;
     float kept = 0.0f, same_class = 0.0f;
