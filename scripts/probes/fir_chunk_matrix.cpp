@@ -107,6 +107,54 @@ int main(int argc, char **argv)
         }
         return 0;
     }
+    if (argc > 2 && argv[2][0] == 'k') {
+        // physically CONTIGUOUS buffers (hipExtMallocWithFlags, hipDeviceMallocContiguous) against plain hipMalloc, as the
+        // FIR's input and output: is the fast mode what a contiguous input gives?
+        CK(hipSetDevice(0));
+        const size_t n = (size_t)1 << 28;
+        void *ci = nullptr, *co = nullptr, *mi = nullptr, *mo = nullptr;
+        const bool contiguous_first = argc > 3 && argv[3][0] == '1';
+        if (contiguous_first) {
+            CK(hipExtMallocWithFlags(&ci, n * 8, hipDeviceMallocContiguous));
+            CK(hipExtMallocWithFlags(&co, n * 8, hipDeviceMallocContiguous));
+        }
+        CK(hipMalloc(&mi, n * 8));
+        CK(hipMalloc(&mo, n * 8));
+        if (!contiguous_first) {
+            CK(hipExtMallocWithFlags(&ci, n * 8, hipDeviceMallocContiguous));
+            CK(hipExtMallocWithFlags(&co, n * 8, hipDeviceMallocContiguous));
+        }
+        SK(sfe_dsp_synth_fill(ci, 2 * n, 20240601u, 0, 0, nullptr));
+        SK(sfe_dsp_synth_fill(mi, 2 * n, 20240601u, 0, 0, nullptr));
+        std::vector<float> taps(256);
+        for (int i = 0; i < 256; i++) {
+            const double k = i - 127.5, x = 0.2 * k;
+            taps[i] = (float)((fabs(x) < 1e-9 ? 1.0 : sin(M_PI * x) / (M_PI * x)) * (0.54 - 0.46 * cos(2 * M_PI * i / 255.0)) * 0.2);
+        }
+        sfe_fir_t f;
+        SK(sfe_dsp_fir_create(taps.data(), 256, 0, 1, 1, 0, 0, &f));
+        sfe_timer_t tm;
+        SK(sfe_dsp_timer_create(&tm));
+        auto run = [&](const void *in, void *out) -> float {
+            for (int k = 0; k < 20; k++) SK(sfe_dsp_fir_process_stream(f, in, out, n, n, n, nullptr));
+            SK(sfe_dsp_timer_start(tm, nullptr));
+            for (int k = 0; k < 40; k++) SK(sfe_dsp_fir_process_stream(f, in, out, n, n, n, nullptr));
+            SK(sfe_dsp_timer_stop(tm, nullptr));
+            float ms = 0;
+            SK(sfe_dsp_timer_elapsed_ms(tm, &ms));
+            return ms / 40;
+        };
+        for (int k = 0; k < 100; k++) SK(sfe_dsp_fir_process_stream(f, mi, mo, n, n, n, nullptr));
+        float a = run(ci, co), b = run(ci, mo), c = run(mi, co), d = run(mi, mo), a2 = run(ci, co), d2 = run(mi, mo);
+        float m1 = 0, m2 = 0, m3 = 0, m4 = 0;
+        SK(sfe_dsp_probe_pair(ci, n * 8, co, n * 8, &m1));
+        SK(sfe_dsp_probe_pair(ci, n * 8, mo, n * 8, &m2));
+        SK(sfe_dsp_probe_pair(mi, n * 8, co, n * 8, &m3));
+        SK(sfe_dsp_probe_pair(mi, n * 8, mo, n * 8, &m4));
+        printf("contiguous %s: FIR  C->C %.4f  C->m %.4f  m->C %.4f  m->m %.4f  (again C->C %.4f  m->m %.4f)   bare mix %.4f %.4f %.4f %.4f   C in %p out %p, m in %p out %p\n",
+               contiguous_first ? "first" : "after the plain ones", a, b, c, d, a2, d2, m1, m2, m3, m4, ci, co, mi, mo);
+        return 0;
+    }
     if (argc > 2 && argv[2][0] == 'c') {
         // every chunk of a fresh process's pool as the FIR's INPUT, one at a time (2^27 samples = 1 GiB; the output a fixed
         // distance away): are there chunks the FIR reads faster, and how many?
