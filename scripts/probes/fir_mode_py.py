@@ -62,6 +62,33 @@ if "pmc" in sys.argv:
         res.append(ms.value / 4)
     print("pmc order: in1->out1 %.4f  in2->out2 %.4f  in1->out2 %.4f  in2->out1 %.4f (events around 4 launches, profiler attached)" % tuple(res))
     sys.exit(0)
+if "pause" in sys.argv:
+    # inside ONE process: the first pair freed, a pause, a second pair; that freed, no pause, a third.  Does the pause that moves
+    # the odds between processes (profiles/r04/fir_modes_input.txt, block 13) do the same after a release inside a process?
+    import time
+
+    def run(a, b):
+        for _ in range(20):
+            ck(L.sfe_dsp_fir_process_stream(f, a, b, C.c_size_t(n), C.c_size_t(n), C.c_size_t(n), None))
+        ck(L.sfe_dsp_timer_start(tm, None))
+        for _ in range(40):
+            ck(L.sfe_dsp_fir_process_stream(f, a, b, C.c_size_t(n), C.c_size_t(n), C.c_size_t(n), None))
+        ck(L.sfe_dsp_timer_stop(tm, None))
+        ms = C.c_float()
+        ck(L.sfe_dsp_timer_elapsed_ms(tm, C.byref(ms)))
+        return ms.value / 40
+    line = "  first pair %.4f" % run(din, dout)
+    pause = float(sys.argv[sys.argv.index("pause") + 1]) if len(sys.argv) > sys.argv.index("pause") + 1 else 5.0
+    for wait in (pause, 0.0, pause, 0.0):
+        ck(L.sfe_dsp_free(din))
+        ck(L.sfe_dsp_free(dout))
+        time.sleep(wait)
+        din, dout = C.c_void_p(), C.c_void_p()
+        ck(L.sfe_dsp_malloc_pair(C.c_size_t(n * 8), C.c_size_t(n * 8), 4, C.byref(din), C.byref(dout), None, None))
+        ck(L.sfe_dsp_synth_fill(din, C.c_uint64(2 * n), C.c_uint32(20240601), C.c_uint32(0), C.c_uint64(0), None))
+        line += " | freed, %.0f s, built again: %.4f" % (wait, run(din, dout))
+    print(line)
+    sys.exit(0)
 if "two" in sys.argv:
     # does the mode follow the OBJECT (its spectrum, twiddle tables and ticket counters: small allocations made after the pool
     # went back) or the PAIR?  a second object, made now; a second pair, built now; all four combinations
