@@ -121,7 +121,7 @@ def collection_block():
         if f.endswith("bench_driver_shape.json"):
             j = json.loads(open(os.path.join(P, "earlier", f)).read().strip().splitlines()[-1])
             earlier.append(f"`{f.split('_')[0]}` {j['value']:,.0f} MS/s / {j['roofline']['frac']:.3f}".replace(",", " "))
-    tail = ("Earlier collections of the round, other boxes of the pool, same product kernels (`profiles/" + tag + "/earlier/`, driver shape, MS/s / `frac`): "
+    tail = ("Other collections of the round, other boxes of the pool, same product kernels (`c6` was made AFTER the one above, on a slower box) (`profiles/" + tag + "/earlier/`, driver shape, MS/s / `frac`): "
             + ", ".join(earlier) + ".") if earlier else ""
     table = ("| kernel | under rocprofv3 (`bench.py --workload … --no-others --no-cpu`) | un-profiled, driver-shape line | un-profiled, default line | PMC traffic |\n"
              "|---|---|---|---|---|\n" + "\n".join(rows))
