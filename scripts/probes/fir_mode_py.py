@@ -20,6 +20,39 @@ def ck(rc):
 
 
 n = 1 << 28
+if "slices" in sys.argv:
+    # the first pair of the process with a 16 GiB input: eight 2 GiB slices of it (two chunks each, all of the input's class) as the
+    # FIR's input, one output.  All eight alike (the pool's or the process's property) or mixed (the chunks')?  (Tried once, eight
+    # processes: the pool did not hold the 18 chunks of one class this needs, the pairs were plain allocations, all slow.)
+    din, dout = C.c_void_p(), C.c_void_p()
+    kept, worst = C.c_float(), C.c_float()
+    ck(L.sfe_dsp_malloc_pair(C.c_size_t(8 * n * 8), C.c_size_t(n * 8), 4, C.byref(din), C.byref(dout), C.byref(kept), C.byref(worst)))
+    kind = C.c_int()
+    ck(L.sfe_dsp_mem_kind(din, C.byref(kind)))
+    ck(L.sfe_dsp_synth_fill(din, C.c_uint64(16 * n), C.c_uint32(20240601), C.c_uint32(0), C.c_uint64(0), None))
+    taps = (C.c_float * 256)()
+    for i in range(256):
+        x = 0.2 * (i - 127.5)
+        taps[i] = math.sin(math.pi * x) / (math.pi * x) * (0.54 - 0.46 * math.cos(2 * math.pi * i / 255.0)) * 0.2
+    f = C.c_void_p()
+    ck(L.sfe_dsp_fir_create(taps, 256, 0, 1, 1, 0, 0, C.byref(f)))
+    tm = C.c_void_p()
+    ck(L.sfe_dsp_timer_create(C.byref(tm)))
+    res = []
+    for rnd in range(2):
+        for k in range(8):
+            a = C.c_void_p(din.value + k * n * 8)
+            for _ in range(40 if (rnd == 0 and k == 0) else 10):
+                ck(L.sfe_dsp_fir_process_stream(f, a, dout, C.c_size_t(n), C.c_size_t(n), C.c_size_t(n), None))
+            ck(L.sfe_dsp_timer_start(tm, None))
+            for _ in range(30):
+                ck(L.sfe_dsp_fir_process_stream(f, a, dout, C.c_size_t(n), C.c_size_t(n), C.c_size_t(n), None))
+            ck(L.sfe_dsp_timer_stop(tm, None))
+            ms = C.c_float()
+            ck(L.sfe_dsp_timer_elapsed_ms(tm, C.byref(ms)))
+            res.append(ms.value / 30)
+    print("slices of a 16 GiB first input (%s): %s | again: %s" % ("built from chunks" if kind.value else "plain allocation", " ".join("%.4f" % v for v in res[:8]), " ".join("%.4f" % v for v in res[8:])))
+    sys.exit(0)
 din, dout = C.c_void_p(), C.c_void_p()
 kept, worst = C.c_float(), C.c_float()
 ck(L.sfe_dsp_malloc_pair(C.c_size_t(n * 8), C.c_size_t(n * 8), 4, C.byref(din), C.byref(dout), C.byref(kept), C.byref(worst)))
