@@ -10,7 +10,9 @@ if "torch" in sys.argv:                          # torch first, as bench.py has 
     torch.cuda.init()
     torch.zeros(16, device="cuda:0")
 here = os.path.dirname(os.path.abspath(__file__))
-L = C.CDLL(os.path.join(here, "..", "..", "simplefe_amd", "libsfe_dsp.so"))
+if "pool" in sys.argv or "pool2" in sys.argv:
+    os.environ["SFE_PAIR_KEEP_POOL"] = "1"       # (read by libsfe_dsp_diag.so's build_pair)
+L = C.CDLL(os.path.join(here, "..", "..", "simplefe_amd", "libsfe_dsp_diag.so" if ("pool" in sys.argv or "pool2" in sys.argv) else "libsfe_dsp.so"))
 L.sfe_dsp_last_error.restype = C.c_char_p
 
 
@@ -20,6 +22,56 @@ def ck(rc):
 
 
 n = 1 << 28
+if "pool2" in sys.argv:
+    # what is done to the input's chunks that is not done to the rest of the pool?  Slots of the kept pool treated one way each
+    # BEFORE the pair's own input is touched: A = the first buffer the FIR ever runs on; B = read by the bare mix first (as the
+    # library's verification reads the input); C = nothing special; then the input itself
+    din, dout = C.c_void_p(), C.c_void_p()
+    kept, worst = C.c_float(), C.c_float()
+    ck(L.sfe_dsp_malloc_pair(C.c_size_t(n * 8), C.c_size_t(n * 8), 4, C.byref(din), C.byref(dout), C.byref(kept), C.byref(worst)))
+    pool, pn = C.c_void_p(), C.c_size_t()
+    ck(L.sfe_dsp_diag_last_pool(C.byref(pool), C.byref(pn)))
+    if not pool.value or pn.value < 40:
+        print("pool2: no pool kept (a pair of plain allocations)")
+        sys.exit(0)
+    GiB = 1 << 30
+    A, B, Cc = (C.c_void_p(pool.value + k * GiB) for k in (10, 20, 30))
+    taps = (C.c_float * 256)()
+    for i in range(256):
+        x = 0.2 * (i - 127.5)
+        taps[i] = math.sin(math.pi * x) / (math.pi * x) * (0.54 - 0.46 * math.cos(2 * math.pi * i / 255.0)) * 0.2
+    f = C.c_void_p()
+    tm = C.c_void_p()
+    ck(L.sfe_dsp_timer_create(C.byref(tm)))
+
+    def fill(a):
+        ck(L.sfe_dsp_synth_fill(a, C.c_uint64(2 * n), C.c_uint32(20240601), C.c_uint32(0), C.c_uint64(0), None))
+
+    def run(a, warm=10, reps=30):
+        for _ in range(warm):
+            ck(L.sfe_dsp_fir_process_stream(f, a, dout, C.c_size_t(n), C.c_size_t(n), C.c_size_t(n), None))
+        ck(L.sfe_dsp_timer_start(tm, None))
+        for _ in range(reps):
+            ck(L.sfe_dsp_fir_process_stream(f, a, dout, C.c_size_t(n), C.c_size_t(n), C.c_size_t(n), None))
+        ck(L.sfe_dsp_timer_stop(tm, None))
+        ms = C.c_float()
+        ck(L.sfe_dsp_timer_elapsed_ms(tm, C.byref(ms)))
+        return ms.value / reps
+    fill(A)
+    ck(L.sfe_dsp_fir_create(taps, 256, 0, 1, 1, 0, 0, C.byref(f)))
+    tA = run(A, 200, 50)
+    mix = C.c_float()
+    for _ in range(2):
+        ck(L.sfe_dsp_probe_pair(B, C.c_size_t(n * 8), dout, C.c_size_t(n * 8), C.byref(mix)))
+    fill(B)
+    tB = run(B)
+    fill(Cc)
+    tC = run(Cc)
+    fill(din)
+    tI = run(din, 40, 50)
+    print("pool2: A (the FIR's first buffer) %.4f  B (read by the bare mix first) %.4f  C (control) %.4f  the pair's input %.4f | again: %.4f %.4f %.4f %.4f" % (
+        tA, tB, tC, tI, run(A), run(B), run(Cc), run(din)))
+    sys.exit(0)
 if "slices" in sys.argv:
     # the first pair of the process with a 16 GiB input: eight 2 GiB slices of it (two chunks each, all of the input's class) as the
     # FIR's input, one output.  All eight alike (the pool's or the process's property) or mixed (the chunks')?  (Tried once, eight
@@ -95,6 +147,36 @@ if "pmc" in sys.argv:
         res.append(ms.value / 4)
     print("pmc order: in1->out1 %.4f  in2->out2 %.4f  in1->out2 %.4f  in2->out1 %.4f (events around 4 launches, profiler attached)" % tuple(res))
     sys.exit(0)
+if "pool" in sys.argv:
+    # the diagnostic library keeps the REST of the classified pool mapped (64 chunks in creation order, without the four the pair
+    # took).  The first pair timed with the pool held; every chunk of the pool as the FIR's input (2^27 samples, output = the
+    # pair's); the input's own two chunks the same way; the pool released; the pair timed again.
+    def run(a, b, cnt, warm=10, reps=20):
+        for _ in range(warm):
+            ck(L.sfe_dsp_fir_process_stream(f, a, b, C.c_size_t(cnt), C.c_size_t(cnt), C.c_size_t(cnt), None))
+        ck(L.sfe_dsp_timer_start(tm, None))
+        for _ in range(reps):
+            ck(L.sfe_dsp_fir_process_stream(f, a, b, C.c_size_t(cnt), C.c_size_t(cnt), C.c_size_t(cnt), None))
+        ck(L.sfe_dsp_timer_stop(tm, None))
+        ms = C.c_float()
+        ck(L.sfe_dsp_timer_elapsed_ms(tm, C.byref(ms)))
+        return ms.value / reps
+    pool, pn = C.c_void_p(), C.c_size_t()
+    ck(L.sfe_dsp_diag_last_pool(C.byref(pool), C.byref(pn)))
+    GiB = 1 << 30
+    held = run(din, dout, n, 10, 40)
+    line = "  pair, pool of %d held: %.4f" % (pn.value, held)
+    half = n // 2
+    line += " | the input's two chunks alone (2^27): %.4f %.4f" % (run(din, dout, half), run(C.c_void_p(din.value + GiB), dout, half))
+    if pool.value and pn.value:
+        ck(L.sfe_dsp_synth_fill(pool, C.c_uint64(pn.value * GiB // 4), C.c_uint32(20240601), C.c_uint32(0), C.c_uint64(0), None))
+        per = [run(C.c_void_p(pool.value + c * GiB), dout, half, 5, 12) for c in range(pn.value)]
+        line += " | pool chunks as input (2^27): " + " ".join("%.3f" % v for v in per)
+        two = [run(C.c_void_p(pool.value + c * GiB), dout, n, 5, 12) for c in range(0, pn.value - 1, 2)]
+        line += " | pool slots of two chunks as input (2^28): " + " ".join("%.3f" % v for v in two)
+        ck(L.sfe_dsp_free(pool))
+        line += " | pool released, the pair again: %.4f" % run(din, dout, n, 10, 40)
+    print(line)
 if "pause" in sys.argv:
     # inside ONE process: the first pair freed, a pause, a second pair; that freed, no pause, a third.  Does the pause that moves
     # the odds between processes (profiles/r04/fir_modes_input.txt, block 13) do the same after a release inside a process?

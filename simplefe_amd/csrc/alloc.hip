@@ -34,6 +34,10 @@ struct Mapped {                                  // one buffer made of chunks: w
 };
 std::mutex g_mu;
 std::unordered_map<void *, Mapped> g_mapped;
+#ifdef SFE_DIAG
+void *g_diag_pool = nullptr;                     // SFE_PAIR_KEEP_POOL=1: the rest of the last classified pool, mapped instead of released
+size_t g_diag_pool_chunks = 0;
+#endif
 
 // median time of the bare read + write mix over the pair (util.hip: pair_probe_kernel), on the null stream
 int probe_pair_ms(const void *d_in, size_t in_bytes, void *d_out, size_t out_bytes, float *ms)
@@ -219,6 +223,21 @@ int build_pair(size_t in_bytes, size_t out_bytes, int tries, void **d_in, void *
     std::vector<hipMemGenericAllocationHandle_t> rest;
     for (size_t c = 0; c < n; c++)
         if (!used[c]) rest.push_back(h[c]);
+#ifdef SFE_DIAG
+    if (ok && getenv("SFE_PAIR_KEEP_POOL") && !rest.empty()) {       // diagnostics: the rest stays, mapped as one range (sfe_dsp_diag_last_pool)
+        void *pp = map_chunks(rest, device);
+        if (pp) {
+            Mapped mp;
+            mp.bytes = rest.size() * CHUNK;
+            mp.chunks = rest;
+            std::lock_guard<std::mutex> lk(g_mu);
+            g_mapped[pp] = mp;
+            g_diag_pool = pp;
+            g_diag_pool_chunks = rest.size();
+            rest.clear();
+        }
+    }
+#endif
     release_chunks(rest);                        // the rest of the pool goes back
     if (!ok) {
         if (pin) unmap_range(pin, n_in);
@@ -363,6 +382,20 @@ int sfe_dsp_malloc_pair_screened(size_t in_bytes, size_t out_bytes, int tries, v
     *d_in = *d_out = nullptr;
     return screen_pair(in_bytes, out_bytes, tries, d_in, d_out, ms_kept, ms_worst);
 }
+
+#ifdef SFE_DIAG
+// diagnostics (libsfe_dsp_diag.so, SFE_PAIR_KEEP_POOL=1): the rest of the pool the last built pair was chosen from, as one
+// mapped range of n_chunks x 1 GiB in creation order (without the chunks the pair took); free it with sfe_dsp_free
+extern "C" int sfe_dsp_diag_last_pool(void **va, size_t *n_chunks)
+{
+    if (!va || !n_chunks) return SFE_EINVAL;
+    *va = g_diag_pool;
+    *n_chunks = g_diag_pool_chunks;
+    g_diag_pool = nullptr;
+    g_diag_pool_chunks = 0;
+    return SFE_OK;
+}
+#endif
 
 int sfe_dsp_mem_kind(const void *dptr, int *kind)
 {
