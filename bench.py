@@ -362,6 +362,24 @@ def screened_input(ctx, leg, src, y):
     return src
 
 
+def verify_input(ctx, leg, windows=24, W=4096):
+    """Is the input the timed launches read still the synthetic stream it was filled with?  (The parity windows feed the
+    oracle what the device holds, so an input that lost its data -- zeros -- would pass them, and a FIR on zeros runs 10 %
+    faster: DESIGN.md 4.2.)  Windows spread over the first and the last region of leg.input_spec = [(offset, n_floats, channel
+    seed)], compared bit for bit with the host generator.  None = nothing to check (derived inputs: u8 legs, shared buffers)."""
+    spec, synth = getattr(leg, "input_spec", None), ctx["synth"]
+    if not spec:
+        return None
+    for off, nf, ch in (spec[0], spec[-1]):
+        for k in range(windows):
+            pos = (nf - W) * k // (windows - 1)
+            pos -= pos % 2
+            got = leg.x[off + pos: off + pos + W].cpu().numpy()
+            if not np.array_equal(got, synth.synth_f32(W, synth.SEED, ch, first=pos)):
+                return False
+    return True
+
+
 def make_fir_leg(ctx, name, taps, n, nch, ch0=0, algo="auto", in_fmt="f32", out_fmt="f32", x_share=None, per_channel=False,
                  y_share=None, calibrate=False):
     """n samples per channel, nch channels on THIS rank, the first of them global channel ch0 (its
@@ -411,6 +429,7 @@ def make_fir_leg(ctx, name, taps, n, nch, ch0=0, algo="auto", in_fmt="f32", out_
         leg.key += "_u8"
         leg.workload += ", u8 (I,Q) wire-format input converted on load"
     leg.x = x
+    leg.input_spec = [(c * 2 * n, 2 * n, leg.seeds[c]) for c in range(nch)] if (in_fmt == "f32" and x_share is None) else None
     if per_channel:
         leg.obj = api.Fir(taps, per_channel=True, device=ctx["local_rank"])
         leg.key += "_pctaps"
@@ -580,6 +599,7 @@ def make_rs_leg(ctx, which, log2n, in_fmt="f32", short_proto=False):
             if x is src:
                 x = leg.x = moved
             src = leg._src = moved
+    leg.input_spec = [(0, 2 * n, 0)] if in_fmt != "u8" else None
     leg.obj = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE if which == "resample" else lib.RS_DECIMATE,
                      data_complex=True, n_channels=1, device=ctx["local_rank"])
     if in_fmt == "u8":
@@ -666,6 +686,7 @@ def make_general_rate_leg(ctx, log2n=28, rate=1.77, interpolate=0):
     leg.x = x
     leg.y = screened_output(ctx, leg, x, out_cap * 2, torch.float32)
     x = leg.x = screened_input(ctx, leg, x, leg.y)
+    leg.input_spec = [(0, 2 * n, 0)]
     leg.obj = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=True, n_channels=1, device=ctx["local_rank"])
     leg.kernel = "poly_rt1_kernel" if interpolate else "poly_gen4096_kernel"
     leg.n_out = 0
@@ -1049,6 +1070,11 @@ def main():
               "ok": bool(worst_all <= (2e-3 if is_tx10 else TOL)), "ranks_checked": world,
               "checked": "last timed step, every rank: " + ("every local channel, first and last window" if world > 1 and head.kind == "fir"
                                                             else "first and last local channel")}
+    held = verify_input(ctx, head)
+    if held is not None:
+        held = bool(shard.max_over_ranks(0.0 if held else 1.0, ctx_red) == 0.0)
+        parity["input_is_the_synthetic_stream"] = held         # (checked after the timed steps: what they read)
+        parity["ok"] = parity["ok"] and held
     if is_tx10:
         parity["note"] = "10-bit output: figure = fraction of packed bytes differing from the oracle's packing (1-LSB code-boundary flips)"
     for leg, row in zip(others, other_rows):
@@ -1056,6 +1082,10 @@ def main():
         if world > 1:
             w, c = shard.max_over_ranks(w, ctx_red), int(shard.sum_over_ranks([c], ctx_red)[0])
         row["parity"] = {"rel_rms_max": w, "windows": c, "window_len": wl_, "tol": TOL, "ok": bool(w <= TOL)}
+        held = verify_input(ctx, leg)
+        if held is not None:
+            row["parity"]["input_is_the_synthetic_stream"] = held
+            row["parity"]["ok"] = row["parity"]["ok"] and held
 
     sharded = world > 1 and head.kind == "fir"
     traffic, traffic_stale = pmc_traffic(head.key)

@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <unistd.h>
+#include <time.h>
 
 #include <algorithm>
 #include <vector>
@@ -105,6 +106,61 @@ int main(int argc, char **argv)
             CK(hipMemAddressFree(bi, 2 * CHUNK));
             CK(hipMemAddressFree(bo, 2 * CHUNK));
         }
+        return 0;
+    }
+    if (argc > 2 && argv[2][0] == 'w') {
+        // WHEN does freshly created memory stop being wiped?  P chunks created and mapped, filled at once with non-zero data
+        // (sfe_dsp_synth_fill), then 16 windows of 4 KiB of every chunk read back every ~20 ms for 4 s: a window that reads all
+        // zero was cleared by the driver AFTER the fill.  One line per chunk whose count of zero windows changes.
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = 0;
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        CK(hipSetDevice(0));
+        CK(hipFree(nullptr));
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
+        const double t0 = now();
+        std::vector<hipMemGenericAllocationHandle_t> h(P);
+        for (int i = 0; i < P; i++) CK(hipMemCreate(&h[i], CHUNK, &prop, 0));
+        const double t_created = now();
+        void *all = nullptr;
+        CK(hipMemAddressReserve(&all, P * CHUNK, CHUNK, nullptr, 0));
+        for (int i = 0; i < P; i++) CK(hipMemMap((char *)all + i * CHUNK, CHUNK, 0, h[i], 0));
+        CK(hipMemSetAccess(all, P * CHUNK, &acc, 1));
+        const double t_mapped = now();
+        SK(sfe_dsp_synth_fill(all, P * CHUNK / 4, 20240601u, 0, 0, nullptr));
+        CK(hipDeviceSynchronize());
+        const double t_filled = now();
+        printf("%d chunks created in %.3f s, mapped %.3f s later, filled (non-zero) %.3f s after that\n", P, t_created - t0, t_mapped - t_created, t_filled - t_mapped);
+        std::vector<int> zeros(P, 0);
+        std::vector<unsigned char> buf(4096);
+        int polls = 0;
+        while (now() - t_filled < 4.0) {
+            for (int i = 0; i < P; i++) {
+                int z = 0;
+                for (int w = 0; w < 16; w++) {
+                    CK(hipMemcpy(buf.data(), (char *)all + i * CHUNK + (size_t)w * (CHUNK / 16) + 8192, 4096, hipMemcpyDeviceToHost));
+                    bool any = false;
+                    for (int b = 0; b < 4096 && !any; b++) any = buf[b] != 0;
+                    z += any ? 0 : 1;
+                }
+                if (z != zeros[i]) {
+                    printf("  %.3f s after the fill: chunk %2d has %2d of 16 windows zero\n", now() - t_filled, i, z);
+                    zeros[i] = z;
+                }
+            }
+            polls++;
+            usleep(5000);
+        }
+        int wiped = 0;
+        for (int i = 0; i < P; i++) wiped += zeros[i] ? 1 : 0;
+        printf("%d polls; %d of %d chunks were wiped after the fill\n", polls, wiped, P);
         return 0;
     }
     if (argc > 2 && argv[2][0] == 'k') {

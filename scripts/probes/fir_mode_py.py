@@ -57,6 +57,25 @@ if "pool2" in sys.argv:
         ms = C.c_float()
         ck(L.sfe_dsp_timer_elapsed_ms(tm, C.byref(ms)))
         return ms.value / reps
+    if "inputfirst" in sys.argv:
+        # the pair's input first (as bench.py has it), then a control slot, then a slot read by the bare mix before it is filled
+        fill(din)
+        ck(L.sfe_dsp_fir_create(taps, 256, 0, 1, 1, 0, 0, C.byref(f)))
+        tI = run(din, 40, 50)
+        fill(A)
+        tA = run(A)
+        mix = C.c_float()
+        for _ in range(2):
+            ck(L.sfe_dsp_probe_pair(B, C.c_size_t(n * 8), dout, C.c_size_t(n * 8), C.byref(mix)))
+        fill(B)
+        tB = run(B)
+        # and a slot whose chunks are first read by the FIR itself before they are filled (zeros or the classification's leavings)
+        tC0 = run(Cc)
+        fill(Cc)
+        tC = run(Cc)
+        print("pool2 inputfirst: the pair's input %.4f  A (control) %.4f  B (read by the bare mix, then filled) %.4f  C (read by the FIR unfilled %.4f, then filled) %.4f | again: %.4f %.4f %.4f %.4f" % (
+            tI, tA, tB, tC0, tC, run(din), run(A), run(B), run(Cc)))
+        sys.exit(0)
     fill(A)
     ck(L.sfe_dsp_fir_create(taps, 256, 0, 1, 1, 0, 0, C.byref(f)))
     tA = run(A, 200, 50)
@@ -147,6 +166,41 @@ if "pmc" in sys.argv:
         res.append(ms.value / 4)
     print("pmc order: in1->out1 %.4f  in2->out2 %.4f  in1->out2 %.4f  in2->out1 %.4f (events around 4 launches, profiler attached)" % tuple(res))
     sys.exit(0)
+if "zeros" in sys.argv:
+    # IS THE FAST INPUT STILL HOLDING ITS DATA?  (The FIR on a buffer of zeros runs at the fast mode's speed: block 19.)  Windows of
+    # the input read back after the timing; then the input filled AGAIN and timed again
+    import time
+    hip = C.CDLL("libamdhip64.so.7")
+
+    def zero_fraction(ptr, nbytes, windows=512, wlen=4096):
+        buf = (C.c_ubyte * wlen)()
+        z = 0
+        for k in range(windows):
+            off = (nbytes - wlen) * k // (windows - 1)
+            off -= off % 8
+            rc = hip.hipMemcpy(buf, C.c_void_p(ptr.value + off), C.c_size_t(wlen), 2)
+            if rc != 0:
+                raise RuntimeError("hipMemcpy %d" % rc)
+            z += 1 if not any(buf) else 0
+        return z / windows
+
+    def run(a, b):
+        for _ in range(10):
+            ck(L.sfe_dsp_fir_process_stream(f, a, b, C.c_size_t(n), C.c_size_t(n), C.c_size_t(n), None))
+        ck(L.sfe_dsp_timer_start(tm, None))
+        for _ in range(40):
+            ck(L.sfe_dsp_fir_process_stream(f, a, b, C.c_size_t(n), C.c_size_t(n), C.c_size_t(n), None))
+        ck(L.sfe_dsp_timer_stop(tm, None))
+        ms = C.c_float()
+        ck(L.sfe_dsp_timer_elapsed_ms(tm, C.byref(ms)))
+        return ms.value / 40
+    t1, z1 = run(din, dout), zero_fraction(din, n * 8)
+    ck(L.sfe_dsp_synth_fill(din, C.c_uint64(2 * n), C.c_uint32(20240601), C.c_uint32(0), C.c_uint64(0), None))
+    t2, z2 = run(din, dout), zero_fraction(din, n * 8)
+    time.sleep(2.0)
+    t3, z3 = run(din, dout), zero_fraction(din, n * 8)
+    print("  as first filled: FIR %.4f ms, %.0f %% of 512 windows of the input read back all zero | filled again: %.4f ms, %.0f %% zero | 2 s later: %.4f ms, %.0f %% zero" % (
+        t1, 100 * z1, t2, 100 * z2, t3, 100 * z3))
 if "pool" in sys.argv:
     # the diagnostic library keeps the REST of the classified pool mapped (64 chunks in creation order, without the four the pair
     # took).  The first pair timed with the pool held; every chunk of the pool as the FIR's input (2^27 samples, output = the

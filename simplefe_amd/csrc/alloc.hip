@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 
 #include <math.h>
+#include <stdint.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -103,6 +105,55 @@ void unmap_range(void *va, size_t n_chunks)
 {
     for (size_t i = 0; i < n_chunks; i++) (void)hipMemUnmap(static_cast<char *>(va) + i * CHUNK, CHUNK);
     (void)hipMemAddressFree(va, n_chunks * CHUNK);
+}
+
+// A freshly mapped range must HOLD what is written to it before it is handed out.  Measured (profiles/r04/fir_modes_input.txt,
+// blocks 19-21): a kernel launched right after hipMemMap + hipMemSetAccess of chunks into a range that was reserved, mapped,
+// unmapped and reserved again moments before can find 50-85 % of the range not backed yet -- its stores are dropped and loads
+// return zero (the sparse-range behaviour of a reservation), without a fault; a little later the same addresses hold data.  A
+// caller that fills its input straight after sfe_dsp_malloc_pair would lose most of it.  So: a non-zero word is written to the
+// whole range and every word of it is read back by a kernel, until two passes 5 ms apart find all of it held.
+// (the one kernel of this file: host code's own check, not a product kernel)
+__global__ __launch_bounds__(256) void count_not_held_kernel(const uint4 *p, size_t n16, uint32_t mark, unsigned *bad)
+{
+    unsigned mine = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        const uint4 v = p[i];
+        mine += (v.x != mark) | (v.y != mark) | (v.z != mark) | (v.w != mark);
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+
+int settle_mapping(void *va, size_t bytes)
+{
+    const uint32_t mark = 0x3f800000u;           // 1.0f
+    unsigned *d_bad = nullptr, bad = 1;
+    SFE_HIP(hipMalloc(&d_bad, sizeof(unsigned)));
+    int rc = SFE_ESTATE, clean = 0;
+    for (int attempt = 0; attempt < 400 && clean < 2; attempt++) {          // up to ~2 s; two clean passes 5 ms apart
+        hipError_t e = clean ? hipSuccess : hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(va), (int)mark, bytes / 4);
+        if (e == hipSuccess) e = hipMemset(d_bad, 0, sizeof(unsigned));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(count_not_held_kernel, dim3(4096), dim3(256), 0, nullptr, static_cast<const uint4 *>(va), bytes / 16, mark, d_bad);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof(unsigned), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            (void)hipFree(d_bad);
+            return hip_fail(e, "malloc_pair (settling a mapping)");
+        }
+        clean = bad == 0 ? clean + 1 : 0;
+        if (clean < 2) usleep(5000);
+    }
+    (void)hipFree(d_bad);
+    if (clean >= 2) {
+        SFE_HIP(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(va), 0, bytes / 4));       // handed out zeroed, as fresh memory is
+        SFE_HIP(hipDeviceSynchronize());
+        rc = SFE_OK;
+    } else {
+        set_error("malloc_pair: a mapped range of %zu bytes did not come to hold what was written to it", bytes);
+    }
+    return rc;
 }
 
 // The built pair.  SFE_ESTATE: not possible here (no virtual-memory support, too little memory, one class only) -- the caller
@@ -215,6 +266,7 @@ int build_pair(size_t in_bytes, size_t out_bytes, int tries, void **d_in, void *
     void *pchk = pout ? map_chunks(mcheck.chunks, device) : nullptr;
     float kept = 0.0f, same_class = 0.0f;
     bool ok = pin && pout && pchk;
+    ok = ok && settle_mapping(pin, n_in * CHUNK) == SFE_OK && settle_mapping(pout, n_out * CHUNK) == SFE_OK;
     if (ok && in_bytes >= 32768 && out_bytes >= 4096) {
         ok = probe_pair_ms(pin, in_bytes, pout, out_bytes, &kept) == SFE_OK && probe_pair_ms(pin, in_bytes, pchk, out_bytes, &same_class) == SFE_OK;
         ok = ok && kept < 0.97f * same_class;    // the built pair must beat a pair of one class, or the classes were misread

@@ -1303,6 +1303,28 @@ def test_fir_per_channel_taps_ticket_groups_by_channel(api, L):
         assert np.array_equal(y[c], np.concatenate([a, b])), c
 
 
+def test_malloc_pair_holds_what_is_written_at_once(L):
+    """Round 4's find (profiles/r04/fir_modes_input.txt, blocks 19-21): a kernel launched straight after chunks are mapped into a
+    range reserved moments after a larger one was given back could find most of the range not backed yet -- stores dropped,
+    loads zero, no fault; the library now waits until the mapping holds a mark before it hands the buffers out.  Twice in one
+    process (the second build re-uses the addresses the first gave back): fill the input AT ONCE, then read 64 windows back."""
+    import ctypes as C
+    from simplefe_amd import synth
+    lib = L.load()
+    n = 1 << 28
+    for _ in range(2):
+        d_in, d_out = C.c_void_p(), C.c_void_p()
+        assert lib.sfe_dsp_malloc_pair(n * 8, n * 8, 4, C.byref(d_in), C.byref(d_out), None, None) == 0
+        assert lib.sfe_dsp_synth_fill(d_in, 2 * n, synth.SEED, 0, 0, None) == 0
+        got = np.empty(4096, np.float32)
+        for k in range(64):
+            pos = ((2 * n - 4096) * k // 63) & ~1
+            assert lib.sfe_dsp_memcpy_d2h(got.ctypes.data, C.c_void_p(d_in.value + 4 * pos), got.nbytes, None) == 0
+            assert lib.sfe_dsp_sync(None) == 0
+            assert np.array_equal(got, synth.synth_f32(4096, synth.SEED, 0, first=pos)), "window %d of the input lost its data" % k
+        assert lib.sfe_dsp_free(d_in) == 0 and lib.sfe_dsp_free(d_out) == 0
+
+
 def test_malloc_pair_builds_a_pair_from_chunks(L):
     """Streams of a GiB and more: sfe_dsp_malloc_pair builds the pair from 1 GiB physical chunks mapped into two contiguous
     ranges (or falls back to screening plain allocations).  Either way the memory is ordinary device memory -- the library's
