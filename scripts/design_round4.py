@@ -80,9 +80,10 @@ def modes_block():
     def head_sentence(h):
         own = h.get("pairs_timed_with_the_legs_own_kernel_ms")
         if own:
-            return ("the headline FIR timed its own launch on %d pairs from the library, %s ms, and kept the fastest — all in the FIR's %s mode "
-                    "(§4.2: a property of the process that no choice among the pairs a process can get has moved)"
-                    % (len(own), " / ".join("%.4f" % v for v in own), "slow" if min(own) > 0.75 else "fast"))
+            return ("the headline FIR timed its own launch on %d pairs from the library, %s ms, and kept the fastest (on data the FIR has ONE "
+                    "mode, 0.77–0.80 ms: the faster one of earlier files was the FIR reading an input that had lost its data, §4.2; these lines predate "
+                    "`bench.py`'s check of its inputs, `profiles/r04/bench_after_fix_driver_shape.json` carries it and reads the same)"
+                    % (len(own), " / ".join("%.4f" % v for v in own)))
         return "the headline FIR's candidates probed %s ms" % pr(h)
 
     def spread(*bs):
