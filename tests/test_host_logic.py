@@ -394,3 +394,29 @@ def test_work_counter_arithmetic_covers_every_transform_once_and_returns_to_zero
         run(rng.randint(grid + 1, 2000), tg, rng.choice([0, 1, 3, 5]), grid)
     for total in range(9, 200):
         run(total, 8, 3, 8)
+
+
+def test_bench_notices_an_input_that_lost_its_data():
+    """bench.py's parity windows feed the oracle what the device holds, so an input that became zeros would pass them (and the
+    FIR runs 10 % faster on it: round 4).  verify_input compares windows of the input with the host generator
+    bit for bit; here on CPU tensors: the intact stream passes, a stream with one zeroed stretch fails, derived inputs are
+    skipped."""
+    import importlib.util
+    import torch
+    from simplefe_amd import synth
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n = 1 << 16
+
+    class Leg:
+        pass
+    leg = Leg()
+    leg.x = torch.from_numpy(np.concatenate([synth.synth_f32(2 * n, synth.SEED, 3), synth.synth_f32(2 * n, synth.SEED, 4)]))
+    leg.input_spec = [(0, 2 * n, 3), (2 * n, 2 * n, 4)]
+    ctx = {"synth": synth}
+    assert bench.verify_input(ctx, leg) is True
+    leg.x[2 * n + 2 * n - 4096:] = 0.0                     # the last window of the last region
+    assert bench.verify_input(ctx, leg) is False
+    leg.input_spec = None
+    assert bench.verify_input(ctx, leg) is None
