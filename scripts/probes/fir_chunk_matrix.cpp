@@ -7,6 +7,14 @@
 // and the bare 1 : 1 mix over the same two slots (sfe_dsp_probe_pair).  Then the same by single chunks with 2^27 samples.
 // If the FIR's mode is a property of the pair like the mix's, its matrix has the mix's block structure; if it belongs to the
 // input or the output alone, rows or columns; if to neither, it is not the memory.
+// Modes (argv: P = chunks in the pool, then a letter; profiles/r04/fir_modes_input.txt says which block each made):
+//   (none) / s  the matrix over slots of two chunks / and over single chunks      o  24 objects on two fixed pairs of slots
+//   t  rests of 0-8 s, then launches in groups of 25                               l  three library pairs in a process that already holds memory
+//   L  bench.py's order: the library's pair first, the object after               x  buffers from chunks that are not neighbours
+//   y / z  the library's order of events by hand with random chunks (pool kept / released)
+//   c  every chunk of a fresh pool as the input, one at a time                    k  physically contiguous allocations against plain ones
+//   w  WHEN is fresh memory wiped after a fill: never (the zeros were a mapping not backed yet, not a late clear)
+// Outcome: the "fast mode" these were written to find was the FIR reading zeros (blocks 19-22); kept as the record of the search.
 //   build: hipcc -O2 scripts/probes/fir_chunk_matrix.cpp -o scripts/probes/fir_chunk_matrix -Iinclude -Lsimplefe_amd -lsfe_dsp -Wl,-rpath,$PWD/simplefe_amd
 #include <hip/hip_runtime.h>
 #include <math.h>

@@ -1,5 +1,8 @@
-"""The FIR's two modes from a Python process WITHOUT torch: the library through ctypes only, bench.py's order
-of events (the pair from sfe_dsp_malloc_pair first, the object after).  One line per process."""
+"""The FIR's "fast mode"  from a Python process WITHOUT torch: the library through ctypes only, bench.py's order
+of events (the pair from sfe_dsp_malloc_pair first, the object after).  One line per process.  Words on the command line pick
+the experiment (profiles/r04/fir_modes_input.txt says which block each made): torch, calibrate, two (object or pair, input or
+output), pause, slices, pool / pool2 [inputfirst] (the diagnostic library keeps the classified pool), pmc, and zeros -- the one
+that settled it: windows of the input read back after the timing (the fast inputs had lost 50-84 % of their data)."""
 import ctypes as C
 import math
 import os
