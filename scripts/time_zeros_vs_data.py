@@ -49,6 +49,17 @@ x, y = api.DeviceArray(2 * n), api.DeviceArray(2 * n)
 f = api.Fir(synth.taps_cfg2(), data_complex=True)
 a = three(x, lambda: f.process_stream(x, y, n))
 print("256-tap FIR (fir_fft4096_kernel), 2^28 cf32:            %.4f | %.4f | %.4f   (%.3f)" % (a[0], a[1], a[2], a[1] / (0.5 * (a[0] + a[2]))), flush=True)
+# what gr-simplefe's source hands on: 8-bit samples as floats, (b - 128) / 127 (source_c_impl.cc:134-153) -- 256 distinct values
+import ctypes as C
+blk = 1 << 24
+q = (np.round(synth.synth_f32(2 * blk, synth.SEED, 0) * 127.0) / 127.0).astype(np.float32)
+for k in range(n // blk):
+    api.check(lib.load().sfe_dsp_memcpy_h2d(C.c_void_p(x.ptr + 8 * blk * k), q.ctypes.data, q.nbytes, None))
+api.sync()
+t8 = timed(lambda: f.process_stream(x, y, n))
+x.fill_synth(synth.SEED)
+api.sync()
+print("   the same FIR on 8-bit samples as floats ((b - 128) / 127, a 2^24-sample block repeated): %.4f ms, on the synthetic stream right after: %.4f" % (t8, timed(lambda: f.process_stream(x, y, n))), flush=True)
 r = api.Rs(synth.taps_cfg3(), 3, 4096, mode=lib.RS_RESAMPLE, data_complex=True)
 cap = n * 3 // 5 + 64
 a = three(x, lambda: r.process_stream(x, n, y, cap, 5.0 / 3.0))
