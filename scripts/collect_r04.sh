@@ -16,4 +16,5 @@ LOG2N=28 timeout -k 10 300 python3 scripts/time_general_rate.py > $O/general_rat
 timeout -k 10 200 python3 scripts/time_real_general.py > $O/general_rate_real.txt 2>&1
 timeout -k 10 200 python3 scripts/time_block_api.py > $O/block_api_latency.txt 2>&1
 timeout -k 10 200 python3 scripts/time_pipe.py > $O/host_pipe.txt 2>&1
+timeout -k 10 200 python3 scripts/time_zeros_vs_data.py > $O/zeros_vs_data.txt 2>&1
 echo collected
