@@ -266,7 +266,8 @@ int build_pair(size_t in_bytes, size_t out_bytes, int tries, void **d_in, void *
     void *pchk = pout ? map_chunks(mcheck.chunks, device) : nullptr;
     float kept = 0.0f, same_class = 0.0f;
     bool ok = pin && pout && pchk;
-    ok = ok && settle_mapping(pin, n_in * CHUNK) == SFE_OK && settle_mapping(pout, n_out * CHUNK) == SFE_OK;
+    ok = ok && settle_mapping(pin, n_in * CHUNK) == SFE_OK && settle_mapping(pout, n_out * CHUNK) == SFE_OK &&
+         settle_mapping(pchk, n_out * CHUNK) == SFE_OK;       // (the check range too: a probe over a range not backed yet reads fast)
     if (ok && in_bytes >= 32768 && out_bytes >= 4096) {
         ok = probe_pair_ms(pin, in_bytes, pout, out_bytes, &kept) == SFE_OK && probe_pair_ms(pin, in_bytes, pchk, out_bytes, &same_class) == SFE_OK;
         ok = ok && kept < 0.97f * same_class;    // the built pair must beat a pair of one class, or the classes were misread
