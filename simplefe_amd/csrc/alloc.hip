@@ -1,5 +1,6 @@
 // alloc.hip -- sfe_dsp_malloc_pair / sfe_dsp_probe_pair / sfe_dsp_free: a PAIR of device buffers for a stream call that reads one
-// while it writes the other.  Host code only.
+// while it writes the other.  Host code, and one small kernel of its own (count_not_held_kernel: the check that a new mapping
+// holds what is written to it); no product kernel lives here, which is why scripts/ leave this file out of the kernel hash.
 //
 // What such a pair gives is fixed when the memory is handed out ("the two modes"): physical memory comes in
 // classes, in stretches of tens of GiB; a read stream and a write stream from the same class run ~8 % slower together (8 : 1
