@@ -10,10 +10,25 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from simplefe_amd import api, synth  # noqa: E402
 
-n = 1 << 28
-x, y = api.DeviceArray(2 * n), api.DeviceArray(2 * n)
-f = api.Fir(synth.taps_cfg2(), data_complex=True)
+from simplefe_amd import lib  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "fir"
+n = 1 << (30 if which == "decimate" else 28)
+x = api.DeviceArray(2 * n)
 t = api.Timer()
+if which == "fir":
+    y = api.DeviceArray(2 * n)
+    f = api.Fir(synth.taps_cfg2(), data_complex=True)
+    call, count = (lambda: f.process_stream(x, y, n)), 3000
+elif which == "decimate":
+    y = api.DeviceArray(2 * (n // 8 + 64))
+    r = api.Rs(synth.taps_cfg4(), 1, 4096, mode=lib.RS_DECIMATE, data_complex=True)
+    call, count = (lambda: r.process_stream(x, n, y, n // 8 + 64, 8.0)), 1600
+else:
+    y = api.DeviceArray(2 * (n * 3 // 5 + 64))
+    r = api.Rs(synth.taps_cfg3(), 3, 4096, mode=lib.RS_RESAMPLE, data_complex=True)
+    call, count = (lambda: r.process_stream(x, n, y, n * 3 // 5 + 64, 5.0 / 3.0)), 3500
+print("# %s" % which)
 
 
 def smi():
@@ -25,24 +40,24 @@ def smi():
     return " ; ".join(keep[:6])
 
 
-for what in ("zeros", "data", "zeros", "data"):
+for what in (("zeros", "data", "zeros", "data") if which == "fir" else ("zeros", "data")):
     if what == "zeros":
         x.zero()
     else:
         x.fill_synth(synth.SEED)
     for _ in range(50):
-        f.process_stream(x, y, n)
+        call()
     api.sync()
     t.start()
-    for _ in range(3000):
-        f.process_stream(x, y, n)
+    for _ in range(count):
+        call()
     t.stop()
     reads = []
     for _ in range(3):
         time.sleep(0.25)
         reads.append(smi())
-    ms = t.elapsed_ms() / 3000
+    ms = t.elapsed_ms() / count
     print("%-5s  %.4f ms per launch" % (what, ms))
-    for r in reads:
-        print("        " + r)
+    for line_ in reads:
+        print("        " + line_)
     sys.stdout.flush()
