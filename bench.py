@@ -88,6 +88,10 @@ def parse():
     ap.add_argument("--screen", type=int, default=4,
                     help="output buffers allocated per leg (twice as many where these show no spread), the one that runs fastest against the input in a bare read + write mix kept "
                          "(sfe_dsp_probe_pair; DESIGN.md 4.2: what a pair of allocations gives is fixed when the memory is handed out). 1: no screening")
+    ap.add_argument("--telemetry", action="store_true",
+                    help="after everything else: an UNTIMED run of ~2 s of the headline's launches with rocm-smi's shader clock and package power read "
+                         "three times while they run, reported as roofline.telemetry (round 4: the FIR runs the package at its power cap on data, "
+                         "DESIGN.md 9; off by default)")
     ap.add_argument("--no-calibrate", action="store_true",
                     help="do not call sfe_dsp_fir_calibrate before the headline leg (run the default variant)")
     ap.add_argument("--single-process", action="store_true",
@@ -360,6 +364,33 @@ def screened_input(ctx, leg, src, y):
         b["input_moved"] = True
         return alt
     return src
+
+
+def telemetry(ctx, leg, kern_ms):
+    """--telemetry: ~2 s of the leg's launches queued (untimed), rocm-smi read three times while they run.  Best effort: any
+    failure is reported in the field, never raised (scripts/probes/fir_power.py is the stand-alone form)."""
+    import re
+    import subprocess
+    torch = ctx["torch"]
+    try:
+        count = max(50, min(4000, int(2000.0 / max(kern_ms, 0.05))))
+        for _ in range(count):
+            leg.step()
+        reads = []
+        for _ in range(3):
+            time.sleep(0.25)
+            txt = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=6).stdout
+            sclk = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", txt)
+            watt = re.search(r"Package Power \(W\): ([0-9.]+)", txt)
+            reads.append({"sclk_mhz": int(sclk.group(1)) if sclk else None, "package_w": float(watt.group(1)) if watt else None})
+        torch.cuda.synchronize()
+        return {"launches_queued": count, "reads_while_running": reads, "source": "rocm-smi --showclocks --showpower"}
+    except Exception as e:                      # noqa: BLE001
+        try:
+            torch.cuda.synchronize()
+        except Exception:                       # noqa: BLE001
+            pass
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 def verify_input(ctx, leg, windows=24, W=4096):
@@ -1121,6 +1152,8 @@ def main():
             "one this leg's own launch ran fastest on is kept, all outside the timed region (DESIGN.md 4.2); --screen 1 disables" if lib else
             "output buffer: the fastest of the candidates against the input in a bare read + write mix (sfe_dsp_probe_pair, outside the "
             "timed region; DESIGN.md 4.2); --screen 1 disables"))
+    if args.telemetry and rank == 0:
+        out["roofline"]["telemetry"] = telemetry(ctx, head, kern_ms)
     if traffic_stale:
         out["roofline"]["traffic_stale"] = True      # simplefe_amd/csrc changed since the PMC pass in profiles/
     if world > 1:
