@@ -420,3 +420,20 @@ def test_bench_notices_an_input_that_lost_its_data():
     assert bench.verify_input(ctx, leg) is False
     leg.input_spec = None
     assert bench.verify_input(ctx, leg) is None
+
+
+def test_bench_telemetry_never_raises():
+    """bench.py --telemetry is best effort: whatever rocm-smi or the device do, the field is a JSON-serialisable dict (here, on a
+    host without a GPU, the synchronise fails or rocm-smi has nothing to show)."""
+    import importlib.util
+    import json
+    import torch
+    spec = importlib.util.spec_from_file_location("bench_module_t", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class Leg:
+        step = staticmethod(lambda: None)
+    got = bench.telemetry({"torch": torch}, Leg(), 40.0)
+    assert isinstance(got, dict) and ("error" in got or "reads_while_running" in got)
+    json.dumps(got)
