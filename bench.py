@@ -428,8 +428,8 @@ def make_fir_leg(ctx, name, taps, n, nch, ch0=0, algo="auto", in_fmt="f32", out_
     else:
         if in_fmt == "f32" and out_fmt == "f32" and y_share is None:
             # up to three pairs from the library; which of them the FIR runs fastest on is decided further down with the
-            # leg's own launch (its persistent workgroups follow the bare mix only loosely: two sustained modes ~10 % apart,
-            # profiles/r04/headline_300_steps.txt)
+            # leg's own launch (they differ by 1-2 %.  The "10 % faster mode" this was written to catch was the FIR reading an
+            # input that had lost its data -- DESIGN.md 4.2; verify_input below is the check that came out of it)
             for _ in range(3):
                 got = built_pair(ctx, leg, nch * n * 2, nch * n * 2, torch.float32, keep=False)
                 if not got:
