@@ -28,10 +28,10 @@ BEFORE anything touches the GPU and relays rank 0's line.  It never prints an n_
                 median of the K steps beside the mean); `traffic` is the PMC-measured HBM bytes
                 per launch from profiles/ -- null if no pass was recorded, and null with
                 `traffic_stale: true` if simplefe_amd/csrc/ has changed since that pass.
-buffers         every leg's output buffer is the fastest of --screen (default 4) candidates against the leg's input in a
-                bare read + write mix (sfe_dsp_probe_pair), chosen OUTSIDE the timed region and reported (`buffers`): what a
-                pair of allocations gives a streaming kernel is fixed when the memory is handed out.
-                --screen 1: plain allocations.
+buffers         plain allocations (torch.empty), whatever the driver hands out: round 4's screening of output candidates and
+                its library-built pairs selected on the measured quantity and are gone (the pair allocator
+                now lives in the diagnostic library only).  Every float32 input is verified bit for bit against the host
+                generator BEFORE the timed steps and again after them; a leg whose input fails is an error row, never timed.
 `other_configs` (N = 1, default workload) the other BASELINE.json configs at G = 1, each a short
                 timed leg of its own with parity: resample 5/3 (configs[2], in both readings of
                 "127-tap polyphase arm": the 381-tap prototype and the 127-tap prototype), decimate by 8
@@ -85,9 +85,6 @@ def parse():
                     help="tx10: the FIR writes the 10-bit transmit wire format (fused TX converter, N2)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-others", action="store_true", help="skip the other_configs legs")
-    ap.add_argument("--screen", type=int, default=4,
-                    help="output buffers allocated per leg (twice as many where these show no spread), the one that runs fastest against the input in a bare read + write mix kept "
-                         "(sfe_dsp_probe_pair; DESIGN.md 4.2: what a pair of allocations gives is fixed when the memory is handed out). 1: no screening")
     ap.add_argument("--telemetry", action="store_true",
                     help="after everything else: an UNTIMED run of ~2 s of the headline's launches with rocm-smi's shader clock and package power read "
                          "three times while they run, reported as roofline.telemetry (round 4: the FIR runs the package at its power cap on data, "
@@ -254,118 +251,6 @@ def _p2(v):
     return "2^%d" % (v.bit_length() - 1) if v > 0 and v & (v - 1) == 0 else str(v)
 
 
-def screened_output(ctx, leg, src, numel, dtype):
-    """The leg's output buffer: ctx["screen"] candidates, each timed against the input `src` with the library's bare read +
-    write mix (sfe_dsp_probe_pair), the fastest kept.  What a PAIR of allocations gives a kernel that reads one while it
-    writes the other is fixed when the memory is handed out -- two classes of allocation, ~8 % between a pair from one class
-    and a pair from two for the decimator's mix, while each stream alone runs the same -- so a caller that
-    cares allocates its pair this way (sfe_dsp_malloc_pair is the same thing behind the C ABI).  Outside the timed region;
-    what was probed is reported in the row ("buffers")."""
-    import ctypes as C
-    torch, L, dev = ctx["torch"], ctx["L"], ctx["dev"]
-    tries = max(1, int(ctx.get("screen", 1)))
-    cands, ms, spacers = [], [], []
-    for k in range(2 * tries if tries > 1 else 1):
-        # twice as many where the first `tries` show no spread (all of one class): the further ones from OTHER stretches of the
-        # memory -- the classes run in stretches of tens of GiB (DESIGN.md 4.2 (e)) and a fresh process tends to be handed what
-        # the last one freed -- by way of a 32 GiB spacer in front of each pair of them, held until the choice is made
-        if k >= tries and (min(ms) <= 0 or min(ms) < 0.96 * max(ms)):
-            break
-        if k >= tries and (k - tries) % 2 == 0:
-            try:
-                spacers.append(torch.empty(32 << 30, dtype=torch.uint8, device=dev))
-            except RuntimeError:
-                pass
-        try:
-            y = torch.empty(numel, dtype=dtype, device=dev)
-        except RuntimeError:                      # out of memory further on: choose among what there is
-            break
-        cands.append(y)
-        t = C.c_float(0.0)
-        if tries > 1 and src.numel() * src.element_size() >= 32768 and y.numel() * y.element_size() >= 4096:
-            torch.cuda.synchronize()
-            ctx["api"].check(L.sfe_dsp_probe_pair(src.data_ptr(), src.numel() * src.element_size(), y.data_ptr(),
-                                                 y.numel() * y.element_size(), C.byref(t)))
-        ms.append(float(t.value))
-    if not cands:
-        raise RuntimeError("no memory for the output buffer")
-    best = int(np.argmin(ms))
-    if tries > 1:
-        leg.buffers = {"output_candidates": len(cands), "probe_ms": [round(v, 4) for v in ms], "kept": best}
-        if spacers:
-            leg.buffers["spacers_gib"] = 32 * len(spacers)
-    y = cands[best]
-    del cands, spacers
-    torch.cuda.empty_cache()                      # the losers and the spacers go back to the driver, not into torch's cache
-    return y
-
-
-class _DevMem:
-    """A library allocation as a torch tensor's storage (__cuda_array_interface__)."""
-    def __init__(self, ptr, n, typestr):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
-
-
-def built_pair(ctx, leg, n_in_f32, numel_out, dtype_out, keep=True, min_bytes=2 << 30):
-    """The leg's input and output as a pair BUILT by the library (sfe_dsp_malloc_pair: 1 GiB physical chunks classified with
-    the bare mix, the input mapped from one class and the output from another) -- for the legs whose input is
-    2 GiB and more, where what a plain pair gives is a lottery worth 8 % (decimate) to 18 % (8 GiB : 8 GiB in the bare mix).
-    Returns (x, y) float32 / dtype_out tensors over that memory, or None (--screen 1, or the library fell back and could
-    not do better than plain allocations: the caller then screens plain tensors).  Outside the timed region; reported."""
-    import ctypes as C
-    torch, L, dev = ctx["torch"], ctx["L"], ctx["dev"]
-    if int(ctx.get("screen", 1)) <= 1 or 4 * n_in_f32 < min_bytes:
-        return None
-    esz = torch.empty(0, dtype=dtype_out).element_size()
-    a, b, kept, worst = C.c_void_p(), C.c_void_p(), C.c_float(), C.c_float()
-    t0 = time.perf_counter()
-    torch.cuda.synchronize()
-    rc = L.sfe_dsp_malloc_pair(4 * n_in_f32, esz * numel_out, int(ctx["screen"]), C.byref(a), C.byref(b), C.byref(kept), C.byref(worst))
-    if rc != 0:
-        return None
-    typestr = {torch.float32: "<f4", torch.uint8: "|u1"}[dtype_out]
-    x = torch.as_tensor(_DevMem(a.value, n_in_f32, "<f4"), device=dev)
-    y = torch.as_tensor(_DevMem(b.value, numel_out, typestr), device=dev)
-    leg.buffers = {"pair": "sfe_dsp_malloc_pair", "probe_ms": [round(float(kept.value), 4)], "kept": 0,
-                   "same_class_probe_ms": round(float(worst.value), 4), "seconds": round(time.perf_counter() - t0, 2)}
-    if keep:
-        ctx.setdefault("_library_memory", []).append((a, b))      # (lives as long as the process)
-        return x, y
-    return x, y, (a, b)
-
-
-def screened_input(ctx, leg, src, y):
-    """Where the output candidates showed NO spread against `src` -- all of the input's class, or all of the other -- one
-    more allocation for the INPUT is probed against the kept output; if that pair is at least 4 % faster the samples are copied
-    over and the leg reads from there (what a pair gives is an exclusive-or of the two allocations' classes).
-    Returns the tensor to read from.  Outside the timed region; reported in the row."""
-    import ctypes as C
-    torch, L = ctx["torch"], ctx["L"]
-    b = getattr(leg, "buffers", None)
-    if not b or len(b["probe_ms"]) < 2 or min(b["probe_ms"]) < 0.96 * max(b["probe_ms"]):
-        return src
-    spacer = None
-    try:
-        spacer = torch.empty(32 << 30, dtype=torch.uint8, device=src.device)      # (another stretch of the memory: screened_output)
-    except RuntimeError:
-        pass
-    try:
-        alt = torch.empty_like(src)
-    except RuntimeError:
-        return src
-    del spacer
-    t = C.c_float(0.0)
-    torch.cuda.synchronize()
-    ctx["api"].check(L.sfe_dsp_probe_pair(alt.data_ptr(), alt.numel() * alt.element_size(), y.data_ptr(), y.numel() * y.element_size(), C.byref(t)))
-    b["input_alternative_probe_ms"] = round(float(t.value), 4)
-    if t.value < 0.96 * b["probe_ms"][b["kept"]]:
-        alt.copy_(src)
-        torch.cuda.synchronize()
-        b["input_moved"] = True
-        return alt
-    return src
-
-
 def telemetry(ctx, leg, kern_ms):
     """--telemetry: ~2 s of the leg's launches queued (untimed), rocm-smi read three times while they run.  Best effort: any
     failure is reported in the field, never raised (scripts/probes/fir_power.py is the stand-alone form)."""
@@ -422,24 +307,12 @@ def make_fir_leg(ctx, name, taps, n, nch, ch0=0, algo="auto", in_fmt="f32", out_
     n_gpu = n * nch
     leg.n, leg.nch, leg.n_gpu = n, nch, n_gpu
     leg.seeds = [ch0 + c for c in range(nch)]                  # global channel id = its seed
-    pair, lib_pairs = None, []
     if x_share is not None:
         x = x_share
     else:
-        if in_fmt == "f32" and out_fmt == "f32" and y_share is None:
-            # up to three pairs from the library; which of them the FIR runs fastest on is decided further down with the
-            # leg's own launch (they differ by 1-2 %.  The "10 % faster mode" this was written to catch was the FIR reading an
-            # input that had lost its data -- DESIGN.md 4.2; verify_input below is the check that came out of it)
-            for _ in range(3):
-                got = built_pair(ctx, leg, nch * n * 2, nch * n * 2, torch.float32, keep=False)
-                if not got:
-                    break
-                lib_pairs.append(got + (dict(leg.buffers),))
-        x = lib_pairs[0][0] if lib_pairs else torch.empty(nch * n * 2, dtype=torch.float32, device=dev)
-        for xx in ([p_[0] for p_ in lib_pairs] or [x]):
-            for c in range(nch):
-                api.check(L.sfe_dsp_synth_fill(xx.data_ptr() + c * n * 8, 2 * n, synth.SEED, leg.seeds[c], 0, stream))
-        pair = lib_pairs[0][:2] if lib_pairs else None
+        x = torch.empty(nch * n * 2, dtype=torch.float32, device=dev)
+        for c in range(nch):
+            api.check(L.sfe_dsp_synth_fill(x.data_ptr() + c * n * 8, 2 * n, synth.SEED, leg.seeds[c], 0, stream))
     in_bytes, out_bytes = 8.0, 8.0
     src = x
     ctaps = bool(np.iscomplexobj(taps))
@@ -474,36 +347,9 @@ def make_fir_leg(ctx, name, taps, n, nch, ch0=0, algo="auto", in_fmt="f32", out_
         out_bytes = 2.5
         leg.key += "_tx10"
         leg.workload += ", 10-bit packed transmit wire format out"
-        leg.y = screened_output(ctx, leg, src, nch * (n * 2 // 4) * 5 + 64, torch.uint8)
+        leg.y = torch.empty(nch * (n * 2 // 4) * 5 + 64, dtype=torch.uint8, device=dev)
     else:
-        leg.y = y_share if y_share is not None else (pair[1] if pair else screened_output(ctx, leg, src, nch * n * 2, torch.float32))
-    if len(lib_pairs) > 1:
-        tm = api.Timer()
-        for _ in range(40):                      # the chip through its start-up transient before anything is compared
-            leg.obj.process_stream(lib_pairs[0][0].data_ptr(), lib_pairs[0][1].data_ptr(), n, stream=stream)
-        times = []
-        for xs, ys, _, _ in lib_pairs:
-            for _ in range(2):
-                leg.obj.process_stream(xs.data_ptr(), ys.data_ptr(), n, stream=stream)
-            tm.start(stream)
-            for _ in range(5):
-                leg.obj.process_stream(xs.data_ptr(), ys.data_ptr(), n, stream=stream)
-            tm.stop(stream)
-            times.append(tm.elapsed_ms() / 5)
-        best = int(np.argmin(times))
-        x = src = leg.x = lib_pairs[best][0]
-        leg.y = lib_pairs[best][1]
-        leg.buffers = dict(lib_pairs[best][3], pairs_timed_with_the_legs_own_kernel_ms=[round(v, 4) for v in times], kept=best)
-        torch.cuda.synchronize()
-        for k, (_, _, (pa, pb), _) in enumerate(lib_pairs):
-            if k == best:
-                ctx.setdefault("_library_memory", []).append((pa, pb))
-            else:
-                L.sfe_dsp_free(pa)
-                L.sfe_dsp_free(pb)
-        leg.obj.reset()
-    elif lib_pairs:
-        ctx.setdefault("_library_memory", []).append(lib_pairs[0][2])
+        leg.y = y_share if y_share is not None else torch.empty(nch * n * 2, dtype=torch.float32, device=dev)
     leg.out_fmt = out_fmt
     leg.bytes_per_launch = (in_bytes + out_bytes) * n_gpu       # 8 B read + 8 B written per sample
     leg.kernel = "fir_fft4096_kernel" if algo != "direct" else "poly_tiled_kernel"
@@ -608,9 +454,7 @@ def make_rs_leg(ctx, which, log2n, in_fmt="f32", short_proto=False):
         leg.key = "decimate8_cf32_2p%d" % log2n
     rate = float(np.float32(S) / np.float32(U))
     leg.taps, leg.U, leg.S, leg.rate = taps, U, S, rate
-    # (the resampler's 2 GiB : 1.2 GiB buffers show no spread in the bare mix: only the decimator's 8 GiB : 1 GiB are built)
-    pair = built_pair(ctx, leg, n * 2, (n * U // S + 8) * 2, torch.float32, min_bytes=4 << 30) if in_fmt != "u8" else None
-    x = pair[0] if pair else torch.empty(n * 2, dtype=torch.float32, device=dev)
+    x = torch.empty(n * 2, dtype=torch.float32, device=dev)
     api.check(L.sfe_dsp_synth_fill(x.data_ptr(), 2 * n, synth.SEED, 0, 0, stream))
     src, in_bytes = x, 8.0
     if in_fmt == "u8":
@@ -621,15 +465,7 @@ def make_rs_leg(ctx, which, log2n, in_fmt="f32", short_proto=False):
         leg.workload += ", u8 (I,Q) wire-format input converted on load"
     leg.x, leg._src = x, src
     out_cap = n * U // S + 8
-    if pair:
-        leg.y = pair[1]
-    else:
-        leg.y = screened_output(ctx, leg, src, out_cap * 2, torch.float32)
-        moved = screened_input(ctx, leg, src, leg.y)
-        if moved is not src:
-            if x is src:
-                x = leg.x = moved
-            src = leg._src = moved
+    leg.y = torch.empty(out_cap * 2, dtype=torch.float32, device=dev)
     leg.input_spec = [(0, 2 * n, 0)] if in_fmt != "u8" else None
     leg.obj = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE if which == "resample" else lib.RS_DECIMATE,
                      data_complex=True, n_channels=1, device=ctx["local_rank"])
@@ -715,8 +551,7 @@ def make_general_rate_leg(ctx, log2n=28, rate=1.77, interpolate=0):
     api.check(L.sfe_dsp_synth_fill(x.data_ptr(), 2 * n, synth.SEED, 0, 0, stream))
     out_cap = int(n / rate) + 4096
     leg.x = x
-    leg.y = screened_output(ctx, leg, x, out_cap * 2, torch.float32)
-    x = leg.x = screened_input(ctx, leg, x, leg.y)
+    leg.y = torch.empty(out_cap * 2, dtype=torch.float32, device=dev)
     leg.input_spec = [(0, 2 * n, 0)]
     leg.obj = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=True, n_channels=1, device=ctx["local_rank"])
     leg.kernel = "poly_rt1_kernel" if interpolate else "poly_gen4096_kernel"
@@ -760,7 +595,7 @@ def group_leg(ctx, taps, total_channels, n_ch, devices, steps, warmup):
     from oracle import binding as orc
     grp = api.FirGroup(taps, total_channels, devices)
     sh = grp.shards()
-    xs, ys, probes = [], [], []
+    xs, ys = [], []
     for d, f, c, _, _ in sh:
         with torch.cuda.device(d):
             x = torch.empty(c * n_ch * 2, dtype=torch.float32, device="cuda:%d" % d)
@@ -768,10 +603,7 @@ def group_leg(ctx, taps, total_channels, n_ch, devices, steps, warmup):
                 api.check(L.sfe_dsp_synth_fill(x.data_ptr() + k * n_ch * 8, 2 * n_ch, synth.SEED, f + k, 0, None))
             torch.cuda.synchronize(d)
             xs.append(x)
-            # the shard's output: screened against its input like every leg's (screened_output)
-            shard_leg = Leg()
-            ys.append(screened_output(dict(ctx, dev="cuda:%d" % d), shard_leg, x, x.numel(), torch.float32))
-            probes.append(getattr(shard_leg, "buffers", None))
+            ys.append(torch.empty_like(x))
     pin, pout = [x.data_ptr() for x in xs], [y.data_ptr() for y in ys]
     for _ in range(max(2, warmup)):
         grp.process_stream(pin, pout, n_ch)
@@ -809,7 +641,6 @@ def group_leg(ctx, taps, total_channels, n_ch, devices, steps, warmup):
             "devices": list(devices), "shards": [[d, f, c] for d, f, c, _, _ in sh],
             "parity": {"rel_rms_max": worst, "windows": count, "window_len": W, "tol": TOL, "ok": bool(worst <= TOL)},
             "checksum": {"samples": csum[0], "sum_re": csum[1], "sum_im": csum[2], "sum_abs2": csum[3]},
-            "buffers": probes if any(probes) else None,
             "timed": "wall clock around %d sfe_dsp_fir_group_process_stream calls + one sfe_dsp_fir_group_sync" % steps}
 
 
@@ -825,7 +656,7 @@ def main_single_process(args):
     if torch.cuda.device_count() < args.gpus and not one_dev:
         raise SystemExit(f"--gpus {args.gpus} but this node shows {torch.cuda.device_count()} GPU(s)")
     devices = [0] * args.gpus if one_dev else list(range(args.gpus))
-    ctx = {"torch": torch, "api": api, "lib": lib, "synth": synth, "shard": shard, "L": lib.load(), "screen": args.screen}
+    ctx = {"torch": torch, "api": api, "lib": lib, "synth": synth, "shard": shard, "L": lib.load()}
     total_channels = args.channels or 64
     log2n = args.log2n or 30
     n_ch = (1 << log2n) // total_channels
@@ -1001,7 +832,7 @@ def main():
 
     ctx = {"torch": torch, "api": api, "lib": lib, "synth": synth, "shard": shard, "L": L, "dev": dev,
            "red_dev": red_dev, "stream": torch.cuda.current_stream().cuda_stream, "rank": rank,
-           "local_rank": local_rank, "world": world, "barrier": barrier, "screen": args.screen}
+           "local_rank": local_rank, "world": world, "barrier": barrier}
     ctx_red = red_dev       # where the control-plane reductions live: the GPU under RCCL, the host under gloo
 
     wl = args.workload
@@ -1060,7 +891,18 @@ def main():
             other_errors = other_errors or [{"error": "an other_configs leg could not be set up on another rank"}]
     other_rows = []
     precondition(ctx, others[0] if others else head, args.precondition)      # whichever leg runs first takes the chip through its start-up transient
+    def input_held(leg):
+        """verify_input agreed over the ranks (every rank reaches the reduction): None = nothing to check"""
+        held = verify_input(ctx, leg)
+        bad = shard.max_over_ranks(1.0 if held is False else 0.0, ctx_red) > 0
+        return None if (held is None and not bad) else (not bad)
+
+    timed_others = []
     for leg in others:
+        if input_held(leg) is False:         # never timed: an input that lost its data runs the kernels faster (DESIGN.md 0)
+            other_errors.append({"workload": leg.workload, "error": "the input is not the synthetic stream BEFORE the timed steps; leg not timed"})
+            continue
+        timed_others.append(leg)
         el, kms = time_leg(ctx, leg, args.other_steps, 3)
         kmean = shard.max_over_ranks(float(np.mean(kms)), ctx_red)
         row = {"workload": leg.workload, "steps": args.other_steps, "ms": kmean,
@@ -1069,20 +911,22 @@ def main():
                "frac": leg.bytes_per_launch / (kmean * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if getattr(leg, "variant", None):
             row["variant"] = leg.variant["ran"]
-        if getattr(leg, "buffers", None):
-            row["buffers"] = leg.buffers
         if leg.name == "decimate":
             # this launch runs in one of two modes ~6 % apart that belong to how the process's 8 GiB + 1 GiB buffers
-            # happen to be backed physically, not to the kernel (profiles/r04/decimate_modes_*.txt):
-            # the line says which one this process landed in
-            row["mode"] = "fast (<= 1.53 ms)" if kmean <= 1.53 else "slow (> 1.53 ms: the allocation's physical backing, DESIGN.md 4.2)"
+            # happen to be backed physically, not to the kernel (profiles/r04/NOTES.md): plain allocations, so the row is
+            # whichever of the two this process was handed
+            row["note"] = "plain allocations: one of two placement modes ~6 % apart (profiles/r04/NOTES.md)"
         if world > 1:
             row["scaling"] = "weak"
             row["workload"] += " -- per rank, %d ranks (weak scaling: the per-GPU launch is the same at every N)" % world
             row["frac_note"] = "per-GPU algorithmic bytes / slowest rank's mean launch time / 8 TB/s"
         other_rows.append(row)
 
+    others = timed_others
     # ---- headline: W untimed + exactly K timed steps
+    held_before = input_held(head)
+    if held_before is False:
+        raise SystemExit("bench.py: the headline input is not the synthetic stream before the timed steps; nothing was timed")
     elapsed, kern_list = time_leg(ctx, head, args.steps, args.warmup)
     ms_per_step = elapsed * 1e3 / args.steps
     job_samples = shard.sum_over_ranks([head.n_gpu], ctx_red)[0]      # all ranks' samples per step
@@ -1101,11 +945,11 @@ def main():
               "ok": bool(worst_all <= (2e-3 if is_tx10 else TOL)), "ranks_checked": world,
               "checked": "last timed step, every rank: " + ("every local channel, first and last window" if world > 1 and head.kind == "fir"
                                                             else "first and last local channel")}
-    held = verify_input(ctx, head)
+    held = input_held(head)
     if held is not None:
-        held = bool(shard.max_over_ranks(0.0 if held else 1.0, ctx_red) == 0.0)
-        parity["input_is_the_synthetic_stream"] = held         # (checked after the timed steps: what they read)
-        parity["ok"] = parity["ok"] and held
+        parity["input_is_the_synthetic_stream"] = bool(held)   # bit for bit, before the timed steps (above) AND after them
+        parity["input_checked"] = "before and after the timed steps"
+        parity["ok"] = parity["ok"] and bool(held)
     if is_tx10:
         parity["note"] = "10-bit output: figure = fraction of packed bytes differing from the oracle's packing (1-LSB code-boundary flips)"
     for leg, row in zip(others, other_rows):
@@ -1113,10 +957,10 @@ def main():
         if world > 1:
             w, c = shard.max_over_ranks(w, ctx_red), int(shard.sum_over_ranks([c], ctx_red)[0])
         row["parity"] = {"rel_rms_max": w, "windows": c, "window_len": wl_, "tol": TOL, "ok": bool(w <= TOL)}
-        held = verify_input(ctx, leg)
+        held = input_held(leg)
         if held is not None:
-            row["parity"]["input_is_the_synthetic_stream"] = held
-            row["parity"]["ok"] = row["parity"]["ok"] and held
+            row["parity"]["input_is_the_synthetic_stream"] = bool(held)
+            row["parity"]["ok"] = row["parity"]["ok"] and bool(held)
 
     sharded = world > 1 and head.kind == "fir"
     traffic, traffic_stale = pmc_traffic(head.key)
@@ -1145,13 +989,7 @@ def main():
     }
     if getattr(head, "variant", None):
         out["roofline"]["variant"] = head.variant     # which data-movement variant this device's measurement picked
-    if getattr(head, "buffers", None):
-        lib = head.buffers.get("pair") == "sfe_dsp_malloc_pair"
-        out["config"]["buffers"] = dict(head.buffers, note=(
-            "input and output from sfe_dsp_malloc_pair (built from physical chunks of different classes); of up to three such pairs the "
-            "one this leg's own launch ran fastest on is kept, all outside the timed region (DESIGN.md 4.2); --screen 1 disables" if lib else
-            "output buffer: the fastest of the candidates against the input in a bare read + write mix (sfe_dsp_probe_pair, outside the "
-            "timed region; DESIGN.md 4.2); --screen 1 disables"))
+    out["config"]["buffers"] = "plain allocations (torch.empty); nothing is selected on a measured quantity"
     if args.telemetry and rank == 0:
         out["roofline"]["telemetry"] = telemetry(ctx, head, kern_ms)
     if traffic_stale:

@@ -125,37 +125,43 @@ def ref_blkconv_lib():
 
 
 FFTW_DLL = os.environ.get("SFE_FFTW_DLL") or "/root/reference/contrib/fftw-3.3.5-dll64/libfftw3f-3.dll"
-_ref_blk_fftw = None
+FFTW_DLL_SHA256 = "42ca18fff35dd12890e04478bc990005b3969cb744f6843976bd436ccd7f0a4c"      # pinned in oracle/pe/peload.c too
+FFTW_OPT_IN = "SFE_ORACLE_RUN_FFTW_DLL"
 
 
-def ref_blkconv_fftw_lib():
-    """The compiled reference blkconv class on the reference's own FFTW 3.3.5 binary
-    (oracle/_ref/libsferef_blkconv_fftw.so, `make -C oracle ref_fftw`), or None where the DLL it
-    maps does not exist (the GPU box) or the library is not built."""
-    global _ref_blk_fftw
-    if _ref_blk_fftw is None:
-        if not os.path.exists(FFTW_DLL):
-            return None
-        p = os.path.join(HERE, "_ref", "libsferef_blkconv_fftw.so")
-        if not os.path.exists(p) and os.path.isdir("/root/reference"):
-            subprocess.check_call(["make", "-s", "-C", HERE, "ref_fftw"])
-        try:
-            R = _load(p)
-        except OSError:
-            R = None
-        if R is None:
-            return None
-        R.ref_blkconv_create.restype = C.c_void_p
-        R.ref_blkconv_create.argtypes = [_f32p, C.c_int, C.c_int]
-        R.ref_blkconv_blksize.argtypes = [C.c_void_p]
-        R.ref_blkconv_buf.restype = C.POINTER(C.c_float)
-        R.ref_blkconv_buf.argtypes = [C.c_void_p]
-        R.ref_blkconv_process.argtypes = [C.c_void_p]
-        R.ref_blkconv_destroy.argtypes = [C.c_void_p]
-        R.ref_blkconv_stream.argtypes = [C.c_void_p, _f32p, _f32p, C.c_long]
-        R.sfe_pe_fftwf_version.restype = C.c_char_p
-        _ref_blk_fftw = R
-    return _ref_blk_fftw
+def ref_blkconv_fftw_available():
+    """The reference's blkconv class on the reference's own FFTW 3.3.5 binary can run here: the DLL exists, is byte for byte the
+    pinned file, and the caller opted in (SFE_ORACLE_RUN_FFTW_DLL=1).  ADVICE r4: an opaque binary from the reference tree is
+    never mapped into THIS process -- oracle/ref_fftw_child.py does that in a child of its own (resource limits, scratch
+    directory, bare environment), and only on request."""
+    if os.environ.get(FFTW_OPT_IN) != "1" or not os.path.exists(FFTW_DLL):
+        return False
+    import hashlib
+    with open(FFTW_DLL, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest() == FFTW_DLL_SHA256
+
+
+def _fftw_child(op, taps=None, fft_len=0, x=None):
+    """One request to the child process: arrays travel as .npy files in a scratch directory."""
+    import sys
+    import tempfile
+    if not ref_blkconv_fftw_available():
+        raise RuntimeError("the FFTW-pinned reference is opt-in: set %s=1 (and /root/reference must hold the pinned DLL)" % FFTW_OPT_IN)
+    so = os.path.join(HERE, "_ref", "libsferef_blkconv_fftw.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref_fftw"])
+    with tempfile.TemporaryDirectory(prefix="sfe_fftw_") as d:
+        if taps is not None:
+            np.save(os.path.join(d, "taps.npy"), _f32(taps))
+            np.save(os.path.join(d, "x.npy"), _f32(x))
+        env = {"PATH": "/usr/bin:/bin", FFTW_OPT_IN: "1", "SFE_FFTW_DLL": FFTW_DLL}
+        r = subprocess.run([sys.executable, os.path.join(HERE, "ref_fftw_child.py"), so, op, str(int(fft_len)), d],
+                           cwd=d, env=env, capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            raise RuntimeError("oracle/ref_fftw_child.py failed: " + r.stderr[-2000:])
+        if op == "version":
+            return r.stdout.strip()
+        return np.load(os.path.join(d, "y.npy"))
 
 
 def _f32(a):
@@ -226,22 +232,24 @@ class RefBlkconv:
             self._h = None
 
 
-class RefBlkconvFFTW(RefBlkconv):
-    """The reference's own blkconv class on the reference's own FFTW 3.3.5 (the vendored Win64 DLL
-    mapped by oracle/pe/).  CPU; exists only where /root/reference does."""
-    _getlib = staticmethod(ref_blkconv_fftw_lib)
-    _libname = "libsferef_blkconv_fftw.so"
+class RefBlkconvFFTW:
+    """The reference's own blkconv class on the reference's own FFTW 3.3.5 (the vendored Win64 DLL mapped by oracle/pe/),
+    run in a CHILD process (oracle/ref_fftw_child.py); opt-in, CPU, exists only where /root/reference does."""
+
+    def __init__(self, taps, fft_len):
+        self.taps, self.fft_len = _f32(taps), int(fft_len)
 
     def stream(self, x):
-        x = _f32(x)
-        y = np.empty_like(x)
-        self._L.ref_blkconv_stream(self._h, x, y, len(x))
-        return y
+        """ref_blkconv_stream of the wrapper: the class driven block by block inside the child's C++"""
+        return _fftw_child("stream", self.taps, self.fft_len, x)
+
+    def stream_blocks(self, x):
+        """the same through get_process_buf() / process() from Python, block by block (RefBlkconv.stream's loop)"""
+        return _fftw_child("blocks", self.taps, self.fft_len, x)
 
     @classmethod
     def fftw_version(cls):
-        L = cls._getlib()
-        return L.sfe_pe_fftwf_version().decode() if L is not None else None
+        return _fftw_child("version") if ref_blkconv_fftw_available() else None
 
 
 class _Rs:

@@ -87,16 +87,73 @@ static uint8_t *g_img_base;
 static uint64_t g_img_size;
 void pe_image_range(void **base, unsigned long *size) { *base = g_img_base; *size = g_img_size; }
 
+/* ---- SHA-256 of the file about to be mapped (an opaque binary from the reference tree is executed in this process; it
+ * is mapped only if it is byte for byte the library the golden vectors were made with, and only when the caller opted in).  FIPS 180-4,
+ * integer arithmetic only. */
+static const uint32_t K256[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+static uint32_t ror32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+static void sha256_block(uint32_t h[8], const uint8_t *b)
+{
+    uint32_t w[64], a[8];
+    for (int i = 0; i < 16; i++) w[i] = (uint32_t)b[4 * i] << 24 | (uint32_t)b[4 * i + 1] << 16 | (uint32_t)b[4 * i + 2] << 8 | b[4 * i + 3];
+    for (int i = 16; i < 64; i++)
+        w[i] = w[i - 16] + (ror32(w[i - 15], 7) ^ ror32(w[i - 15], 18) ^ (w[i - 15] >> 3)) + w[i - 7] +
+               (ror32(w[i - 2], 17) ^ ror32(w[i - 2], 19) ^ (w[i - 2] >> 10));
+    memcpy(a, h, sizeof a);
+    for (int i = 0; i < 64; i++) {
+        uint32_t t1 = a[7] + (ror32(a[4], 6) ^ ror32(a[4], 11) ^ ror32(a[4], 25)) + ((a[4] & a[5]) ^ (~a[4] & a[6])) + K256[i] + w[i];
+        uint32_t t2 = (ror32(a[0], 2) ^ ror32(a[0], 13) ^ ror32(a[0], 22)) + ((a[0] & a[1]) ^ (a[0] & a[2]) ^ (a[1] & a[2]));
+        memmove(a + 1, a, 7 * sizeof a[0]);
+        a[4] += t1;
+        a[0] = t1 + t2;
+    }
+    for (int i = 0; i < 8; i++) h[i] += a[i];
+}
+static void sha256_hex(const uint8_t *p, uint64_t n, char out[65])
+{
+    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    uint64_t i = 0;
+    for (; i + 64 <= n; i += 64) sha256_block(h, p + i);
+    uint8_t tail[128] = {0};
+    uint64_t r = n - i, bits = n * 8;
+    memcpy(tail, p + i, r);
+    tail[r] = 0x80;
+    unsigned len = r + 9 <= 64 ? 64 : 128;
+    for (int k = 0; k < 8; k++) tail[len - 1 - k] = (uint8_t)(bits >> (8 * k));
+    sha256_block(h, tail);
+    if (len == 128) sha256_block(h, tail + 64);
+    for (int k = 0; k < 8; k++) snprintf(out + 8 * k, 9, "%08x", h[k]);
+}
+/* FFTW 3.3.5 single precision, the Win64 build the reference vendors (contrib/fftw-3.3.5-dll64/libfftw3f-3.dll) */
+#define SFE_PINNED_DLL_SHA256 "42ca18fff35dd12890e04478bc990005b3969cb744f6843976bd436ccd7f0a4c"
+
 pe_image *pe_load(const char *path, pe_resolver resolve)
 {
     pe_image *im = NULL;
     uint8_t *file = MAP_FAILED;
     struct stat st;
+    /* explicit opt-in: nothing maps and runs the binary unless the caller's environment says so */
+    const char *optin = getenv("SFE_ORACLE_RUN_FFTW_DLL");
+    if (!optin || strcmp(optin, "1") != 0) {
+        snprintf(g_err, sizeof g_err, "refusing to map %s: set SFE_ORACLE_RUN_FFTW_DLL=1 to opt in (it executes a binary from the reference tree)", path);
+        return NULL;
+    }
     int fd = open(path, O_RDONLY);
     if (fd < 0) { snprintf(g_err, sizeof g_err, "cannot open %s", path); return NULL; }
     if (fstat(fd, &st) != 0 || st.st_size < 0x200) FAIL("%s: too small for a PE image", path);
     file = mmap(NULL, st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     if (file == MAP_FAILED) FAIL("mmap of %s failed", path);
+    {
+        char hex[65];
+        sha256_hex(file, (uint64_t)st.st_size, hex);
+        if (strcmp(hex, SFE_PINNED_DLL_SHA256) != 0) FAIL("%s: sha256 %s is not the pinned library (%s)", path, hex, SFE_PINNED_DLL_SHA256);
+    }
 
     if (rd16(file) != 0x5a4d) FAIL("%s: no MZ header", path);
     uint32_t nt = rd32(file + 0x3c);

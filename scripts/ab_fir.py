@@ -2,6 +2,8 @@
 """Interleaved A/B timing of FIR kernel variants in ONE process on ONE device
 (cdna_hip_programming.md rule 24), through the DIAGNOSTIC library libsfe_dsp_diag.so (-DSFE_DIAG:
 built on demand; the product library has none of these switches).
+L / M / N = T without the two middle LDS exchanges / with one multiply per twiddle / both; l / n the same of X (round 5: energy
+ablations, WRONG results on purpose -- never compared for parity).  WATTS=1 also prints the in-kernel clock of each variant.
 Usage: ab_fir.py "4n.h" "3p" "c:8" "4n.h+1" ...   variant[:wg_per_cu][+diag bits: 1 no loads, 2 no stores]
   variant = <waves per SIMD 2-4><p prefetch | n none>[s XOR-swizzled LDS][h H/N in registers]
             c / d / e = the bare access pattern (8-byte plain / 16-byte plain / 8-byte nontemporal lanes)"""
@@ -98,4 +100,11 @@ if os.environ.get("WATTS") == "1":
             watt = re.search(r"Package Power \(W\): ([0-9.]+)", txt)
             reads.append("%s MHz %s W" % (sclk.group(1) if sclk else "?", watt.group(1) if watt else "?"))
         api.sync()
-        print(f"{v:8s} while running: " + " | ".join(reads))
+        # the clock workgroup 0 of the last of those launches saw (s_memtime / s_memrealtime stamps, diagnostic build only)
+        import ctypes as C
+        mhz, span = C.c_double(), C.c_double()
+        clk = ""
+        fn = getattr(lib.load(), "sfe_dsp_diag_fir_clock", None)
+        if fn is not None and fn(C.byref(mhz), C.byref(span)) == 0:
+            clk = f"   in-kernel clock {mhz.value:.0f} MHz over {span.value:.4f} ms"
+        print(f"{v:8s} while running: " + " | ".join(reads) + clk)

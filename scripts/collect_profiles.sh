@@ -4,7 +4,7 @@
 # the two transform kernels, and the variant / ablation tables from the diagnostic library.
 # Output under gpurun_out/prof_<tag>_*/; summarised into profiles/ by scripts/summarise_profiles.py
 # (run in the authoring container).   usage: scripts/collect_profiles.sh [tag]
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp; export TMPDIR=/tmp
 for WL in fir decimate resample; do
@@ -41,9 +41,10 @@ bash scripts/prof_pmc.sh prof_${TAG}_sq_fir fir_fft4096 -- python3 $R/bench.py -
 bash scripts/prof_pmc.sh prof_${TAG}_sq_decimate poly_tiled -- python3 $R/bench.py --workload decimate --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1 || exit 1
 bash scripts/prof_pmc.sh prof_${TAG}_sq_resample poly_fft256 -- python3 $R/bench.py --workload resample --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1 || exit 1
 # round 4: the general-rate transform-domain kernel (2^28 samples at rate 1.77, 381 taps in 3 phases)
-export LOG2N=28 GENERAL_ONLY=1
-bash scripts/prof_pmc.sh prof_${TAG}_sq_general poly_gen4096 -- python3 $R/scripts/time_general_rate.py > /dev/null 2>&1 || exit 1
-unset LOG2N GENERAL_ONLY
+# (round 5: ONE shape per counter file -- rate 1.77 alone, the default dispatch alone; round 4's file averaged 1.77 and 0.77)
+export LOG2N=28 GENERAL_ONLY=1 RATES=1.77 DEFAULT_ONLY=1
+bash scripts/prof_pmc.sh prof_${TAG}_sq_general poly_gen -- python3 $R/scripts/time_general_rate.py > /dev/null 2>&1 || exit 1
+unset LOG2N GENERAL_ONLY RATES DEFAULT_ONLY
 # COUNTERS_ONLY=1: stop here -- the kernel-trace / counter passes above are what is stamped with the source hash; the tables
 # below are interleaved A/B runs of named variants and stay valid while those variants' code does
 if [ -n "$COUNTERS_ONLY" ]; then echo collected counters; exit 0; fi

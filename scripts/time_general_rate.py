@@ -17,6 +17,12 @@ shapes = (("31 taps, U = 4", synth.lowpass_taps(31, 0.18, gain=4.0), 4, (1.77, 2
           ("381 taps, U = 3", synth.taps_cfg3(), 3, (1.77, 0.77)))
 if os.environ.get("GENERAL_ONLY"):         # counter passes: the long filter alone (the transform-domain kernel's shape)
     shapes = shapes[1:]
+if os.environ.get("RATES"):                # RATES=1.77: ONE rate per process, so that a counter pass averages launches of one shape
+    rr = tuple(float(v) for v in os.environ["RATES"].split(","))     # (round 4's counters mixed 1.77 and 0.77)
+    shapes = tuple((nm, tp, U, rr) for nm, tp, U, _ in shapes)
+algos = ((lib.RS_ALGO_AUTO, "default dispatch"), (lib.RS_ALGO_DIRECT, "direct form (poly_seg_kernel)"))
+if os.environ.get("DEFAULT_ONLY"):         # counter passes: the default dispatch alone
+    algos = algos[:1]
 timer = api.Timer()
 for name, taps, U, rates in shapes:
   r = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=True)
@@ -33,7 +39,7 @@ for name, taps, U, rates in shapes:
     dt = (time.perf_counter() - t0) / 3
     print(f"rate {rate}: 2^{log2n} cf32 in -> {k} out: {dt * 1e3:.2f} ms per call ({n / dt / 1e6:.0f} MS/s)")
     # ... and what of that is the kernel (HIP events on the launch stream) with each of the two kernels
-    for algo, label in ((lib.RS_ALGO_AUTO, "default dispatch"), (lib.RS_ALGO_DIRECT, "direct form (poly_seg_kernel)")):
+    for algo, label in algos:
         r.set_algo(algo)
         r.process_stream(x, n, y, cap, rate)
         v = []

@@ -22,9 +22,9 @@ ARCH = "gfx950"
 # bit-exact restatements of the reference arithmetic: no implicit FMA contraction
 EXACT_SOURCES = ("polyphase.hip", "util.hip")
 TICKET_SOURCES = ("fir_fft.hip", "poly_fft.hip")
-# host side only (handles, plans, launch choices, device groups; alloc.hip also holds the one check kernel of sfe_dsp_malloc_pair, which
-# no measured path launches): not part of the kernel-source hash
-HOST_SOURCES = ("api.hip", "api_plans.hip", "api_fir.hip", "api_rs.hip", "api_pipe.hip", "group.hip", "alloc.hip", "host.h")
+# host side only (handles, plans, launch choices, device groups):
+# not part of the kernel-source hash
+HOST_SOURCES = ("api.hip", "api_plans.hip", "api_fir.hip", "api_rs.hip", "api_pipe.hip", "group.hip", "host.h")
 
 
 def sources(diag=False):

@@ -104,7 +104,13 @@ int sfe_dsp_malloc(void **dptr, size_t bytes)
     SFE_HIP(hipMalloc(dptr, bytes ? bytes : 16));
     return SFE_OK;
 }
-// (sfe_dsp_free, sfe_dsp_malloc_pair, sfe_dsp_probe_pair: alloc.hip)
+#ifndef SFE_DIAG      // (the diagnostic library's own, diag/alloc.hip, also undoes the chunk-mapped ranges of its sfe_dsp_malloc_pair)
+int sfe_dsp_free(void *dptr)
+{
+    if (dptr) SFE_HIP(hipFree(dptr));
+    return SFE_OK;
+}
+#endif
 int sfe_dsp_host_alloc(void **hptr, size_t bytes)
 {
     if (!hptr) return SFE_EINVAL;

@@ -264,10 +264,6 @@ struct PolyGenArgs {
     int         adv;            // input samples a block owns (launcher: 4096 - ovl, fewer for rates below ~1)
     int         real;           // a real float32 stream: two consecutive blocks per transform (poly_gen.hip: REAL)
     int         in_u8;          // the stream is u8 offset binary, converted on load (poly_gen.hip: IN_U8)
-    // (the diagnostic persistent form only, diag/poly_gen_persistent.hip: blocks per channel in a launch's list, where the
-    // list starts, channels, blocks dealt by a device counter)
-    long long   nblk, blk_first;
-    int         n_channels, tickets;
 };
 // SFE_ESTATE: outside what the kernel takes (caller: launch_poly_seg)
 int launch_poly_gen(const PolyGenArgs &a, int max_runs, float step, int n_channels, hipStream_t s);
@@ -284,6 +280,5 @@ int launch_synth_fill(float *d, uint64_t n, uint32_t seed, uint32_t ch, uint64_t
                       hipStream_t s);
 int launch_rx_u8_to_f32(const uint8_t *src, float *dst, size_t n, hipStream_t s);
 int launch_tx_f32_to_10bit(const float *src, uint8_t *dst, size_t n_floats, hipStream_t s);
-int launch_pair_probe(const void *in, size_t in_bytes, void *out, size_t out_bytes, hipStream_t s);
 
 }  // namespace sfe

@@ -1,4 +1,5 @@
-// alloc.hip -- sfe_dsp_malloc_pair / sfe_dsp_probe_pair / sfe_dsp_free: a PAIR of device buffers for a stream call that reads one
+// diag/alloc.hip -- DIAGNOSTIC LIBRARY ONLY (round 5: demoted from the product, DESIGN.md 9 -- the loss of data on a fresh mapping
+// was never tied to a cause, and a built pair never reached what the best plain pair gives).  sfe_dsp_malloc_pair / sfe_dsp_probe_pair / sfe_dsp_free: a PAIR of device buffers for a stream call that reads one
 // while it writes the other.  Host code, and one small kernel of its own (count_not_held_kernel: the check that a new mapping
 // holds what is written to it); no product kernel lives here, which is why scripts/ leave this file out of the kernel hash.
 //
@@ -24,7 +25,8 @@
 #include <unordered_map>
 #include <vector>
 
-#include "common.h"
+#include "../common.h"
+#include "sfe_dsp_diag.h"
 
 namespace sfe {
 namespace {
@@ -33,6 +35,7 @@ constexpr size_t CHUNK = (size_t)1 << 30;
 
 struct Mapped {                                  // one buffer made of chunks: what sfe_dsp_free has to undo
     size_t bytes = 0;                            // of the reserved range
+    int device = 0;                              // the device the chunks live on (the free must sync and unmap THERE)
     std::vector<hipMemGenericAllocationHandle_t> chunks;
 };
 std::mutex g_mu;
@@ -42,12 +45,52 @@ void *g_diag_pool = nullptr;                     // SFE_PAIR_KEEP_POOL=1: the re
 size_t g_diag_pool_chunks = 0;
 #endif
 
+// ---- the pair probe (sfe_dsp_probe_pair, sfe_dsp_malloc_pair; DESIGN.md 4.2 "the two modes") ----------------------
+// What a pair of allocations gives a kernel that reads one while it writes the other is fixed when the memory is handed
+// out: two classes of allocation, a read stream and a write stream from the same class run ~8 % slower together than a pair
+// from different classes, while each stream alone runs the same in both (measured: profiles/r04/decimate_modes_parts.txt,
+// decimate_modes_pairs.txt).  This kernel is the bare mix, one short-lived workgroup per tile as the bulk kernels launch:
+// sixteen rows of 256 8-byte lanes read (32 KiB), `nw` rows of 256 sixteen-byte lanes written, contiguous.
+__global__ __launch_bounds__(256) void pair_probe_kernel(const v2f *in, v4f *out, int nw)
+{
+    const v2f *p = in + (size_t)blockIdx.x * 4096 + threadIdx.x;
+    v2f v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) v[u] = __builtin_nontemporal_load(p + 256 * u);
+    v2f acc = v[0];
+#pragma unroll
+    for (int u = 1; u < 16; u++) acc += v[u];
+    v4f *q = out + (size_t)blockIdx.x * 256 * nw + threadIdx.x;
+    for (int u = 0; u < nw; u++) __builtin_nontemporal_store((v4f){acc.x, acc.y, v[u & 15].x, v[u & 15].y}, q + 256 * u);
+}
+
+// one launch of the bare mix over (in, out): tiles of 32 KiB read, the output written in proportion (at least one row of
+// 4 KiB per tile, at most 64)
+int launch_pair_probe(const void *in, size_t in_bytes, void *out, size_t out_bytes, hipStream_t s)
+{
+    const size_t tiles = in_bytes / 32768;
+    if (tiles == 0 || out_bytes < 4096) return SFE_OK;
+    size_t nw = out_bytes / tiles / 4096;                     // rows of 4 KiB per tile that fit the output
+    if (nw < 1) nw = 1;
+    if (nw > 64) nw = 64;
+    size_t t = tiles;
+    while (t * nw * 4096 > out_bytes) t--;                     // (an output shorter than one row per tile: fewer tiles)
+    if (t == 0 || t > 0x7fffffffu) return SFE_OK;
+    hipLaunchKernelGGL(pair_probe_kernel, dim3((unsigned)t), dim3(256), 0, s, static_cast<const v2f *>(in), static_cast<v4f *>(out), (int)nw);
+    SFE_HIP(hipGetLastError());
+    return SFE_OK;
+}
+
+
 // median time of the bare read + write mix over the pair (util.hip: pair_probe_kernel), on the null stream
 int probe_pair_ms(const void *d_in, size_t in_bytes, void *d_out, size_t out_bytes, float *ms)
 {
     hipEvent_t e0, e1;
     SFE_HIP(hipEventCreate(&e0));
-    SFE_HIP(hipEventCreate(&e1));
+    if (hipError_t e = hipEventCreate(&e1); e != hipSuccess) {
+        (void)hipEventDestroy(e0);
+        return hip_fail(e, "probe_pair");
+    }
     int rc = SFE_OK;
     float v[5] = {0, 0, 0, 0, 0};
     for (int i = 0; i < 3 && rc == SFE_OK; i++) rc = launch_pair_probe(d_in, in_bytes, d_out, out_bytes, nullptr);
@@ -285,6 +328,7 @@ int build_pair(size_t in_bytes, size_t out_bytes, int tries, void **d_in, void *
             mp.bytes = rest.size() * CHUNK;
             mp.chunks = rest;
             std::lock_guard<std::mutex> lk(g_mu);
+            mp.device = device;
             g_mapped[pp] = mp;
             g_diag_pool = pp;
             g_diag_pool_chunks = rest.size();
@@ -304,6 +348,7 @@ int build_pair(size_t in_bytes, size_t out_bytes, int tries, void **d_in, void *
     mout.bytes = n_out * CHUNK;
     {
         std::lock_guard<std::mutex> lk(g_mu);
+        min.device = mout.device = device;
         g_mapped[pin] = min;
         g_mapped[pout] = mout;
     }
@@ -468,7 +513,6 @@ int sfe_dsp_free(void *dptr)
         auto it = g_mapped.find(dptr);
         if (it != g_mapped.end()) {
             m = it->second;
-            g_mapped.erase(it);
             mapped = true;
         }
     }
@@ -476,7 +520,12 @@ int sfe_dsp_free(void *dptr)
         SFE_HIP(hipFree(dptr));
         return SFE_OK;
     }
+    DeviceGuard guard(m.device);                 // the chunks' own device, whatever is current (group calls switch devices)
     SFE_HIP(hipDeviceSynchronize());             // (hipFree waits for the device by itself; the unmapping does not)
+    {
+        std::lock_guard<std::mutex> lk(g_mu);    // forgotten only once the device is known to be done with it
+        g_mapped.erase(dptr);
+    }
     unmap_range(dptr, m.chunks.size());
     release_chunks(m.chunks);
     return SFE_OK;

@@ -76,6 +76,22 @@ __device__ __forceinline__ void store_group(unsigned char *d, unsigned u0, unsig
     d[4] = (unsigned char)u3;
 }
 
+#ifdef SFE_DIAG
+// In-kernel clock of a launch (MI355X_MICROARCH.md, DVFS give-back item 6): workgroup 0 stamps s_memtime (shader clocks) and
+// s_memrealtime (100 MHz) when it starts and when it leaves; the ratio of the two differences x 100 MHz is the clock the chip
+// held over the launch.  Diagnostic library only (sfe_dsp_diag_fir_clock, scripts/ab_fir.py); the values go nowhere else.
+__device__ unsigned long long g_fir_clk[4];
+#define SFE_FIR_STAMP(i)                                                                   \
+    do {                                                                                   \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                      \
+            g_fir_clk[i] = __builtin_amdgcn_s_memtime();                                   \
+            g_fir_clk[(i) + 1] = __builtin_amdgcn_s_memrealtime();                         \
+        }                                                                                  \
+    } while (0)
+#else
+#define SFE_FIR_STAMP(i) do { } while (0)
+#endif
+
 // WAVES = waves per SIMD the register allocator must fit (3 -> <=168 VGPRs, 2 -> <=256);
 // PREFETCH = request transform i+1's rows during transform i's inverse stages.
 // HREG = keep this thread's 16 bins of H/N in registers (32 VGPRs) instead of re-reading 32 KiB
@@ -132,10 +148,20 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
     // DIAG bit 3 (diagnostic library only, variants y / u): a row is stored as soon as the butterfly of the last DFT16
     // that completes it is done, instead of behind the whole DFT16 (DESIGN.md 9 lead (ii); it spills: see the store section)
     constexpr bool INTERLEAVE = (DIAG & 8) != 0;
+    // DIAG bits 4 and 5 (diagnostic library only, round 5's energy pass): ablations that leave WRONG results and a
+    // true timing / power picture.  Bit 4 (NOMID): the two MIDDLE exchanges (F2 -> F3 and I1 -> I2) neither write nor read the
+    // LDS and their three barriers go -- each thread carries on with its own sixteen values; the arithmetic is untouched.  What a
+    // 64 x 64 decomposition with one exchange per direction could save at most (it would pay cross-lane moves for it).
+    // Bit 5 (NORECON): every twiddle is ONE complex multiply (by q alone) instead of q[a] p[b]: what a resident table of all 15
+    // factors per stage could save at most (it would pay 36 more VGPRs for it).
+    constexpr bool NOMID = (DIAG & 16) != 0, NORECON = (DIAG & 32) != 0;
+    auto tw2f = [](v2f x, v2f q, v2f p) -> v2f { return NORECON ? cmul(x, q) : cmul2(x, q, p); };
+    auto tw2i = [](v2f x, v2f q, v2f p) -> v2f { return NORECON ? cmul_conj(x, q) : cmul2_conj(x, q, p); };
     static_assert(!TICKET || !PREFETCH, "the register prefetch looks ahead by a fixed stride");
     __shared__ v2f lds[WP ? 4 * WP_REGION : FFT_ROWS * LDS_K2_STRIDE];
     __shared__ unsigned s_next;       // TICKET: the next transform drawn by lane 0
     const unsigned t = threadIdx.x;   // unsigned: lets loads/stores use SGPR base + 32-bit VGPR offset
+    SFE_FIR_STAMP(0);
     int ch = TICKET ? 0 : blockIdx.y;
     const unsigned lo = t & 15, hi = t >> 4;
     // LDS cell of element (k2, a, n0), a = n1 or k1:
@@ -440,7 +466,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             v2f x = nx[P16(k)];
-            if ((k >> 2) && (k & 3)) x = cmul2(x, q1[k >> 2], p1[k & 3]);
+            if ((k >> 2) && (k & 3)) x = tw2f(x, q1[k >> 2], p1[k & 3]);
             else if (k >> 2) x = cmul(x, q1[k >> 2]);
             else if (k & 3) x = cmul(x, p1[k & 3]);
             lds[base_a + row_a(k)] = x;
@@ -453,22 +479,28 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 #pragma unroll
         for (int r = 0; r < 16; r++) v[r] = lds[cell_b1(r)];
         dft16<-1>(v);
-        if (!SWZ) lds_barrier();
+        if (NOMID) { }
+        else if (!SWZ) lds_barrier();
         else __builtin_amdgcn_sched_barrier(0);   // keep the stages apart in the scheduler (register pressure)
         fresh_b();
+        v2f wmid[16];                             // NOMID only: what would have gone through the LDS
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             v2f x = v[P16(k)];
-            if ((k >> 2) && (k & 3)) x = cmul2(x, q2[k >> 2], p2[k & 3]);
+            if ((k >> 2) && (k & 3)) x = tw2f(x, q2[k >> 2], p2[k & 3]);
             else if (k >> 2) x = cmul(x, q2[k >> 2]);
             else if (k & 3) x = cmul(x, p2[k & 3]);
-            lds[cell_b2(k)] = x;
+            if constexpr (NOMID) wmid[k] = x;
+            else lds[cell_b2(k)] = x;
         }
-        lds_barrier();
+        if (!NOMID) lds_barrier();
         // ---- F3: gather n0 for (k2=hi, k1=lo); spectrum multiply; first inverse stage
         fresh_c();
 #pragma unroll
-        for (int r = 0; r < 16; r++) v[r] = lds[cell_c(r)];
+        for (int r = 0; r < 16; r++) {
+            if constexpr (NOMID) v[r] = wmid[r];
+            else v[r] = lds[cell_c(r)];
+        }
         dft16<-1>(v);
         {
             // spectrum multiply in place (bin k sits in v[P16(k)]), then the first inverse stage
@@ -480,7 +512,10 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             // I1: element n0 goes back to the cell this thread read n0 from (no barrier needed)
             fresh_c();
 #pragma unroll
-            for (int k = 0; k < 16; k++) lds[cell_c(k)] = v[k];
+            for (int k = 0; k < 16; k++) {
+                if constexpr (NOMID) wmid[k] = v[k];
+                else lds[cell_c(k)] = v[k];
+            }
         }
         // every wave "looks at" the draw here, so that the compiler's wait for the atomic sits HERE on every
         // path: left to the one-lane branch below, the other waves' path keeps it pending and a vmcnt(0)
@@ -511,14 +546,17 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         fresh_b();
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            v2f x = lds[cell_b2(r)];
-            if ((r >> 2) && (r & 3)) x = cmul2_conj(x, q2[r >> 2], p2[r & 3]);
+            v2f x;
+            if constexpr (NOMID) x = wmid[r];
+            else x = lds[cell_b2(r)];
+            if ((r >> 2) && (r & 3)) x = tw2i(x, q2[r >> 2], p2[r & 3]);
             else if (r >> 2) x = cmul_conj(x, q2[r >> 2]);
             else if (r & 3) x = cmul_conj(x, p2[r & 3]);
             v[r] = x;
         }
         dft16<+1>(v);
-        if (!SWZ) lds_barrier();
+        if (NOMID) { }
+        else if (!SWZ) lds_barrier();
         else __builtin_amdgcn_sched_barrier(0);   // keep the stages apart in the scheduler (register pressure)
         fresh_b();
 #pragma unroll
@@ -528,7 +566,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             v2f x = lds[base_a + row_a(r)];
-            if ((r >> 2) && (r & 3)) x = cmul2_conj(x, q1[r >> 2], p1[r & 3]);
+            if ((r >> 2) && (r & 3)) x = tw2i(x, q1[r >> 2], p1[r & 3]);
             else if (r >> 2) x = cmul_conj(x, q1[r >> 2]);
             else if (r & 3) x = cmul_conj(x, p1[r & 3]);
             v[r] = x;
@@ -739,6 +777,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             set_channel(ch);
         }
     }
+    SFE_FIR_STAMP(2);
 }
 
 
@@ -747,6 +786,19 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
 #endif  // SFE_DIAG
 
 }  // namespace
+
+#ifdef SFE_DIAG
+// the clock workgroup 0 of the LAST FIR launch on the current device saw (the caller has synchronised): MHz, and its own span in ms
+extern "C" int sfe_dsp_diag_fir_clock(double *mhz, double *ms)
+{
+    unsigned long long c[4];
+    SFE_HIP(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_fir_clk), sizeof c));
+    const double dr = (double)(c[3] - c[1]);
+    if (mhz) *mhz = dr > 0 ? (double)(c[2] - c[0]) / dr * 100.0 : 0.0;
+    if (ms) *ms = dr / 1e5;
+    return SFE_OK;
+}
+#endif
 
 bool fir_fft_has_variants(const FirFftArgs &a, int in_complex, int out_complex, int in_u8, int out_tx10, int n_channels, int accumulate)
 {

@@ -32,9 +32,6 @@
 #include <stdint.h>
 
 #include <type_traits>
-#ifdef SFE_DIAG
-#include <stdlib.h>
-#endif
 
 #include "common.h"
 #include "fft16.h"
@@ -231,6 +228,7 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
         }
     }
     const int T = idx_base[NC];                  // <= 256 KPT (launcher)
+    if (T == 0) return;                          // uniform: nothing lands here (the block behind a stream that ends on a block seam)
 
     // The table, [output of the block]: the byte address in the exchange buffer of the output's first phase sample << 19 |
     // (cells to its second one: 0 the next phase of the same input sample, 1 / 17 phase 0 of the next one) << 10 | the
@@ -429,10 +427,6 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
 
 }  // namespace
 
-#ifdef SFE_DIAG
-int launch_poly_gen_persistent(const PolyGenArgs &a, int max_runs_two_calls, float step, int n_channels, hipStream_t s, int tickets);
-#endif
-
 int poly_gen_outputs_per_block(int U, int adv, float step)
 {
     // consecutive outputs are >= step (1 - 2^-22) apart on the upsampled grid
@@ -461,14 +455,12 @@ int launch_poly_gen(const PolyGenArgs &a0, int max_runs, float step, int n_chann
         if (a.adv < 512 || poly_gen_outputs_per_block(a.U, per_wg * a.adv, step) > 256 * kpt_max) return SFE_ESTATE;
     }
     if (a.blksize < a.adv) return SFE_ESTATE;                 // a block overlaps at most two reference calls, a pair three
-#ifdef SFE_DIAG
-    // the persistent form with the next block fetched ahead (measured and not kept: diag/poly_gen_persistent.hip)
-    if (const char *e = getenv("SFE_GEN_PERSISTENT"))
-        if (atoi(e) > 0 && !a.real && a.adv == FFT_N - a.ovl) return launch_poly_gen_persistent(a, max_runs, step, n_channels, s, atoi(e) > 1);
-#endif
     const int per_block = poly_gen_outputs_per_block(a.U, per_wg * a.adv, step);
     const long long A = a.adv;
-    const long long nblk = ((a.n_in + A - 1) / A + per_wg - 1) / per_wg;
+    // block b owns the outputs whose first sample n = floor(P / U) lies in [b A - 1, (b + 1) A - 1): sample n_in - 1, which the
+    // reference still emits from while its phase leaves a successor (resample.cxx:137-146), belongs to block floor(n_in / A) --
+    // one MORE than ceil(n_in / A) blocks when n_in is a multiple of A (that output was never stored)
+    const long long nblk = (a.n_in / A + 1 + per_wg - 1) / per_wg;
     if (nblk > 0x7fffffffLL) return SFE_ESTATE;
     dim3 grid((unsigned)nblk, (unsigned)n_channels), block(256);
     const int kpt = (per_block + 255) / 256;

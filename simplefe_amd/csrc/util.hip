@@ -156,40 +156,4 @@ int launch_tx_f32_to_10bit(const float *src, uint8_t *dst, size_t n_floats, hipS
     return SFE_OK;
 }
 
-// ---- the pair probe (sfe_dsp_probe_pair, sfe_dsp_malloc_pair; DESIGN.md 4.2 "the two modes") ----------------------
-// What a pair of allocations gives a kernel that reads one while it writes the other is fixed when the memory is handed
-// out: two classes of allocation, a read stream and a write stream from the same class run ~8 % slower together than a pair
-// from different classes, while each stream alone runs the same in both (measured: profiles/r04/decimate_modes_parts.txt,
-// decimate_modes_pairs.txt).  This kernel is the bare mix, one short-lived workgroup per tile as the bulk kernels launch:
-// sixteen rows of 256 8-byte lanes read (32 KiB), `nw` rows of 256 sixteen-byte lanes written, contiguous.
-__global__ __launch_bounds__(256) void pair_probe_kernel(const v2f *in, v4f *out, int nw)
-{
-    const v2f *p = in + (size_t)blockIdx.x * 4096 + threadIdx.x;
-    v2f v[16];
-#pragma unroll
-    for (int u = 0; u < 16; u++) v[u] = __builtin_nontemporal_load(p + 256 * u);
-    v2f acc = v[0];
-#pragma unroll
-    for (int u = 1; u < 16; u++) acc += v[u];
-    v4f *q = out + (size_t)blockIdx.x * 256 * nw + threadIdx.x;
-    for (int u = 0; u < nw; u++) __builtin_nontemporal_store((v4f){acc.x, acc.y, v[u & 15].x, v[u & 15].y}, q + 256 * u);
-}
-
-// one launch of the bare mix over (in, out): tiles of 32 KiB read, the output written in proportion (at least one row of
-// 4 KiB per tile, at most 64)
-int launch_pair_probe(const void *in, size_t in_bytes, void *out, size_t out_bytes, hipStream_t s)
-{
-    const size_t tiles = in_bytes / 32768;
-    if (tiles == 0 || out_bytes < 4096) return SFE_OK;
-    size_t nw = out_bytes / tiles / 4096;                     // rows of 4 KiB per tile that fit the output
-    if (nw < 1) nw = 1;
-    if (nw > 64) nw = 64;
-    size_t t = tiles;
-    while (t * nw * 4096 > out_bytes) t--;                     // (an output shorter than one row per tile: fewer tiles)
-    if (t == 0 || t > 0x7fffffffu) return SFE_OK;
-    hipLaunchKernelGGL(pair_probe_kernel, dim3((unsigned)t), dim3(256), 0, s, static_cast<const v2f *>(in), static_cast<v4f *>(out), (int)nw);
-    SFE_HIP(hipGetLastError());
-    return SFE_OK;
-}
-
 }  // namespace sfe

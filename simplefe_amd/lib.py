@@ -36,10 +36,6 @@ SIGNATURES = {
     "sfe_dsp_sync": (i32, [vp]),
     "sfe_dsp_malloc": (i32, [C.POINTER(vp), sz]),
     "sfe_dsp_free": (i32, [vp]),
-    "sfe_dsp_probe_pair": (i32, [vp, sz, vp, sz, C.POINTER(C.c_float)]),
-    "sfe_dsp_malloc_pair": (i32, [sz, sz, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
-    "sfe_dsp_malloc_pair_screened": (i32, [sz, sz, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
-    "sfe_dsp_mem_kind": (i32, [vp, C.POINTER(C.c_int)]),
     "sfe_dsp_host_alloc": (i32, [C.POINTER(vp), sz]),
     "sfe_dsp_host_free": (i32, [vp]),
     "sfe_dsp_memcpy_h2d": (i32, [vp, vp, sz, vp]),
@@ -111,6 +107,14 @@ SIGNATURES = {
     "sfe_dsp_tx_f32_to_10bit": (i32, [vp, vp, sz, vp]),
 }
 
+# the diagnostic library only (simplefe_amd/csrc/diag/sfe_dsp_diag.h; scripts/ load it by pointing LIB_PATH at it): bound when present
+DIAG_SIGNATURES = {
+    "sfe_dsp_probe_pair": (i32, [vp, sz, vp, sz, C.POINTER(C.c_float)]),
+    "sfe_dsp_malloc_pair": (i32, [sz, sz, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "sfe_dsp_malloc_pair_screened": (i32, [sz, sz, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "sfe_dsp_mem_kind": (i32, [vp, C.POINTER(C.c_int)]),
+}
+
 _lib = None
 
 
@@ -128,6 +132,11 @@ def load():
         fn = getattr(L, name)          # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in DIAG_SIGNATURES.items():
+        fn = getattr(L, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     _lib = L
     return L
 

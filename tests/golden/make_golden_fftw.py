@@ -59,14 +59,14 @@ def main():
     out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden", "g7_blkconv_fftw.npz")
     ver = orc.RefBlkconvFFTW.fftw_version()
     if ver is None:
-        raise SystemExit("oracle/_ref/libsferef_blkconv_fftw.so is not usable here (no /root/reference?)")
+        raise SystemExit("the FFTW-pinned reference is not usable here (no /root/reference, or SFE_ORACLE_RUN_FFTW_DLL=1 not set)")
     print("FFTW binary reports:", ver)
     g = {}
     print(f"{'case':8s} {'taps':>5s} {'fft':>5s} {'port~FFTW':>10s} {'hipFFTW~FFTW':>13s} {'FFTW~f64':>10s} {'port~f64':>10s} {'hipFFTW~f64':>12s}")
     for name, taps, fft_len, x, y_hip in cases():
-        r = orc.RefBlkconvFFTW(taps, fft_len)
-        assert r.blk == fft_len + 1 - len(taps) and len(x) % r.blk == 0
-        y = orc.RefBlkconv.stream(r, x)             # block by block through the process buffer
+        r = orc.RefBlkconvFFTW(taps, fft_len)       # (round 5: runs in a child process, opt-in: SFE_ORACLE_RUN_FFTW_DLL=1)
+        assert len(x) % (fft_len + 1 - len(taps)) == 0
+        y = r.stream_blocks(x)                      # block by block through the process buffer
         assert np.array_equal(y, orc.RefBlkconvFFTW(taps, fft_len).stream(x))
         g.update({f"{name}_taps": taps, f"{name}_fft_len": fft_len, f"{name}_x": x, f"{name}_y": y})
         o = orc.Blkconv(taps, fft_len).stream(x)

@@ -76,9 +76,13 @@ def test_bench_gpus4_rehearsal_and_the_single_process_group_form():
                     env_extra={"SFE_BENCH_ONE_DEVICE": "1"})
     assert r1.returncode == 0, r1.stdout + r1.stderr
     assert j1["n_gpus"] == 8 and j1["parity"]["ok"] and len(j1["config"]["shards"]) == 8
+    # ... and ONE handle over all 64 channels on the one device: the partition into 4 ranks or 8 blocks changes nothing
+    r0, j0 = _bench("--gpus", "1", "--log2n", "24", "--channels", "64", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-others")
+    assert r0.returncode == 0, r0.stdout + r0.stderr
     for k in ("sum_re", "sum_im", "sum_abs2"):
-        a, b = j1["checksum"][k], j4["checksum"][k]
+        a, b, c = j1["checksum"][k], j4["checksum"][k], j0["checksum"][k]
         assert abs(a - b) <= 1e-9 * max(1.0, abs(a)), (k, a, b)
+        assert abs(a - c) <= 1e-9 * max(1.0, abs(a)), (k, a, c)
 
 
 def test_bench_gpus2_default_shape_carries_the_weak_row():
@@ -111,5 +115,10 @@ def test_bench_default_line_small():
     rf = j["roofline"]
     assert rf["kernel_ms_min"] <= rf["kernel_ms_median"] <= rf["kernel_ms_max"] and rf["kernel_ms_std"] >= 0
     assert rf["traffic"] is None or not rf.get("traffic_stale")      # never stale bytes
+    # round 5: plain allocations, nothing selected on the measured quantity; the input verified before and after the timed steps
+    assert j["config"]["buffers"].startswith("plain allocations")
+    assert j["parity"]["input_is_the_synthetic_stream"] is True and j["parity"]["input_checked"] == "before and after the timed steps"
+    for row in j.get("other_configs", []):
+        assert "error" in row or "buffers" not in row
     cb = j["cpu_baseline"]
     assert cb["cores"] == 1 and cb["all_cores"]["cores"] == cb["host_cores"] >= 1

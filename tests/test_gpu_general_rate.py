@@ -153,3 +153,32 @@ def test_transform_domain_general_rate_u8_input(api, L, orc, cplx, rate):
         ref, _ = orc.Resample(taps, U, B).stream(np.ascontiguousarray(xf[part::w]), rate)
         got = outs["u8"][part::w]
         assert len(ref) - len(got) in (0, 1) and synth.rel_rms(got, ref[: len(got)]) <= TOL
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+@pytest.mark.parametrize("k", [1, 2, 3, 8, 31, 32, 33, 64])
+def test_stream_that_ends_on_a_block_seam(api, L, k, cplx):
+    """input sample n_in - 1 belongs to block floor(n_in / adv) -- one more block than ceil(n_in / adv) when the
+    call's length is a multiple of the block advance (a real stream: an even multiple, two blocks per transform).  The
+    reference still emits an output whose first sample is the call's last one while its phase leaves a successor
+    (libdsp/resample.cxx:137-146); the launch was one workgroup short and that output was never stored.  Shape: BASELINE cfg3's
+    381 taps in 3 phases (overlap 128, advance 3968) at rate 1.77; k = 32 is the advisor's own hit (last output at sample
+    4095, phase 1 of the 31st call).  Count AND values against the exact kernel, the output buffer poisoned first."""
+    taps, U, B = synth.taps_cfg3(), 3, 4096
+    rate = float(np.float32(1.77))
+    adv = 4096 - 128
+    n = k * adv * (1 if cplx else 2)
+    w = 2 if cplx else 1
+    x = (synth.synth_cf32 if cplx else synth.synth_f32)(n, ch=900 + k)
+    exact, fast = _pair(api, L, taps, U, B, cplx=cplx)
+    d_in = api.DeviceArray.from_numpy(x)
+    cap = int(n / rate) + 16 + 2 * (n // B + 1)
+    poison = np.full(w * cap, 7.0e7, dtype=np.float32)
+    de, df = api.DeviceArray.from_numpy(poison), api.DeviceArray.from_numpy(poison)
+    ke = exact.process_stream(d_in, n, de, cap, rate)
+    kf = fast.process_stream(d_in, n, df, cap, rate)
+    assert ke == kf and ke > 0
+    ye, yf = de.to_numpy()[: w * ke], df.to_numpy()[: w * kf]
+    assert np.abs(yf).max() < 1.0e6, "an output of the call was never stored"
+    assert synth.rel_rms(yf, ye) <= TOL
+    assert np.abs(yf[-w:] - ye[-w:]).max() <= 2e-5 * max(1.0, float(np.abs(ye).max()))

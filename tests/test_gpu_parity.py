@@ -1260,27 +1260,6 @@ def test_stream_entry_points_reject_bad_buffers(api, L):
     api.sync()
 
 
-def test_malloc_pair_and_probe_pair(L):
-    """sfe_dsp_malloc_pair / sfe_dsp_probe_pair (include/sfe_dsp.h): a pair of buffers screened for the read + write
-    interaction of DESIGN.md 4.2.  The kept candidate is the fastest of those probed; bad arguments are refused."""
-    import ctypes as C
-    lib = L.load()
-    d_in, d_out, kept, worst = C.c_void_p(), C.c_void_p(), C.c_float(), C.c_float()
-    rc = lib.sfe_dsp_malloc_pair(1 << 28, 1 << 25, 4, C.byref(d_in), C.byref(d_out), C.byref(kept), C.byref(worst))
-    assert rc == 0 and d_in.value and d_out.value
-    assert 0.0 < kept.value <= worst.value
-    ms = C.c_float()
-    assert lib.sfe_dsp_probe_pair(d_in, 1 << 28, d_out, 1 << 25, C.byref(ms)) == 0 and ms.value > 0.0
-    # 256 MiB read + 32 MiB written cannot take longer than a millisecond on this device (~0.05 ms at 6 TB/s)
-    assert ms.value < 1.0
-    assert lib.sfe_dsp_probe_pair(d_in, 100, d_out, 1 << 25, C.byref(ms)) != 0            # too short to probe
-    assert lib.sfe_dsp_malloc_pair(1 << 20, 1 << 20, 0, C.byref(d_in), C.byref(d_out), None, None) != 0
-    assert lib.sfe_dsp_free(d_in) == 0 and lib.sfe_dsp_free(d_out) == 0
-    # tries = 1, tiny sizes: two plain allocations, nothing probed
-    assert lib.sfe_dsp_malloc_pair(64, 64, 1, C.byref(d_in), C.byref(d_out), C.byref(kept), None) == 0
-    assert lib.sfe_dsp_free(d_in) == 0 and lib.sfe_dsp_free(d_out) == 0
-
-
 def test_fir_per_channel_taps_ticket_groups_by_channel(api, L):
     """Sixteen channels (a multiple of the eight ticket groups) with more transforms than resident workgroups: the launch
     deals each group whole channels (FirFftArgs::ch_groups, DESIGN.md 4.1) -- every channel against a single-channel handle
@@ -1301,57 +1280,3 @@ def test_fir_per_channel_taps_ticket_groups_by_channel(api, L):
         a = one.filter(x[c, : 2 * cut])[0]
         b = one.filter(x[c, 2 * cut:])[0]
         assert np.array_equal(y[c], np.concatenate([a, b])), c
-
-
-def test_malloc_pair_holds_what_is_written_at_once(L):
-    """Round 4's find (profiles/r04/fir_modes_input.txt, blocks 19-21): a kernel launched straight after chunks are mapped into a
-    range reserved moments after a larger one was given back could find most of the range not backed yet -- stores dropped,
-    loads zero, no fault; the library now waits until the mapping holds a mark before it hands the buffers out.  Twice in one
-    process (the second build re-uses the addresses the first gave back): fill the input AT ONCE, then read 64 windows back."""
-    import ctypes as C
-    from simplefe_amd import synth
-    lib = L.load()
-    n = 1 << 28
-    for _ in range(2):
-        d_in, d_out = C.c_void_p(), C.c_void_p()
-        assert lib.sfe_dsp_malloc_pair(n * 8, n * 8, 4, C.byref(d_in), C.byref(d_out), None, None) == 0
-        assert lib.sfe_dsp_synth_fill(d_in, 2 * n, synth.SEED, 0, 0, None) == 0
-        got = np.empty(4096, np.float32)
-        for k in range(64):
-            pos = ((2 * n - 4096) * k // 63) & ~1
-            assert lib.sfe_dsp_memcpy_d2h(got.ctypes.data, C.c_void_p(d_in.value + 4 * pos), got.nbytes, None) == 0
-            assert lib.sfe_dsp_sync(None) == 0
-            assert np.array_equal(got, synth.synth_f32(4096, synth.SEED, 0, first=pos)), "window %d of the input lost its data" % k
-        assert lib.sfe_dsp_free(d_in) == 0 and lib.sfe_dsp_free(d_out) == 0
-
-
-def test_malloc_pair_builds_a_pair_from_chunks(L):
-    """Streams of a GiB and more: sfe_dsp_malloc_pair builds the pair from 1 GiB physical chunks mapped into two contiguous
-    ranges (or falls back to screening plain allocations).  Either way the memory is ordinary device memory -- the library's
-    own calls and kernels work on it across chunk boundaries -- and sfe_dsp_free releases it."""
-    import ctypes as C
-    lib = L.load()
-    d_in, d_out, kept, worst = C.c_void_p(), C.c_void_p(), C.c_float(), C.c_float()
-    n_in, n_out = (2 << 30) + 4096, (1 << 30) + (1 << 20)     # not whole chunks
-    assert lib.sfe_dsp_malloc_pair(n_in, n_out, 2, C.byref(d_in), C.byref(d_out), C.byref(kept), C.byref(worst)) == 0
-    assert d_in.value and d_out.value and kept.value > 0.0
-    # a stream call that crosses a chunk boundary of both buffers: synth fill, FIR, read back
-    from simplefe_amd import api, synth
-    n = (n_in // 8) & ~1
-    assert lib.sfe_dsp_synth_fill(d_in, 2 * n, synth.SEED, 0, 0, None) == 0
-    m = min(n, n_out // 8)
-    f = api.Fir(synth.taps_cfg2(), data_complex=True)
-    f.process_stream(d_in.value, d_out.value, m)
-    ref_in, ref_out = api.DeviceArray(2 * m), api.DeviceArray(2 * m)
-    ref_in.fill_synth(synth.SEED)
-    g = api.Fir(synth.taps_cfg2(), data_complex=True)
-    g.process_stream(ref_in, ref_out, m)
-    api.sync()
-    lo = (1 << 30) // 8 - 2048                               # a window across the output's first chunk boundary
-    got = np.empty(8192, np.float32)
-    assert lib.sfe_dsp_memcpy_d2h(got.ctypes.data, C.c_void_p(d_out.value + 8 * lo), got.nbytes, None) == 0
-    api.sync()
-    assert np.array_equal(got, ref_out.to_numpy(8192, offset=2 * lo))
-    kind = C.c_int(-1)
-    assert lib.sfe_dsp_mem_kind(d_out, C.byref(kind)) == 0 and kind.value in (0, 1)          # built, or the screened fallback
-    assert lib.sfe_dsp_free(d_in) == 0 and lib.sfe_dsp_free(d_out) == 0
