@@ -61,6 +61,10 @@ def lib():
             getattr(L, f"orc_{k}_create").argtypes = [_f32p, C.c_int, C.c_int, C.c_int]
             getattr(L, f"orc_{k}_process").argtypes = [C.c_void_p, _f32p, C.c_int, _f32p, C.c_int, C.c_float]
             getattr(L, f"orc_{k}_destroy").argtypes = [C.c_void_p]
+        L.orc_resample_skip_calls.restype = C.c_long
+        L.orc_resample_skip_calls.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_float]
+        L.orc_resample_get_time.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        L.orc_resample_set_time.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int]
         L.orc_blkconv_stream_mt.restype = C.c_long
         L.orc_blkconv_stream_mt.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_void_p, C.c_long, C.c_int]
         L.orc_rs_stream_mt.restype = C.c_long
@@ -293,6 +297,24 @@ class _Rs:
 
 class Resample(_Rs):
     _prefix = "orc_resample"
+
+    def skip_calls(self, n_calls, n_in, rate):
+        """The time law of n_calls process() calls of n_in samples each, without their samples (sfe_oracle.c:
+        orc_resample_skip_calls): the state (pos, mu, leftover) the reference's object would hold after them.  Returns how many
+        outputs those calls emit.  Run one REAL call before checking values (history, m_last_remain)."""
+        k = self._L.orc_resample_skip_calls(self._h, int(n_calls), int(n_in), float(rate))
+        if k < 0:
+            raise ValueError("skip_calls: n_in / rate outside what process() takes")
+        return int(k)
+
+    def get_time(self):
+        """(m_pos, m_mu, m_is_leftover)"""
+        p, m, l = C.c_int(), C.c_float(), C.c_int()
+        self._L.orc_resample_get_time(self._h, C.byref(p), C.byref(m), C.byref(l))
+        return p.value, m.value, l.value
+
+    def set_time(self, state):
+        self._L.orc_resample_set_time(self._h, int(state[0]), float(state[1]), int(state[2]))
 
 
 class Decimate(_Rs):

@@ -392,6 +392,37 @@ int orc_resample_process(orc_resample *r, const float *in, int n_in, float *out,
     return timelaw_run(&r->tl, r->U, n_in, out, out_len, rate, resample_pick, r);
 }
 
+/* Test helper (tests/test_gpu_fullsize.py: parity windows deep inside a 2^28-sample stream at a general rate): the time law of
+ * `n_calls` consecutive process() calls of `n_in` samples each, WITHOUT their samples -- the same timelaw_run (resample.cxx:119-150)
+ * picking zeros -- so that (m_pos, m_mu, m_is_leftover) arrive where the reference's would after those calls; the float32
+ * recurrence has no closed form, it has to be walked.  Returns the number of outputs those calls emit.  The history and
+ * m_last_remain are NOT those of the stream: the caller runs one real call before the window it checks. */
+static float zero_pick(void *self, int phase, int n) { (void)self; (void)phase; (void)n; return 0.0f; }
+long orc_resample_skip_calls(orc_resample *r, long n_calls, int n_in, float rate)
+{
+    if (n_in > r->blksize || rate < 1.0 / r->U || n_in < 1) return -1;
+    const int cap = (int)((double)n_in * r->U) + 8;                  /* step >= 1: at most n_in U outputs per call */
+    float *scratch = (float *)malloc(sizeof(float) * (size_t)cap);
+    long total = 0;
+    for (long c = 0; c < n_calls; c++) total += timelaw_run(&r->tl, r->U, n_in, scratch, cap, rate, zero_pick, NULL);
+    free(scratch);
+    return total;
+}
+
+/* test helpers: the time state alone (m_pos, m_mu, m_is_leftover), so that one walked object can hand its place to fresh ones */
+void orc_resample_get_time(const orc_resample *r, int *pos, float *mu, int *leftover)
+{
+    *pos = r->tl.pos;
+    *mu = r->tl.mu;
+    *leftover = r->tl.leftover;
+}
+void orc_resample_set_time(orc_resample *r, int pos, float mu, int leftover)
+{
+    r->tl.pos = pos;
+    r->tl.mu = mu;
+    r->tl.leftover = leftover;
+}
+
 void orc_resample_destroy(orc_resample *r)
 {
     if (!r) return;

@@ -43,6 +43,10 @@ typedef struct orc_resample orc_resample;
 orc_resample *orc_resample_create(const float *taps, int n_taps, int upsample, int blksize);
 int           orc_resample_process(orc_resample *r, const float *in, int n_in,
                                    float *out, int out_len, float rate);
+/* test helper: the time law of n_calls calls of n_in samples without their samples; returns the outputs they emit */
+long          orc_resample_skip_calls(orc_resample *r, long n_calls, int n_in, float rate);
+void          orc_resample_get_time(const orc_resample *r, int *pos, float *mu, int *leftover);
+void          orc_resample_set_time(orc_resample *r, int pos, float mu, int leftover);
 void          orc_resample_destroy(orc_resample *r);
 
 /* ---- decimate : libdsp/decimate.h:33-63, libdsp/decimate.cxx:37-140 ----------- */

@@ -92,6 +92,34 @@ def test_against_live_reference_random(orc):
     assert na == nb and np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("rate", [1.77, 0.77, 2.5, 1.0009])
+def test_time_law_skip_lands_where_the_reference_is(orc, g4, rate):
+    """orc_resample_skip_calls (the helper the full-size general-rate windows restart the oracle with, tests/test_gpu_fullsize.py):
+    after the time law of c calls WITHOUT samples and ONE real call, every further call's outputs -- values and count -- are
+    bit for bit those of the reference's own class run over the whole stream (oracle/_ref when present, else the restatement
+    run in full); and the outputs skipped are as many as the reference emitted.  Several cuts, the reference driver's own
+    shape (libdsp/test/test_decimate.py:10-17: 31 taps, U = 4, blksize 128) and BASELINE cfg3's."""
+    rate = float(np.float32(rate))
+    full_cls = orc.RefResample if orc.ref_lib() is not None else orc.Resample
+    for taps, U, B, calls in ((g4["taps"], int(g4["U"]), 128, 60), (synth.taps_cfg3(), 3, 512, 24)):
+        x = synth.synth_f32(calls * B, ch=31)
+        ol = int(B / rate) + 8
+        full = full_cls(taps, U, B)
+        per_call = [full.process(x[c * B:(c + 1) * B], ol, rate) for c in range(calls)]
+        plen = (len(taps) + U - 1) // U
+        for cut in (1, 7, calls // 2, calls - 3):
+            if (cut + 1) * B < plen + 2:
+                continue                                  # the one real call must refill the whole history
+            o = orc.Resample(taps, U, B)
+            skipped = o.skip_calls(cut, B, rate)
+            assert skipped == sum(n for n, _ in per_call[:cut]), (rate, cut)
+            n, _ = o.process(x[cut * B:(cut + 1) * B], ol, rate)             # history and m_last_remain: values not compared
+            assert n == per_call[cut][0]
+            for c in range(cut + 1, calls):
+                n, y = o.process(x[c * B:(c + 1) * B], ol, rate)
+                assert n == per_call[c][0] and np.array_equal(y[:n], per_call[c][1][:n]), (rate, cut, c)
+
+
 # ------------------------------------------------------------------------- blkconv
 def test_blkconv_known_answer(orc, g1):
     """libdsp/test/test_blkconv.cxx:5-33: boxcar(5), fft 32 -> blksize 28; ones then zeros."""
