@@ -173,37 +173,36 @@ public:
                          gr::io_signature::make(n_channels, n_channels, sizeof(gr_complex))),
           d_g(0), d_max(max_items > 0 ? max_items : 65536)
     {
-        check(sfe_dsp_fir_group_create(taps.data(), (int)taps.size(), 0, 1, 0, n_channels, devices.data(), (int)devices.size(), &d_g),
-              "fir_bank_ccf_sync");
-        int n = 0, home = 0;
-        check(sfe_dsp_fir_group_shards(d_g, &n), "fir_bank_ccf_sync");
+        // (a check() that throws part-way leaves a half-built object whose destructor never runs -- everything
+        // acquired so far is released here and the caller's current device put back before the exception goes on)
+        int home = 0;
         sfe_dsp_get_device(&home);
-        d_sh.resize(n);
-        d_in.assign(n, (void *)0);
-        d_out.assign(n, (void *)0);
-        for (int k = 0; k < n; k++) {
-            part &s = d_sh[k];
-            check(sfe_dsp_fir_group_shard(d_g, k, &s.device, &s.first, &s.count, 0, &s.stream), "fir_bank_ccf_sync");
-            const size_t bytes = (size_t)s.count * d_max * sizeof(gr_complex);
-            check(sfe_dsp_set_device(s.device), "fir_bank_ccf_sync");
-            check(sfe_dsp_malloc(&d_in[k], bytes), "fir_bank_ccf_sync");
-            check(sfe_dsp_malloc(&d_out[k], bytes), "fir_bank_ccf_sync");
-            check(sfe_dsp_host_alloc(&s.h_in, bytes), "fir_bank_ccf_sync");
-            check(sfe_dsp_host_alloc(&s.h_out, bytes), "fir_bank_ccf_sync");
+        try {
+            check(sfe_dsp_fir_group_create(taps.data(), (int)taps.size(), 0, 1, 0, n_channels, devices.data(), (int)devices.size(), &d_g),
+                  "fir_bank_ccf_sync");
+            int n = 0;
+            check(sfe_dsp_fir_group_shards(d_g, &n), "fir_bank_ccf_sync");
+            d_sh.resize(n);
+            d_in.assign(n, (void *)0);
+            d_out.assign(n, (void *)0);
+            for (int k = 0; k < n; k++) {
+                part &s = d_sh[k];
+                check(sfe_dsp_fir_group_shard(d_g, k, &s.device, &s.first, &s.count, 0, &s.stream), "fir_bank_ccf_sync");
+                const size_t bytes = (size_t)s.count * d_max * sizeof(gr_complex);
+                check(sfe_dsp_set_device(s.device), "fir_bank_ccf_sync");
+                check(sfe_dsp_malloc(&d_in[k], bytes), "fir_bank_ccf_sync");
+                check(sfe_dsp_malloc(&d_out[k], bytes), "fir_bank_ccf_sync");
+                check(sfe_dsp_host_alloc(&s.h_in, bytes), "fir_bank_ccf_sync");
+                check(sfe_dsp_host_alloc(&s.h_out, bytes), "fir_bank_ccf_sync");
+            }
+        } catch (...) {
+            release();
+            sfe_dsp_set_device(home);
+            throw;
         }
         sfe_dsp_set_device(home);
     }
-    ~fir_bank_ccf_sync_impl()
-    {
-        if (d_g) sfe_dsp_fir_group_sync(d_g);
-        for (size_t k = 0; k < d_sh.size(); k++) {
-            if (d_in[k]) sfe_dsp_free(d_in[k]);
-            if (d_out[k]) sfe_dsp_free(d_out[k]);
-            if (d_sh[k].h_in) sfe_dsp_host_free(d_sh[k].h_in);
-            if (d_sh[k].h_out) sfe_dsp_host_free(d_sh[k].h_out);
-        }
-        sfe_dsp_fir_group_destroy(d_g);
-    }
+    ~fir_bank_ccf_sync_impl() { release(); }
 
     int work(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &output_items)
     {
@@ -234,6 +233,26 @@ private:
         void *h_in, *h_out;
         part() : device(0), first(0), count(0), stream(0), h_in(0), h_out(0) {}
     };
+    // gives back whatever has been acquired (each device's memory with that device current); safe on a half-built object
+    void release()
+    {
+        int home = 0;
+        sfe_dsp_get_device(&home);
+        if (d_g) sfe_dsp_fir_group_sync(d_g);
+        for (size_t k = 0; k < d_sh.size(); k++) {
+            sfe_dsp_set_device(d_sh[k].device);
+            if (k < d_in.size() && d_in[k]) sfe_dsp_free(d_in[k]);
+            if (k < d_out.size() && d_out[k]) sfe_dsp_free(d_out[k]);
+            if (d_sh[k].h_in) sfe_dsp_host_free(d_sh[k].h_in);
+            if (d_sh[k].h_out) sfe_dsp_host_free(d_sh[k].h_out);
+        }
+        d_sh.clear();
+        d_in.clear();
+        d_out.clear();
+        if (d_g) sfe_dsp_fir_group_destroy(d_g);
+        d_g = 0;
+        sfe_dsp_set_device(home);
+    }
     sfe_fir_group_t d_g;
     int d_max;
     std::vector<part> d_sh;

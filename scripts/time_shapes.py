@@ -3,7 +3,9 @@
 interpolating ratio (UP > SP -- what `resample` can do and `decimate` cannot, libdsp/resample.cxx:91 against
 libdsp/decimate.cxx:75-78) and decimations the tables skip.  2^28 cf32 samples in (LOG2N), prototypes of
 32 * U taps (32 per polyphase arm), the product library's default dispatch; HIP events on the launch stream,
-median of 9 x 3 launches; the output buffer screened as bench.py's are (SCREEN=1: the first allocation).  frac = algorithmic bytes (8 B per input + 8 B per output) / time / 8 TB/s; the bar
+median of 9 x 3 launches, plain allocations.  BARE=1 (round 5; loads the DIAGNOSTIC library, which holds sfe_dsp_probe_pair): beside
+each row the bare read : write mix of the shape -- 32 KiB read per workgroup, the output written in proportion, nothing
+computed -- as time, as `frac`, and the kernel's time as a share of it.  frac = algorithmic bytes (8 B per input + 8 B per output) / time / 8 TB/s; the bar
 north_star sets is 0.40.  Also checked here: the fused result against the float64 definition on a window.
 
     python scripts/time_shapes.py > profiles/r04/shapes.txt
@@ -14,9 +16,12 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from simplefe_amd import lib  # noqa: E402
+from simplefe_amd import build, lib  # noqa: E402
 if os.environ.get("SFE_LIB"):
     lib.LIB_PATH = os.environ["SFE_LIB"]
+BARE = os.environ.get("BARE") == "1"
+if BARE:
+    lib.LIB_PATH = build.build_lib(diag=True)      # the same kernels; the diagnostic library adds the bare-mix probe
 from simplefe_amd import api, synth  # noqa: E402
 
 log2n = int(os.environ.get("LOG2N", "28"))
@@ -33,26 +38,19 @@ x = api.DeviceArray(2 * n)
 x.fill_synth(synth.SEED)
 t = api.Timer()
 print(f"# 2^{log2n} cf32 in, 32 taps per polyphase arm; kernel = what the default dispatch ran; exact = the bit-exact mode's time")
-print(f"{'shape':28s} {'U':>2s} {'step':>4s} {'out/in':>7s} {'ms':>8s} {'GB':>6s} {'frac':>6s} {'exact ms':>9s} {'rel-RMS vs f64':>15s}")
+print(f"{'shape':28s} {'U':>2s} {'step':>4s} {'out/in':>7s} {'ms':>8s} {'GB':>6s} {'frac':>6s} {'exact ms':>9s} {'rel-RMS vs f64':>15s}" + ("   bare mix ms / frac / kernel as a share of it" if BARE else ""))
 for name, U, step in SHAPES:
     rate = float(np.float32(step) / np.float32(U))
     assert float(np.float32(rate) * np.float32(U)) == float(step), (name, "step must be exact in float32")
     taps = synth.lowpass_taps(32 * U, 0.9 * min(1.0 / U, 1.0 / step), gain=float(U))
     cap = n * U // step + 64
-    # the output buffer: the fastest of four candidates against the input in the library's bare read + write mix (what a PAIR
-    # of allocations gives a streaming kernel is fixed when the memory is handed out; bench.py does the same)
     import ctypes as C
-    cands, probe = [], []
-    for _ in range(int(os.environ.get("SCREEN", "4"))):
-        c = api.DeviceArray(2 * cap)
+    y = api.DeviceArray(2 * cap)
+    bare = None
+    if BARE and step <= 8 * U:              # (the probe writes at least one 4 KiB row per 32 KiB read: ratios beyond 8 : 1 are not its to give)
         ms = C.c_float(0.0)
-        api.check(lib.load().sfe_dsp_probe_pair(x.ptr, 8 * n, c.ptr, 8 * cap, C.byref(ms)))
-        cands.append(c)
-        probe.append(ms.value)
-    y = cands[int(np.argmin(probe))]
-    for c in cands:
-        if c is not y:
-            c.free()
+        api.check(lib.load().sfe_dsp_probe_pair(x.ptr, 8 * n, y.ptr, 8 * (n * U // step), C.byref(ms)))
+        bare = float(ms.value)
     res = {}
     for exact in (False, True, "direct", "fft"):
         r = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=True)
@@ -88,5 +86,6 @@ for name, U, step in SHAPES:
             err = float(np.sqrt(np.sum(np.abs((got[0::2] + 1j * got[1::2]) - ref) ** 2) / np.sum(np.abs(ref) ** 2)))
         r.close()
     gb = 8.0 * (n + k) / 1e9
-    print(f"{name:28s} {U:2d} {step:4d} {k / n:7.4f} {res[False]:8.4f} {gb:6.2f} {gb / res[False] / 8.0:6.3f} {res[True]:9.4f} {err:15.2e}   direct {res['direct']:.4f}  transform (where instantiated) {res['fft']:.4f}", flush=True)
+    tail = f"   bare {bare:.4f} / {gb / bare / 8.0:.3f} / {100.0 * bare / res[False]:.0f} %" if bare else ""
+    print(f"{name:28s} {U:2d} {step:4d} {k / n:7.4f} {res[False]:8.4f} {gb:6.2f} {gb / res[False] / 8.0:6.3f} {res[True]:9.4f} {err:15.2e}   direct {res['direct']:.4f}  transform (where instantiated) {res['fft']:.4f}{tail}", flush=True)
     y.free()

@@ -238,6 +238,15 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
     // its own (pieces hold one to a few runs, except where a call starts: there a dozen binades pass in as many outputs).
     // Round 4's first version searched and walked per output, with 64-bit positions: 850 of the block's 2 900 vector
     // instructions per wave.
+    // (round 5) Slots behind the block's last output hold an entry that matches no phase -- cell 0, both phase fields 31 (the
+    // launcher takes U <= 31, so a real phase is at most 30) -- so that the shares loop of step 2 runs without a guard and
+    // without a branch per output.
+#pragma unroll
+    for (int q = 0; q < KPT; q++)
+        if ((int)t + 256 * q >= T) {
+            tab_pos[256 * q + t] = 31u | (31u << 5);
+            tab_mu[256 * q + t] = 0.0f;
+        }
     const unsigned Uu = (unsigned)U, Minv = Uu > 1u ? 0xFFFFFFFFu / Uu + 1u : 0u;      // floor(x / U) = mulhi(x, Minv), x < 2 U A
     const unsigned e0 = (unsigned)a.ovl - 1u;    // transform element of a block's first owned input sample
 #pragma unroll
@@ -387,35 +396,30 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
 #pragma unroll
         for (int r = 0; r < 16; r++) lds[t + (unsigned)r * LDS_K2_STRIDE] = v[P16(r)];
         lds_barrier();
-        // the outputs' shares of S_j
+        // the outputs' shares of S_j.  Branch-free (round 5): every slot reads its two cells in every phase and weighs them with
+        // (1 - mu) / mu where the sample's phase is j and with 0 where it is not -- the guarded form (a test, an exec mask and a
+        // branch per sample and phase) cost ~600 scalar instructions per wave and block on a kernel bound by instruction issue at
+        // three waves per SIMD (profiles/r05/general_rate_counters_1p77.txt).  A share weighed 0 leaves the accumulator as it was.
         const unsigned ju = (unsigned)j;
         const char *lb = reinterpret_cast<const char *>(lds);
 #pragma unroll
         for (int q = 0; q < KPT; q++) {
-            if ((int)t + 256 * q >= T) continue;
             const unsigned pw = tab_pos[256 * q + t];
             const float mu_q = tab_mu[256 * q + t];
+            const float w0 = (pw & 31u) == ju ? 1.0f - mu_q : 0.0f;                // resample.cxx:147
+            const float w1 = ((pw >> 5) & 31u) == ju ? mu_q : 0.0f;
             if constexpr (!REAL) {
                 const unsigned a0 = pw >> 16;                                  // byte address of the first sample
-                if ((pw & 31u) == ju) {
-                    const v2f s0 = *reinterpret_cast<const v2f *>(lb + a0);
-                    const float om = 1.0f - mu_q;                  // resample.cxx:147
-                    acc[q] = __builtin_elementwise_fma((v2f){om, om}, s0, acc[q]);
-                }
-                if (((pw >> 5) & 31u) == ju) {
-                    const v2f s1 = *reinterpret_cast<const v2f *>(lb + a0 + (((pw >> 10) & 31u) << 3));
-                    acc[q] = __builtin_elementwise_fma((v2f){mu_q, mu_q}, s1, acc[q]);
-                }
+                const v2f s0 = *reinterpret_cast<const v2f *>(lb + a0);
+                const v2f s1 = *reinterpret_cast<const v2f *>(lb + a0 + (((pw >> 10) & 31u) << 3));
+                acc[q] = __builtin_elementwise_fma((v2f){w0, w0}, s0, acc[q]);
+                acc[q] = __builtin_elementwise_fma((v2f){w1, w1}, s1, acc[q]);
             } else {
                 const unsigned a0 = (pw >> 16) + ((pw >> 13) & 4u);            // ... of the half the output belongs to: + 4 bytes for the imaginary part
-                if ((pw & 31u) == ju) {
-                    const float s0 = *reinterpret_cast<const float *>(lb + a0);
-                    acc[q] = __builtin_fmaf(1.0f - mu_q, s0, acc[q]);
-                }
-                if (((pw >> 5) & 31u) == ju) {
-                    const float s1 = *reinterpret_cast<const float *>(lb + a0 + (((pw >> 10) & 31u) << 3));
-                    acc[q] = __builtin_fmaf(mu_q, s1, acc[q]);
-                }
+                const float s0 = *reinterpret_cast<const float *>(lb + a0);
+                const float s1 = *reinterpret_cast<const float *>(lb + a0 + (((pw >> 10) & 31u) << 3));
+                acc[q] = __builtin_fmaf(w0, s0, acc[q]);
+                acc[q] = __builtin_fmaf(w1, s1, acc[q]);
             }
         }
     }
@@ -442,7 +446,7 @@ int launch_poly_gen(const PolyGenArgs &a0, int max_runs, float step, int n_chann
     PolyGenArgs a = a0;
     if (a.ovl < a.plen || a.ovl >= FFT_N / 2 || (a.ovl & 15) || max_runs > GEN_MAX_RUNS) return SFE_ESTATE;
     // the table's fields: 5 bits per phase; a call's positions as 32-bit integers
-    if (a.U > 32 || (long long)a.blksize * a.U >= 0x7fffffffLL) return SFE_ESTATE;
+    if (a.U > 31 || (long long)a.blksize * a.U >= 0x7fffffffLL) return SFE_ESTATE;      // (31: the phase value no slot has)
     // A block owns `adv` input samples: all 4096 - ovl its transform yields validly while their outputs fit the table
     // (256 x 16; a real stream's pair of blocks: 256 x 22), fewer below that -- rates under ~1, MORE outputs than inputs: what
     // `resample` takes and `decimate` refuses, libdsp/resample.cxx:91 -- down to the reference's own limit rate = 1 / U (step 1:

@@ -50,8 +50,11 @@ def found(q, decimals, vals):
     return False
 
 
+DOCS = ("DESIGN.md", "profiles/r04/NOTES.md")      # (round 5: the allocation-mode narrative and round 3's closed leads moved to NOTES.md)
+
+
 def claims():
-    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    text = "\n\n".join(open(os.path.join(ROOT, d)).read() for d in DOCS)
     for s in sentences(text):
         cites = CITE.findall(s)
         if not cites:
@@ -83,6 +86,29 @@ def test_every_ms_figure_attributed_to_a_profile_is_in_that_profile():
 
 
 def test_cited_profiles_exist():
-    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    text = "\n\n".join(open(os.path.join(ROOT, d)).read() for d in DOCS)
     missing = sorted({c for c in CITE.findall(text) if not os.path.exists(os.path.join(ROOT, c))})
     assert not missing, missing
+
+
+SHAPE_HDR = re.compile(r"^#\s*shape:\s*(.+)$", re.M)
+
+
+def test_counter_figures_quoted_with_a_shape_come_from_a_file_of_that_one_shape():
+    """round 4 quoted per-wave counter figures "at rate 1.77" from a file that averaged launches of two shapes.
+    Convention from round 5 on: a counter file that DESIGN.md cites from `profiles/r05/` on carries a first line
+    `# shape: ...` naming the ONE launch shape all its rows are of, and every sentence that cites it names every number of that
+    header (rate, taps, size) -- so the prose cannot drift to another shape than the file's."""
+    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    checked = 0
+    for s in sentences(text):
+        for c in CITE.findall(s):
+            if "counters" not in os.path.basename(c) or not re.search(r"profiles/r0[5-9]/", c):
+                continue
+            body = open(os.path.join(ROOT, c), errors="replace").read()
+            m = SHAPE_HDR.search(body.split("\n", 1)[0] + "\n")
+            assert m, "%s: a counter file cited by DESIGN.md starts with '# shape: ...'" % c
+            for num in re.findall(r"\d+(?:\.\d+)?(?:\^\d+)?", m.group(1)):
+                assert num in s, "%s is of the shape <%s>; the sentence citing it does not say %s: <<%s>>" % (c, m.group(1), num, s[:200])
+            checked += 1
+    assert checked >= 1, "DESIGN.md cites no round-5 counter file: the general-rate paragraph (4.3b) should"

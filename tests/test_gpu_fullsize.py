@@ -438,7 +438,7 @@ def _general_rate_windows(api, L, orc, taps, U, rate, n, cuts, fmt, n_windows, s
         x = api.DeviceArray(w * n)
         x.fill_synth(synth.SEED, channel=seed)
         host = (lambda a, m: synth.synth_cf32(m, ch=seed, first_sample=a)) if cplx else (lambda a, m: synth.synth_f32(m, synth.SEED, seed, first=a))
-    cap = int(n / rate) + 4096
+    cap = int(n / rate) + 4 * (n // B) + 4096          # (the library wants room for every reference call's worst case)
     y = api.DeviceArray(w * cap)
     r = api.Rs(taps, U, B, mode=L.RS_RESAMPLE, data_complex=cplx)
     if fmt == "u8":

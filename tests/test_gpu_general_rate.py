@@ -102,8 +102,8 @@ def test_transform_domain_general_rate_against_the_oracle(api, L, orc, g4, rate)
 
 def test_default_dispatch_takes_the_transform_kernel_for_bulk_calls_only(api, L):
     """AUTO: bulk complex calls in fused arithmetic take the transform-domain kernel (round 4's second pass: at any rate the
-    reference takes, below 1 too); small calls, the exact mode, real streams and SFE_RS_ALGO_DIRECT keep the direct kernel
-    -- all of them the same law."""
+    reference takes, below 1 too), and so do bulk REAL streams (two blocks per transform; include/sfe_dsp.h, api_rs.hip); small
+    calls, the exact mode and SFE_RS_ALGO_DIRECT keep the direct kernel -- all of them the same law."""
     taps, U, rate = synth.taps_cfg3(), 3, float(np.float32(1.77))
     n = 1 << 18
     x = synth.synth_cf32(n, ch=5)
