@@ -4,9 +4,11 @@
 built on demand; the product library has none of these switches).
 L / M / N = T without the two middle LDS exchanges / with one multiply per twiddle / both; l / n the same of X (round 5: energy
 ablations, WRONG results on purpose -- never compared for parity).  WATTS=1 also prints the in-kernel clock of each variant.
-Usage: ab_fir.py "4n.h" "3p" "c:8" "4n.h+1" ...   variant[:wg_per_cu][+diag bits: 1 no loads, 2 no stores]
-  variant = <waves per SIMD 2-4><p prefetch | n none>[s XOR-swizzled LDS][h H/N in registers]
-            c / d / e = the bare access pattern (8-byte plain / 16-byte plain / 8-byte nontemporal lanes)"""
+Usage: ab_fir.py T X W "T:4" "X+1" "e:8" ...   variant[:wg_per_cu][+diag bits: 1 no loads, 2 no stores]
+  variant = T / X / W = the product's three data-movement variants (register loads / LDS-DMA / LDS-DMA into the wave-private layout),
+            t / x / w = the same with round 2's guarded store loop, u / y = stores interleaved with the last DFT16,
+            c / d / e / E / b / g / G / q / Q / p = the bare access patterns (fir_fft_diag.inc), P = the product's own dispatch.
+  (Round 5 removed the round-1 kernels "4n.h", "3p", D ... with their template switches.)"""
 import os
 import sys
 
@@ -17,7 +19,7 @@ from simplefe_amd import build, lib  # noqa: E402
 lib.LIB_PATH = os.environ.get("SFE_DIAG_LIB") or build.build_lib(diag=True)      # SFE_DIAG_LIB: a saved build to compare against          # before anything loads the product library
 from simplefe_amd import api, synth  # noqa: E402
 
-variants = sys.argv[1:] or ["3n", "3p", "2n", "2p"]
+variants = sys.argv[1:] or ["T", "X", "W", "e:8"]
 log2n = int(os.environ.get("LOG2N", "28"))
 rounds = int(os.environ.get("ROUNDS", "6"))
 # ZEROS=1: the input holds zeros (what the kernel costs without the data's toggling: DESIGN.md 9); WATTS=1: after the timing, ~1.5 s of

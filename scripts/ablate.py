@@ -44,8 +44,8 @@ if which == "fir":
     f = api.Fir(synth.taps_cfg2(), data_complex=True, algo=lib.FIR_ALGO_FFT)
     cases = [("product kernel (work counters + LDS-DMA, X)", ("X", "0")), ("  X: output stores suppressed", ("X", "2")),
              ("  X: input loads replaced", ("X", "1")), ("  X: neither (on-chip work only)", ("X", "3")),
-             ("round-1 kernel (register loads, 4n.h)", ("4n.h", "0")), ("  4n.h: output stores suppressed", ("4n.h", "2")),
-             ("  4n.h: input loads replaced", ("4n.h", "1")), ("  4n.h: neither (on-chip work only)", ("4n.h", "3")),
+             ("product kernel (work counters + register loads, T)", ("T", "0")), ("  T: output stores suppressed", ("T", "2")),
+             ("  T: input loads replaced", ("T", "1")), ("  T: neither (on-chip work only)", ("T", "3")),
              ("access pattern of the LDS-DMA variant alone (g)", ("g", "0")),
              ("access pattern alone, 8 B nt lanes (e)", ("e", "0")), ("access pattern, 8 B plain (c)", ("c", "0")),
              ("access pattern, 16 B plain (d)", ("d", "0"))]

@@ -52,7 +52,7 @@ if [ -n "$COUNTERS_ONLY" ]; then echo collected counters; exit 0; fi
 mkdir -p $R/gpurun_out/prof_${TAG}_tables
 timeout -k 10 300 python3 scripts/ablate.py fir > gpurun_out/prof_${TAG}_tables/fir_variants_ab.txt 2>&1 || exit 1
 timeout -k 10 300 python3 scripts/ablate.py resample > gpurun_out/prof_${TAG}_tables/resample_fft_ablation.txt 2>&1 || exit 1
-ROUNDS=8 timeout -k 10 300 python3 scripts/ab_fir.py 4n.h D T X W e:8 E e:300 > gpurun_out/prof_${TAG}_tables/fir_walk_vs_tickets.txt 2>&1 || exit 1
+ROUNDS=8 timeout -k 10 300 python3 scripts/ab_fir.py T X W e:8 E e:300 > gpurun_out/prof_${TAG}_tables/fir_walk_vs_tickets.txt 2>&1 || exit 1
 # round 3: the three product variants with the straight-line store block (T X W) against the round-2 guarded store loop
 # (t x w) and against stores interleaved with the last DFT16 (u y); P = the product's own dispatch (measured choice)
 ROUNDS=10 timeout -k 10 300 python3 scripts/ab_fir.py T t X x W w u y P > gpurun_out/prof_${TAG}_tables/fir_store_block.txt 2>&1 || exit 1

@@ -89,7 +89,7 @@ def parse_resources(text):
     return out
 
 
-FIR_TEMPLATE_ARGS = "IN_C OUT_C WAVES PREFETCH SWZ HREG IN_U8 PAIR OUT_TX10 DMA DIAG TICKET ACC WP HCH".split()
+FIR_TEMPLATE_ARGS = "IN_C OUT_C IN_U8 PAIR OUT_TX10 DMA DIAG ACC WP HCH".split()
 
 
 def fir_kernel_flags(name):

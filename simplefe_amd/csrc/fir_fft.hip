@@ -18,7 +18,7 @@
 // Global traffic is perfectly coalesced in both directions (lane == consecutive sample,
 // register == row of 256); the first hl/256 rows of the result are the overlap-save discard.
 // LDS rows are padded (272 / 17 complex) so every ds_read_b64/ds_write_b64 is conflict-free.
-// Twiddle bases AND this thread's 16 bins of the taps' spectrum H/N (HREG, 32 VGPRs) live in
+// Twiddle bases AND this thread's 16 bins of the taps' spectrum H/N (hreg, 32 VGPRs) live in
 // registers for the life of the (persistent) workgroup, which walks transforms blockIdx.x,
 // +gridDim.x, ...  Budget: <= 128 VGPRs and 34 KiB LDS -> 4 workgroups per CU.
 //
@@ -92,10 +92,11 @@ __device__ unsigned long long g_fir_clk[4];
 #define SFE_FIR_STAMP(i) do { } while (0)
 #endif
 
-// WAVES = waves per SIMD the register allocator must fit (3 -> <=168 VGPRs, 2 -> <=256);
-// PREFETCH = request transform i+1's rows during transform i's inverse stages.
-// HREG = keep this thread's 16 bins of H/N in registers (32 VGPRs) instead of re-reading 32 KiB
-// from L2 per transform (that stream shares the CU's vector-memory path with the samples).
+// Every instantiation: 256 threads, four workgroups per CU (<= 128 VGPRs), this thread's 16 bins of H/N in registers (32 VGPRs:
+// re-reading 32 KiB from L2 per transform shares the CU's vector-memory path with the samples and cost 10 %), transforms drawn from
+// device counters.  (Rounds 1-3 carried five more template switches -- waves per SIMD, a register prefetch, an XOR-swizzled
+// exchange buffer, the spectrum streamed from L2, a fixed-stride walk instead of counters -- each measured and lost; round 5
+// removed them and their diagnostic instantiations: profiles/r02 and r03 hold the tables, the history the code.)
 // PAIR (real data, real taps only): the real and imaginary parts of one transform carry two
 // CONSECUTIVE real segments of the stream (z = x_A + j x_B; real taps keep them apart), so a real
 // stream costs what a complex one does per sample instead of twice as much.
@@ -106,17 +107,14 @@ __device__ unsigned long long g_fir_clk[4];
 // requested by LDS-DMA (global_load_lds_dwordx4: 16-byte lanes, no VGPR destination) straight into
 // the exchange buffer's padded row layout, and they are requested EARLY -- as soon as the previous
 // transform's last LDS reads are done, i.e. before its final DFT16 and its 15 rows of stores -- so
-// part of the HBM latency runs under that work without costing a register (the register prefetch
-// variant lost a resident workgroup to its 32 extra VGPRs).  F1 then reads its column from LDS.
+// part of the HBM latency runs under that work without costing a register.  F1 then reads its column from LDS.
 // Edge transforms (history in front, ragged end) keep the guarded register loads.
-template <bool IN_C, bool OUT_C, int WAVES, bool PREFETCH, bool SWZ, bool HREG = false, bool IN_U8 = false, bool PAIR = false,
-          bool OUT_TX10 = false, bool DMA = false, int DIAG = 0, bool TICKET = true, bool ACC = false, bool WP = false,
-          bool HCH = false>
-__global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
+template <bool IN_C, bool OUT_C, bool IN_U8 = false, bool PAIR = false, bool OUT_TX10 = false, bool DMA = false, int DIAG = 0,
+          bool ACC = false, bool WP = false, bool HCH = false>
+__global__ __launch_bounds__(256, 4) void fir_fft4096_kernel(FirFftArgs a)
 {
-    // HCH (with HREG): per-channel taps -- the spectrum registers are reloaded when the workgroup's next transform
+    // HCH: per-channel taps -- the spectrum registers are reloaded when the workgroup's next transform
     // belongs to another channel (channel-major tickets: every few transforms at 64 x 2^24, not every one)
-    static_assert(!HCH || (HREG && TICKET), "per-channel spectra ride the register-resident, ticketed kernels");
     // WP (with DMA): wave-private [n2|k2][column] layout.  Thread t touches column t of the first /
     // last exchange layout in F1 (read + write), I3 (read) and nothing else does between the I2->I3
     // barrier and the F1->F2 barrier; if every wave's 64 columns sit in a region of their own AND the
@@ -133,7 +131,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
     // delayed by a.shift = p*hl samples and, with ACC, adds its result to what the earlier partitions
     // left in the output.  a.hist_len >= a.hl + a.shift samples of history precede the input.
     static_assert(!ACC || (!OUT_TX10 && !DMA), "accumulating launches write float32 through the plain store path");
-    // TICKET: the persistent workgroups do not walk a fixed stride (blockIdx.x, +gridDim.x, ...) but
+    // Tickets: the persistent workgroups do not walk a fixed stride (blockIdx.x, +gridDim.x, ...) but
     // draw the next transform from one device-wide counter, channel-major.  Whatever the speed of
     // individual workgroups, the transforms in flight are then always the ~1000 NEXT ones of the
     // stream: one compact, advancing window of reads and one of writes, as a one-workgroup-per-
@@ -144,7 +142,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
     // DIAG (instantiated under -DSFE_DIAG only, scripts/ablate.py): bit 0 = input loads replaced by
     // constants, bit 1 = output stores folded into one never-taken store -- compile-time, so the
     // product kernel's instruction stream and register allocation are untouched.
-    static_assert(!DMA || (IN_C && !IN_U8 && !PAIR && !SWZ && !PREFETCH), "LDS-DMA input: complex float32, padded layout");
+    static_assert(!DMA || (IN_C && !IN_U8 && !PAIR), "LDS-DMA input: complex float32, padded layout");
     // DIAG bit 3 (diagnostic library only, variants y / u): a row is stored as soon as the butterfly of the last DFT16
     // that completes it is done, instead of behind the whole DFT16 (DESIGN.md 9 lead (ii); it spills: see the store section)
     constexpr bool INTERLEAVE = (DIAG & 8) != 0;
@@ -157,37 +155,26 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
     constexpr bool NOMID = (DIAG & 16) != 0, NORECON = (DIAG & 32) != 0;
     auto tw2f = [](v2f x, v2f q, v2f p) -> v2f { return NORECON ? cmul(x, q) : cmul2(x, q, p); };
     auto tw2i = [](v2f x, v2f q, v2f p) -> v2f { return NORECON ? cmul_conj(x, q) : cmul2_conj(x, q, p); };
-    static_assert(!TICKET || !PREFETCH, "the register prefetch looks ahead by a fixed stride");
     __shared__ v2f lds[WP ? 4 * WP_REGION : FFT_ROWS * LDS_K2_STRIDE];
-    __shared__ unsigned s_next;       // TICKET: the next transform drawn by lane 0
+    __shared__ unsigned s_next;       // the next transform drawn by lane 0
     const unsigned t = threadIdx.x;   // unsigned: lets loads/stores use SGPR base + 32-bit VGPR offset
     SFE_FIR_STAMP(0);
-    int ch = TICKET ? 0 : blockIdx.y;
+    int ch = 0;
     const unsigned lo = t & 15, hi = t >> 4;
-    // LDS cell of element (k2, a, n0), a = n1 or k1:
-    //   padded  (SWZ=0): [k2][n1][n0] -> 272 k2 + 16 n1 + n0,  [k2][k1][n0] -> 272 k2 + 17 k1 + n0
-    //   swizzled(SWZ=1): both             272 k2 + 16 a + (n0 ^ a)
-    // The swizzle keeps every access conflict-free AND makes each stage rewrite exactly the cells
-    // it has just read, which removes the three write-after-read barriers (7 -> 4 per transform)
-    // at the price of one v_xor per access in the two middle exchanges.
-    const unsigned base_a = WP ? (t >> 6) * WP_REGION + (t & 63u)
-                               : (SWZ ? ((t & ~15u) | ((t ^ (t >> 4)) & 15u)) : t);   // + row_a(k2)
-    unsigned base_b = hi * LDS_K2_STRIDE + lo;                   // SWZ: (base_b ^ a) + 16 a
-    unsigned base_c = hi * LDS_K2_STRIDE + lo * LDS_K1_STRIDE;   // SWZ: base_c ^ n0
+    // LDS cell of element (k2, a, n0), a = n1 or k1 (padded rows: every access conflict-free):
+    //   [k2][n1][n0] -> 272 k2 + 16 n1 + n0,  [k2][k1][n0] -> 272 k2 + 17 k1 + n0
+    const unsigned base_a = WP ? (t >> 6) * WP_REGION + (t & 63u) : t;   // + row_a(k2)
+    const unsigned base_b = hi * LDS_K2_STRIDE + lo;
+    const unsigned base_c = hi * LDS_K2_STRIDE + lo * LDS_K1_STRIDE;
     const unsigned base_w = (hi & 7u) * WP_PITCH + (hi >> 3) * 64u + lo;      // WP: row hi of column lo (+ 16 n1)
     // offset of row r in the first / last layout, relative to the thread's column
     auto row_a = [](int r) -> unsigned { return WP ? (unsigned)((r & 7) * WP_PITCH + (r >> 3) * 64) : (unsigned)(r * LDS_K2_STRIDE); };
     auto cell_b1 = [&](int a1) -> unsigned {
         if (WP) return base_w + (unsigned)((a1 >> 2) * WP_REGION + 16 * (a1 & 3));     // column lo + 16 a1 of row hi
-        return SWZ ? ((base_b ^ (unsigned)a1) + 16u * a1) : base_b + 16u * a1;
+        return base_b + 16u * a1;
     };
-    auto cell_b2 = [&](int a1) -> unsigned { return SWZ ? ((base_b ^ (unsigned)a1) + 16u * a1) : base_b + (unsigned)LDS_K1_STRIDE * a1; };
-    auto cell_c = [&](int n0) -> unsigned { return SWZ ? (base_c ^ (unsigned)n0) : base_c + n0; };
-    // Called before each group of swizzled accesses: makes the base opaque there, so the 16
-    // addresses (base ^ i) are recomputed at the point of use (one v_xor each) instead of being
-    // hoisted out of the transform loop / kept live across a DFT16 (16-32 VGPRs).
-    auto fresh_b = [&]() { if (SWZ) asm volatile("" : "+v"(base_b)); };
-    auto fresh_c = [&]() { if (SWZ) asm volatile("" : "+v"(base_c)); };
+    auto cell_b2 = [&](int a1) -> unsigned { return base_b + (unsigned)LDS_K1_STRIDE * a1; };
+    auto cell_c = [&](int n0) -> unsigned { return base_c + n0; };
 
     constexpr int ISZ = IN_U8 ? (IN_C ? 2 : 1) : (IN_C ? 8 : 4);   // bytes per input sample
     const char *in_c, *hist_c;
@@ -275,7 +262,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
     };
     auto draw = [&]() -> unsigned { return draw_finish(draw_issue()); };
     const unsigned nblk32 = (unsigned)a.nblk;
-    if (HREG && !HCH) {
+    if (!HCH) {
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             hreg[k] = (a.hs + k * 256)[t];
@@ -289,7 +276,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         if constexpr (PAIR) {
             // segment A = transform 2*blk of the real stream, segment B = transform 2*blk + 1
             const long long baseA = 2 * blk * a.advance - a.hl - a.shift, baseB = baseA + a.advance;
-            if constexpr (IN_U8 && !PREFETCH) {
+            if constexpr (IN_U8) {
                 // real u8 stream: each segment's 4 KiB as one 16-byte lane per thread, parked raw in
                 // LDS and picked up bytewise (the complex form is below)
                 if (baseA >= 0 && baseB + FFT_N <= a.n && (reinterpret_cast<uintptr_t>(in_c) & 15u) == 0) {
@@ -336,7 +323,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             for (int r = 0; r < 16; r++) x[r] = (v2f){__builtin_bit_cast(float, 0x3f000000u | ((u + 256u * r) & 0x7fffffu)), 0.25f};
             return;
         }
-        if constexpr (IN_U8 && IN_C && !PREFETCH) {
+        if constexpr (IN_U8 && IN_C) {
             // u8 wire format, interior transform, 16-byte-aligned stream: the transform's 8 KiB are
             // requested as 16-byte lanes (two per thread instead of sixteen 2-byte ones), parked raw
             // in the first 8 KiB of the exchange buffer and picked up as this thread's 16 samples.
@@ -426,13 +413,10 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         }
     };
 
-    // Software pipeline: the rows of transform i+1 are requested after the spectrum stage of
-    // transform i (where register pressure peaks) and land while its two inverse stages and
-    // its stores run; F1 of the next iteration consumes them.
     v2f nx[16];
-    long long blk = blockIdx.x;
+    long long blk;
     unsigned kt_next = 0;
-    if constexpr (TICKET) {
+    {
         if (t == 0) s_next = few ? blockIdx.x : draw();
         lds_barrier();
         const unsigned kt = __builtin_amdgcn_readfirstlane(s_next);
@@ -441,8 +425,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         blk = kt - (unsigned)ch * nblk32;
         load_spectrum(ch);
         set_channel(ch);
-    } else if (blk >= a.nblk) return;
-    if (PREFETCH) load_rows(nx, blk);
+    }
     bool landed = false;         // DMA: this transform's rows were requested by the previous iteration
     bool counted = false;        // ... and exactly 15 stores were issued after them (vmcnt(15) suffices)
     if (DMA && interior(blk)) {
@@ -460,7 +443,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             if (!WP) lds_barrier();       // every wave's pieces have landed (WP: this wave's own are all it reads)
 #pragma unroll
             for (int r = 0; r < 16; r++) nx[r] = lds[base_a + row_a(r)];
-        } else if (!PREFETCH) load_rows(nx, blk);
+        } else load_rows(nx, blk);
         // ---- F1: over n2, twiddle W_4096^(t k2), scatter to [k2][t]
         dft16<-1>(nx);
 #pragma unroll
@@ -473,16 +456,12 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         }
         lds_barrier();
         unsigned drawn = 0;
-        if (TICKET && t == 0) drawn = draw_issue();      // finished two stages further down
+        if (t == 0) drawn = draw_issue();      // finished two stages further down
         // ---- F2: gather n1 for (k2=hi, n0=lo)
-        fresh_b();
 #pragma unroll
         for (int r = 0; r < 16; r++) v[r] = lds[cell_b1(r)];
         dft16<-1>(v);
-        if (NOMID) { }
-        else if (!SWZ) lds_barrier();
-        else __builtin_amdgcn_sched_barrier(0);   // keep the stages apart in the scheduler (register pressure)
-        fresh_b();
+        if (!NOMID) lds_barrier();
         v2f wmid[16];                             // NOMID only: what would have gone through the LDS
 #pragma unroll
         for (int k = 0; k < 16; k++) {
@@ -495,7 +474,6 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         }
         if (!NOMID) lds_barrier();
         // ---- F3: gather n0 for (k2=hi, k1=lo); spectrum multiply; first inverse stage
-        fresh_c();
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             if constexpr (NOMID) v[r] = wmid[r];
@@ -505,12 +483,10 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         {
             // spectrum multiply in place (bin k sits in v[P16(k)]), then the first inverse stage
             // with the transposed schedule, which consumes exactly that order: no shuffling.
-            // H/N for this thread's 16 bins is streamed from L2 each transform.
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[P16(k)] = cmul(v[P16(k)], HREG ? hreg[k] : (a.hs + (size_t)ch * a.hs_stride + k * 256)[t]);
+            for (int k = 0; k < 16; k++) v[P16(k)] = cmul(v[P16(k)], hreg[k]);
             dft16_rev<+1>(v);
             // I1: element n0 goes back to the cell this thread read n0 from (no barrier needed)
-            fresh_c();
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 if constexpr (NOMID) wmid[k] = v[k];
@@ -520,30 +496,20 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         // every wave "looks at" the draw here, so that the compiler's wait for the atomic sits HERE on every
         // path: left to the one-lane branch below, the other waves' path keeps it pending and a vmcnt(0)
         // appears in front of the stores -- behind the next transform's rows
-        if (TICKET) asm volatile("" : "+v"(drawn));
-        if (TICKET && t == 0) s_next = draw_finish(drawn);
+        asm volatile("" : "+v"(drawn));
+        if (t == 0) s_next = draw_finish(drawn);
         lds_barrier();
-        if (TICKET) kt_next = __builtin_amdgcn_readfirstlane(s_next);
+        kt_next = __builtin_amdgcn_readfirstlane(s_next);
         // the transform after this one: (nch, nb), uniform
-        bool more;
-        int nch = ch;
-        long long nb;
-        if constexpr (TICKET) {
-            more = kt_next < a.total;
-            nch = (int)(kt_next / nblk32);
-            nb = kt_next - (unsigned)nch * nblk32;
-        } else {
-            nb = blk + gridDim.x;
-            more = nb < a.nblk;
-        }
+        const bool more = kt_next < a.total;
+        const int nch = (int)(kt_next / nblk32);
+        const long long nb = kt_next - (unsigned)nch * nblk32;
         // per-channel spectra: this transform's has just been multiplied in -- if the next transform belongs to another
         // channel its sixteen bins are requested HERE, under the two inverse stages and the stores still to come, and in
         // front of the next transform's rows (round 4; until then they were requested after the stores, at the top of the
         // next transform: with channel-major tickets every ~6th transform of a workgroup at 64 x 2^24, 3.6-5.7 % of the launch)
         if (HCH && more && nch != ch) load_spectrum(nch);
-        if (PREFETCH && more) load_rows(nx, nb);   // see above
         // ---- I2: gather k1 for (k2=hi, n0=lo)
-        fresh_b();
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             v2f x;
@@ -555,10 +521,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             v[r] = x;
         }
         dft16<+1>(v);
-        if (NOMID) { }
-        else if (!SWZ) lds_barrier();
-        else __builtin_amdgcn_sched_barrier(0);   // keep the stages apart in the scheduler (register pressure)
-        fresh_b();
+        if (!NOMID) lds_barrier();
 #pragma unroll
         for (int k = 0; k < 16; k++) lds[cell_b1(k)] = v[P16(k)];
         lds_barrier();
@@ -583,8 +546,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
             if constexpr (INTERLEAVE) dft16_head<+1>(v); else dft16<+1>(v);
         } else {
         if constexpr (INTERLEAVE) dft16_head<+1>(v); else dft16<+1>(v);
-        if (!SWZ) lds_barrier();   // LDS free for the next transform
-        else __builtin_amdgcn_sched_barrier(0);
+        lds_barrier();   // LDS free for the next transform
         }
         // (INTERLEAVE: the last four butterflies of that DFT16 run below, next to the stores of the rows each completes)
 
@@ -772,7 +734,7 @@ __global__ __launch_bounds__(256, WAVES) void fir_fft4096_kernel(FirFftArgs a)
         // ---- on to the next transform (drawn two stages ago, or blockIdx.x + k gridDim.x)
         if (!more) break;
         blk = nb;
-        if (TICKET && nch != ch) {
+        if (nch != ch) {
             ch = nch;
             set_channel(ch);
         }
@@ -875,50 +837,46 @@ int launch_fir_fft(const FirFftArgs &a0, int in_complex, int out_complex, int in
     const dim3 grid((unsigned)gt), block(256);
 #define SFE_K(...) hipLaunchKernelGGL((fir_fft4096_kernel<__VA_ARGS__>), grid, block, 0, s, a)
 #ifdef SFE_DIAG
-    // fixed-stride walk (round 1): blockIdx.x, + gridDim.x, ... per channel on a 2-D grid
+    // the bare access-pattern kernels keep round 1's fixed-stride walk: blockIdx.x, + gridDim.x, ... per channel on a 2-D grid
     long long gx = nb;
     const long long cap = ((long long)cus * wg_per_cu + n_channels - 1) / n_channels;
     if (gx > cap) gx = cap < 1 ? 1 : cap;
     const dim3 grid2((unsigned)gx, (unsigned)n_channels);
-#define SFE_K2(...) hipLaunchKernelGGL((fir_fft4096_kernel<__VA_ARGS__>), grid2, block, 0, s, a)
-#endif
-#ifdef SFE_DIAG
 #include "diag/fir_fft_launch_diag.inc"
 #endif
-    //       IN_C   OUT_C  WAVES PREFETCH SWZ  HREG  IN_U8  PAIR   OUT_TX10 DMA DIAG TICKET ACC
+    //    IN_C   OUT_C  IN_U8  PAIR   TX10   DMA    DIAG ACC   WP     HCH
     if (a.hs_stride) {          // per-channel taps: the channel's spectrum is reloaded into registers on a channel change (cf32 streams only)
         if (!in_complex || !out_complex || in_u8 || out_tx10) {
             set_error("fir_fft: per-channel taps are built for complex float32 streams");
             return SFE_EINVAL;
         }
-        //                         IN_C  OUT_C W  PREF   SWZ    HREG  IN_U8  PAIR   TX10   DMA    DG TICKET ACC   WP     HCH
-        if (accumulate) SFE_K(true, true, 4, false, false, true, false, false, false, false, 0, true, true, false, true);
-        else if (var != FIR_VAR_REG) SFE_K(true, true, 4, false, false, true, false, false, false, true, 0, true, false, false, true);
-        else SFE_K(true, true, 4, false, false, true, false, false, false, false, 0, true, false, false, true);
+        if (accumulate) SFE_K(true, true, false, false, false, false, 0, true, false, true);
+        else if (var != FIR_VAR_REG) SFE_K(true, true, false, false, false, true, 0, false, false, true);
+        else SFE_K(true, true, false, false, false, false, 0, false, false, true);
     } else if (accumulate) {           // partitions after the first: out += this partition's result
         if (in_complex) {
-            if (in_u8) SFE_K(true, true, 4, false, false, true, true, false, false, false, 0, true, true);
-            else SFE_K(true, true, 4, false, false, true, false, false, false, false, 0, true, true);
+            if (in_u8) SFE_K(true, true, true, false, false, false, 0, true);
+            else SFE_K(true, true, false, false, false, false, 0, true);
         } else if (out_complex) {
-            SFE_K(false, true, 4, false, false, true, false, false, false, false, 0, true, true);
+            SFE_K(false, true, false, false, false, false, 0, true);
         } else {
-            if (in_u8) SFE_K(false, false, 4, false, false, true, true, true, false, false, 0, true, true);
-            else SFE_K(false, false, 4, false, false, true, false, true, false, false, 0, true, true);
+            if (in_u8) SFE_K(false, false, true, true, false, false, 0, true);
+            else SFE_K(false, false, false, true, false, false, 0, true);
         }
     } else if (in_complex) {
-        if (in_u8 && out_tx10) SFE_K(true, true, 4, false, false, true, true, false, true);      // wire to wire
-        else if (out_tx10) SFE_K(true, true, 4, false, false, true, false, false, true);
-        else if (in_u8) SFE_K(true, true, 4, false, false, true, true);
-        else if (var == FIR_VAR_DMA) SFE_K(true, true, 4, false, false, true, false, false, false, true);      // LDS-DMA early request
-        else if (var == FIR_VAR_WP) SFE_K(true, true, 4, false, false, true, false, false, false, true, 0, true, false, true);      // ... into the wave-private layout
-        else SFE_K(true, true, 4, false, false, true);
+        if (in_u8 && out_tx10) SFE_K(true, true, true, false, true);      // wire to wire
+        else if (out_tx10) SFE_K(true, true, false, false, true);
+        else if (in_u8) SFE_K(true, true, true);
+        else if (var == FIR_VAR_DMA) SFE_K(true, true, false, false, false, true);      // LDS-DMA early request
+        else if (var == FIR_VAR_WP) SFE_K(true, true, false, false, false, true, 0, false, true);      // ... into the wave-private layout
+        else SFE_K(true, true);
     } else if (out_complex) {
-        SFE_K(false, true, 4, false, false, true);                                                // real data, complex taps
+        SFE_K(false, true);                                               // real data, complex taps
     } else {
-        if (in_u8 && out_tx10) SFE_K(false, false, 4, false, false, true, true, true, true);
-        else if (out_tx10) SFE_K(false, false, 4, false, false, true, false, true, true);
-        else if (in_u8) SFE_K(false, false, 4, false, false, true, true, true);
-        else SFE_K(false, false, 4, false, false, true, false, true);
+        if (in_u8 && out_tx10) SFE_K(false, false, true, true, true);
+        else if (out_tx10) SFE_K(false, false, false, true, true);
+        else if (in_u8) SFE_K(false, false, true, true);
+        else SFE_K(false, false, false, true);
     }
 #undef SFE_K
     SFE_HIP(hipGetLastError());
