@@ -31,6 +31,8 @@ SHAPES = [("interpolate x2 (rate 1/2)", 2, 1), ("3/4 (4 out per 3 in)", 4, 3), (
           ("decimate by 6", 1, 6), ("decimate by 7", 1, 7), ("decimate by 16", 1, 16),
           ("interpolate x4 (rate 1/4)", 4, 1), ("7/4", 4, 7), ("2/3 (3 out per 2 in)", 3, 2), ("3/2 (2 out per 3 in)", 2, 3), ("7/3 (3 out per 7 in)", 3, 7), ("4/5 (5 out per 4 in)", 5, 4),
           ("interpolate x3 (rate 1/3)", 3, 1), ("interpolate x8 (rate 1/8)", 8, 1)]
+if os.environ.get("EXTRA") == "1":          # round 5: long decimations, for the tile-size rule of poly_rt_kernel
+    SHAPES += [("decimate by 12", 1, 12), ("decimate by 13", 1, 13), ("decimate by 24", 1, 24), ("decimate by 32", 1, 32), ("decimate by 48", 1, 48)]
 if os.environ.get("SHAPES"):
     want = os.environ["SHAPES"].split(",")
     SHAPES = [s for s in SHAPES if any(w in s[0] for w in want)]

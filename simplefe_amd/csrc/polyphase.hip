@@ -471,7 +471,8 @@ __global__ __launch_bounds__(256) void poly_rt_kernel(PolyTiledArgs a)
         // local time qt = SP qq + p descending = tap index ascending; sample (mi, qt) sits at row p, column mi + qq
         unsigned off = (SP - 1u) * RL + (unsigned)(Lq - 1) + (unsigned)mi0;
         unsigned p = SP - 1u;
-#pragma unroll 2
+        // (round 5) with one m per thread the loop is a chain of LDS-read latencies: eight taps' reads in flight instead of two
+#pragma unroll(MB == 1 ? 8 : (MB == 2 ? 4 : 2))
         for (int qt = a.Lp - 1; qt >= 0; --qt) {
             T x[MB];
 #pragma unroll
@@ -1194,6 +1195,11 @@ static int launch_poly_rt(const PolyTiledPlan &plan, const PolyTiledArgs &a0, in
     a.SP = plan.SP;
     a.UP = plan.UP;
     a.tm = rt_tile_m(plan.SP, plan.UP);
+#ifdef SFE_DIAG
+    // SFE_RT_TM=<m per tile, a multiple of 64>: smaller tiles = more resident workgroups (scripts/time_shapes.py, round 5)
+    if (const char *e = getenv("SFE_RT_TM"))
+        if (atoi(e) >= 64 && atoi(e) <= 2048 && atoi(e) % 64 == 0) a.tm = atoi(e);
+#endif
     a.rowlen = rt_rowlen(plan.SP, a.tm, plan.Lp / plan.SP, esz);
     a.sp_inv = (unsigned)((0x100000000ull + (unsigned)plan.SP - 1) / (unsigned)plan.SP);
     const long long mtot = (a.n_out + plan.UP - 1) / plan.UP;
