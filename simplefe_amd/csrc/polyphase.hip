@@ -471,8 +471,9 @@ __global__ __launch_bounds__(256) void poly_rt_kernel(PolyTiledArgs a)
         // local time qt = SP qq + p descending = tap index ascending; sample (mi, qt) sits at row p, column mi + qq
         unsigned off = (SP - 1u) * RL + (unsigned)(Lq - 1) + (unsigned)mi0;
         unsigned p = SP - 1u;
-        // (round 5) with one m per thread the loop is a chain of LDS-read latencies: eight taps' reads in flight instead of two
-#pragma unroll(MB == 1 ? 8 : (MB == 2 ? 4 : 2))
+        // (round 5 tried eight / four taps' reads in flight for one / two m per thread: no change beyond the run-to-run noise,
+        // profiles/r05/shapes_tile_sizes.txt)
+#pragma unroll 2
         for (int qt = a.Lp - 1; qt >= 0; --qt) {
             T x[MB];
 #pragma unroll
