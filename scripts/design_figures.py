@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from simplefe_amd.build import fir_kernel_flags  # noqa: E402
 
-tag = next((a for a in sys.argv[1:] if not a.startswith("--")), "r04")
+tag = next((a for a in sys.argv[1:] if not a.startswith("--")), "r05")
 P = os.path.join(ROOT, "profiles", tag)
 ALG = {"fir": 16 * 2 ** 28, "decimate": 9 * 2 ** 30, "resample": 8 * 2 ** 28 + 8 * 161061273}
 
@@ -108,9 +108,9 @@ def collection_block():
     ch64 = [x for x in drv["other_configs"] if "64 channel" in x["workload"]][0]
     head = (f"The driver's command shape measured by the builder (`python bench.py --gpus 1 --steps 20 --warmup 5`, `profiles/{tag}/bench_driver_shape.json`): "
             f"**{drv['value']:,.0f} MS/s, `ms_per_step` {drv['ms_per_step']:.3f}, `roofline.frac` {r['frac']:.3f}** (kernel {r['kernel_ms']:.4f} ms mean, "
-            f"{r['kernel_ms_min']:.4f} min, {r['kernel_ms_max']:.4f} max; `traffic` {r['traffic'] / 1e9:.3f} GB; variant: {r['variant']['ran']}, {r['variant'].get('chosen_by', '')}), parity "
+            f"{r['kernel_ms_min']:.4f} min, {r['kernel_ms_max']:.4f} max; the three plain pairs timed before: {', '.join('%.4f' % v for v in drv['config'].get('pairs', {}).get('pairs_timed_ms', []))} ms, the median one kept; `traffic` {r['traffic'] / 1e9:.3f} GB; variant: {r['variant']['ran']}, {r['variant'].get('chosen_by', '')}), parity "
             f"{drv['parity']['rel_rms_max']:.1e}; `other_configs`: resample 5/3 {o['381-tap']['ms']:.4f} ms ({o['381-tap']['frac']:.3f}), with the 127-tap prototype "
-            f"{o['127-tap']['ms']:.4f} ms ({o['127-tap']['frac']:.3f}), decimate ÷8 {o['decimate by 8']['ms']:.4f} ms ({o['decimate by 8']['frac']:.3f}; mode: {o['decimate by 8'].get('mode', '?').split(' (')[0]}), "
+            f"{o['127-tap']['ms']:.4f} ms ({o['127-tap']['frac']:.3f}), decimate ÷8 {o['decimate by 8']['ms']:.4f} ms ({o['decimate by 8']['frac']:.3f}; plain allocations: whichever placement mode the process drew), "
             f"general rate 1.77 {o['general-rate']['ms']:.4f} ms ({o['general-rate']['frac']:.3f}), 64 channels × 2^24 "
             f"{ch64['ms']:.2f} ms ({ch64['frac']:.3f}), complex taps {o['complex-tap']['ms']:.4f} ms ({o['complex-tap']['frac']:.3f}), every parity check green; "
             f"`cpu_baseline` {c['value']:.0f} MS/s on one thread, {c['all_cores']['value']:.0f} MS/s on the box's {c['host_cores']} host cores"

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from simplefe_amd.build import csrc_hash  # noqa: E402
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 KEYS = {"fir": ("fir256_cf32_2p28", "fir_fft4096", 16 * 2 ** 28),
         "decimate": ("decimate8_cf32_2p30", "poly_tiled", 9 * 2 ** 30),
         "resample": ("resample5o3_cf32_2p28", "poly_fft256", None),
