@@ -264,6 +264,7 @@ struct PolyGenArgs {
     int         adv;            // input samples a block owns (launcher: 4096 - ovl, fewer for rates below ~1)
     int         real;           // a real float32 stream: two consecutive blocks per transform (poly_gen.hip: REAL)
     int         in_u8;          // the stream is u8 offset binary, converted on load (poly_gen.hip: IN_U8)
+    int         diag_T;         // (diagnostic library's prologue ablation only: outputs per block of the synthetic table)
 };
 // SFE_ESTATE: outside what the kernel takes (caller: launch_poly_seg)
 int launch_poly_gen(const PolyGenArgs &a, int max_runs, float step, int n_channels, hipStream_t s);

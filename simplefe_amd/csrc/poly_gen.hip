@@ -33,6 +33,10 @@
 
 #include <type_traits>
 
+#ifdef SFE_DIAG
+#include <stdlib.h>
+#endif
+
 #include "common.h"
 #include "fft16.h"
 
@@ -62,7 +66,9 @@ constexpr int GEN_MAX_RUNS = 1024;       // runs of the (at most two) calls a bl
 // IN_U8: the stream is the device's receive wire format, u8 offset binary ((I, Q) byte pairs; REAL: one byte per sample),
 // converted as the rows are loaded -- (b - 128) / 127, the reference's converter (gr-simplefe/lib/source_c_impl.cc:121-132):
 // the same bits as the float32 path fed the converted samples.  The carried history is float32 either way.
-template <int KPT, bool REAL, bool IN_U8>
+// NOPRO (diagnostic library only, round 5): the whole of step 0 -- call records, runs, bound searches, the table of (position, mu) -- replaced by a
+// synthetic table of a.diag_T outputs at a fixed step (WRONG results on purpose): what a table that arrived ready-made could save at most.
+template <int KPT, bool REAL, bool IN_U8, bool NOPRO = false>
 __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(PolyGenArgs a)
 {
     constexpr int NC = REAL ? 3 : 2;             // reference calls a block (pair) can overlap: its span <= (REAL ? 2 : 1) x blksize
@@ -128,6 +134,24 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
         }
     }
 
+    int T = 0;
+    long long k_first = 0;
+    if constexpr (NOPRO) {
+        T = a.diag_T < 256 * KPT ? a.diag_T : 256 * KPT;
+        k_first = (long long)blockIdx.x * T;
+        const unsigned Uu = (unsigned)U, e0 = (unsigned)a.ovl - 1u;
+#pragma unroll
+        for (int q = 0; q < KPT; q++) {
+            const unsigned idx = t + 256u * q;
+            const unsigned pl = (unsigned)(((unsigned long long)idx * (unsigned)A * Uu) / (unsigned)(T > 0 ? T : 1));      // spread over the block's positions
+            const unsigned n = pl / Uu, ph = pl - n * Uu, e = e0 + (n < (unsigned)A ? n : (unsigned)A - 1u);
+            const bool wrap = ph + 1u == Uu;
+            const unsigned cell = (e >> 8) * LDS_K2_STRIDE + (e & 255u);
+            const unsigned dcell = wrap ? ((e & 255u) == 255u ? LDS_K2_STRIDE - 255u : 1u) : 0u;
+            tab_pos[idx] = (int)idx < T ? ((cell << 19) | (dcell << 10) | ((wrap ? 0u : ph + 1u) << 5) | ph) : (31u | (31u << 5));
+            tab_mu[idx] = 0.25f;
+        }
+    } else {
     // ---- 0. which outputs are this block's, and where each of them sits
     // positions on the upsampled grid, absolute (relative to the launch's first input sample):
     // P = in_off U + floor(t); the block (pair) owns Plo <= P < Phi.  Call c emitted the outputs with
@@ -214,7 +238,7 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
     lds_barrier();
     int k_lo[NC], n_part[NC], idx_base[NC + 1], run_lo[NC];
     idx_base[0] = 0;
-    long long k_first = cc[0].k_first + __builtin_amdgcn_readfirstlane(s_bound[0]);
+    k_first = cc[0].k_first + __builtin_amdgcn_readfirstlane(s_bound[0]);
     bool have_first = false;
 #pragma unroll
     for (int i = 0; i < NC; i++) {
@@ -227,7 +251,7 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
             have_first = true;
         }
     }
-    const int T = idx_base[NC];                  // <= 256 KPT (launcher)
+    T = idx_base[NC];                            // <= 256 KPT (launcher)
     if (T == 0) return;                          // uniform: nothing lands here (the block behind a stream that ends on a block seam)
 
     // The table, [output of the block]: the byte address in the exchange buffer of the output's first phase sample << 19 |
@@ -286,6 +310,7 @@ __global__ __launch_bounds__(256, KPT <= 9 ? 3 : 2) void poly_gen4096_kernel(Pol
             }
         }
     }
+    }                                            // (!NOPRO)
     lds_barrier();                               // the runs are dead: the buffer is the exchange buffer from here on
 
     // ---- twiddle bases (fir_fft.hip: W^(e (4a + b)) = q[a] p[b]), re-read where a stage needs them: the index is made
@@ -468,6 +493,16 @@ int launch_poly_gen(const PolyGenArgs &a0, int max_runs, float step, int n_chann
     if (nblk > 0x7fffffffLL) return SFE_ESTATE;
     dim3 grid((unsigned)nblk, (unsigned)n_channels), block(256);
     const int kpt = (per_block + 255) / 256;
+#ifdef SFE_DIAG
+    // SFE_GEN_NOPRO=1 (scripts/ab_general.py): the prologue ablation, complex float32 streams at up to nine outputs per thread only
+    if (const char *e = getenv("SFE_GEN_NOPRO"))
+        if (atoi(e) && !a.real && !a.in_u8 && kpt <= 9) {
+            a.diag_T = per_block - 3;                     // (never more outputs than the law emits: the synthetic blocks write T each)
+            hipLaunchKernelGGL((poly_gen4096_kernel<9, false, false, true>), grid, block, 0, s, a);
+            SFE_HIP(hipGetLastError());
+            return SFE_OK;
+        }
+#endif
 #define SFE_GEN(KPTv, REALv)                                                                           \
     do {                                                                                              \
         if (a.in_u8) hipLaunchKernelGGL((poly_gen4096_kernel<KPTv, REALv, true>), grid, block, 0, s, a);      \
