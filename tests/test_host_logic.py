@@ -437,3 +437,35 @@ def test_bench_telemetry_never_raises():
     got = bench.telemetry({"torch": torch}, Leg(), 40.0)
     assert isinstance(got, dict) and ("error" in got or "reads_while_running" in got)
     json.dumps(got)
+
+
+def test_time_law_of_the_library_and_of_the_oracle_agree_call_by_call_property(L, orc):
+    """Property test (hypothesis): the library's host replay of the reference's float32 time law (sfe_dsp_rs_plan = timelaw.h:
+    time_law, what every GPU path places its outputs by) and the oracle's restatement of libdsp/resample.cxx:119-150
+    (sfe_oracle.c: timelaw_run, driven without samples by orc_resample_skip_calls) walk the SAME sequence of states: after every
+    call the same number of outputs and bit for bit the same (m_pos, m_mu, m_is_leftover) -- for random upsampling factors, call
+    lengths, rates from 1 / U upwards (a step of exactly 1 included) and streams of calls of unequal length."""
+    from hypothesis import given, settings, strategies as hst
+    from simplefe_amd import api, lib
+
+    @settings(max_examples=120, deadline=None)
+    @given(U=hst.integers(1, 8), B=hst.integers(1, 700), frac=hst.floats(0.0, 1.0), top=hst.sampled_from([1.0, 1.5, 3.0, 9.0, 40.0]),
+           cuts=hst.lists(hst.integers(1, 700), min_size=1, max_size=12))
+    def prop(U, B, frac, top, cuts):
+        lo = 1.0 / U
+        rate = float(np.float32(lo + frac * (max(top, lo) - lo)))
+        while float(np.float32(rate)) < lo:                       # the reference refuses rate < 1 / U (resample.cxx:91)
+            rate = float(np.nextafter(np.float32(rate), np.float32(np.inf)))
+        taps = np.ones(U, np.float32)
+        o = orc.Resample(taps, U, 700)
+        st = lib.TimeState(0, 0.0, 0)
+        for m in [min(c, 700) for c in cuts] + [B]:
+            out_len = m * U + 8                                   # a step is >= 1: never the limit
+            p, w = api.rs_plan(st, U, m, out_len, rate)
+            k = o.skip_calls(1, m, rate)
+            assert k == len(p), (U, m, rate)
+            pos, mu, left = o.get_time()
+            assert (pos, left) == (st.pos, st.leftover) and np.float32(mu).tobytes() == np.float32(st.mu).tobytes(), (U, m, rate, pos, st.pos, mu, st.mu)
+            if len(p):
+                assert np.all(np.diff(p.astype(np.int64)) >= 1) and np.all((w >= 0) & (w < 1))
+    prop()
