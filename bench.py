@@ -149,7 +149,7 @@ def pmc_traffic(workload_key):
                 best = d
     if best is None:
         return None, False
-    if best.get("csrc_sha256") != _b.csrc_hash():
+    if best.get("csrc_sha256") != _b.csrc_hash(best.get("csrc_kind")):      # the files of this workload's kernel (older passes: every kernel source)
         return None, True
     return best["hbm_bytes_per_launch"], False
 

@@ -11,7 +11,7 @@ for WL in fir decimate resample; do
   O=$R/gpurun_out/prof_${TAG}_${WL}
   mkdir -p $O
   # the kernel sources these counters belong to (bench.py reports roofline.traffic only while this matches the tree)
-  (cd $R && python3 -m simplefe_amd.build --hash) > $O/csrc_hash.txt
+  (cd $R && python3 -m simplefe_amd.build --hash $WL) > $O/csrc_hash.txt
   # --no-others: the headline kernel alone (the default line's other_configs legs launch the same
   # kernel name on other shapes, which would mix into the per-name average)
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --workload $WL --no-cpu --no-others > $O/kt.log 2>&1 || exit 1
@@ -25,7 +25,7 @@ for SHAPE in "64 30" "32 29" "16 28" "8 27"; do
   set -- $SHAPE
   O=$R/gpurun_out/prof_${TAG}_fir_$1ch
   mkdir -p $O
-  (cd $R && python3 -m simplefe_amd.build --hash) > $O/csrc_hash.txt
+  (cd $R && python3 -m simplefe_amd.build --hash fir) > $O/csrc_hash.txt
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --channels $1 --log2n $2 --steps 3 --warmup 1 --no-cpu --no-others > $O/fetch.log 2>&1 || exit 1
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --channels $1 --log2n $2 --steps 3 --warmup 1 --no-cpu --no-others > $O/write.log 2>&1 || exit 1
 done

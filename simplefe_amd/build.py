@@ -37,21 +37,49 @@ def _deps():
         os.path.join(os.path.dirname(HERE), "include", "*.h"))
 
 
-def csrc_hash():
-    """sha256 over the KERNEL sources (csrc/*.hip and csrc/*.h except HOST_SOURCES, the host side: handles, plans,
-    launch choices -- what the counters count is the kernels' traffic; file names and CODE: `//` comments, blank
-    lines and indentation are left out, so that rewording a comment does not orphan a counter pass).
+# the files that define one workload's kernel (round 5): a counter pass is stamped with the hash of THESE, so that a change to another
+# kernel's file does not orphan it.  None = every kernel source.
+KERNEL_FILES = {"fir": ("fir_fft.hip", "fft16.h", "common.h"), "resample": ("poly_fft.hip", "fft16.h", "common.h"),
+                "decimate": ("polyphase.hip", "common.h")}
+
+
+def csrc_hash(kind=None):
+    """sha256 over the KERNEL sources -- csrc/*.hip and csrc/*.h except HOST_SOURCES (the host side: handles, plans, launch
+    choices; what the counters count is the kernels' traffic), or, with `kind` in KERNEL_FILES, the files of that workload's
+    kernel only.  File names and CODE: `//` comments, blank lines and indentation are left out, and so is everything between
+    `#ifdef SFE_DIAG` and its `#else` / `#endif` (the diagnostic library's switches: not in the product kernels), so that
+    rewording a comment or adding a diagnostic variant does not orphan a counter pass.
     Stamped into profiles/pmc_*.json when counters are collected; bench.py reports roofline.traffic
     only while the stamp matches the tree (otherwise traffic: null, traffic_stale: true)."""
     import hashlib
     import re
     h = hashlib.sha256()
-    for p in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))):
+    paths = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")))
+    if kind is not None:
+        paths = [p for p in paths if os.path.basename(p) in KERNEL_FILES[kind]]
+    for p in paths:
         if os.path.basename(p) in HOST_SOURCES:
             continue
         h.update(os.path.basename(p).encode() + b"\0")
+        depth, skip_at = 0, None          # preprocessor nesting; the depth at which a diagnostic block opened
         for line in open(p, errors="replace"):
             code = re.sub(r"\s+", " ", re.sub(r"//.*$", "", line)).strip()
+            if code.startswith("#if"):
+                depth += 1
+                if skip_at is None and re.match(r"#ifdef SFE_DIAG\b", code):
+                    skip_at = depth
+                    continue
+            elif code.startswith("#else") and skip_at == depth:
+                skip_at = -depth           # the product's branch of a diagnostic conditional: hashed
+                continue
+            elif code.startswith("#endif"):
+                closing = depth
+                depth -= 1
+                if skip_at is not None and abs(skip_at) == closing:
+                    skip_at = None
+                    continue
+            if skip_at is not None and skip_at > 0:
+                continue
             if code:
                 h.update(code.encode() + b"\n")
         h.update(b"\0")
@@ -181,7 +209,8 @@ def build_lib(force=False, verbose=False, extra=(), diag=False):
 
 
 if __name__ == "__main__":
-    if "--hash" in sys.argv:
-        print(csrc_hash())
+    if "--hash" in sys.argv:          # --hash [fir|resample|decimate]
+        k = sys.argv[sys.argv.index("--hash") + 1] if len(sys.argv) > sys.argv.index("--hash") + 1 else None
+        print(csrc_hash(k if k in KERNEL_FILES else None))
         raise SystemExit(0)
     print(build_lib(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv))

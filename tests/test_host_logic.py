@@ -469,3 +469,27 @@ def test_time_law_of_the_library_and_of_the_oracle_agree_call_by_call_property(L
             if len(p):
                 assert np.all(np.diff(p.astype(np.int64)) >= 1) and np.all((w >= 0) & (w < 1))
     prop()
+
+
+def test_kernel_source_hash_ignores_comments_and_diagnostic_blocks_and_other_kernels(tmp_path, monkeypatch):
+    """simplefe_amd/build.py: csrc_hash -- the stamp a counter pass carries.  A reworded comment, a change inside
+    `#ifdef SFE_DIAG` ... `#else` / `#endif`, or a change to ANOTHER kernel's file must not orphan a pass; a change to the
+    kernel's own code, or to the product branch of a diagnostic conditional, must."""
+    from simplefe_amd import build as b
+    monkeypatch.setattr(b, "CSRC", str(tmp_path))
+
+    def write(fir_body, other="int other;\n"):
+        (tmp_path / "fir_fft.hip").write_text(fir_body)
+        (tmp_path / "fft16.h").write_text("// header\nint f16;\n")
+        (tmp_path / "common.h").write_text("int common;\n")
+        (tmp_path / "polyphase.hip").write_text(other)
+        return b.csrc_hash("fir"), b.csrc_hash("decimate"), b.csrc_hash()
+
+    base = "int a;   // one\n#ifdef SFE_DIAG\nint diag_only;\n#if 1\nint nested;\n#endif\n#else\nint product_branch;\n#endif\nint b;\n"
+    h0 = write(base)
+    assert write(base.replace("// one", "// another wording"))[0] == h0[0]
+    assert write(base.replace("int diag_only;", "int diag_only; int more_diag;").replace("int nested;", "int nested2;")) == h0
+    fir, dec, all_ = write(base, other="int other; int changed;\n")
+    assert fir == h0[0] and dec != h0[1] and all_ != h0[2]
+    assert write(base.replace("int b;", "int b2;"))[0] != h0[0]
+    assert write(base.replace("int product_branch;", "int product_branch2;"))[0] != h0[0]
