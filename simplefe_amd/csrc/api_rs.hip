@@ -434,7 +434,11 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
             ta.hl = r->hl;
             ta.Lp = pl->Lp;
             ta.e_max = pl->e_max;
-            rc = launch_poly_tiled(*pl, ta, r->data_complex, r->exact_stream, r->in_u8, r->n_channels, s);
+            // shapes outside the compiled tables that mostly read, odd input step, cf32, fused arithmetic: the LDS-DMA form (poly_rt_dma.hip)
+            rc = SFE_ESTATE;
+            if (r->data_complex && !r->exact_stream && !r->in_u8 && !poly_tiled_is_compiled(pl->SP, pl->UP, pl->Lp))
+                rc = launch_poly_rt_dma(*pl, ta, r->n_channels, s);
+            if (rc == SFE_ESTATE) rc = launch_poly_tiled(*pl, ta, r->data_complex, r->exact_stream, r->in_u8, r->n_channels, s);
         } else {
             if (r->in_u8) {
                 set_error("rs_process_stream: u8 input needs a tiled kernel for this rate/tap shape");
