@@ -1,6 +1,7 @@
 // api_rs.hip -- the resample / decimate handle behind sfe_rs_t (libdsp/resample.cxx:37-153, libdsp/decimate.cxx:37-140):
 // the time law and its run memo, the choice of kernel, carried state, and the sfe_dsp_rs_* entry points.  Host code only.
 #include "host.h"
+#include <stdlib.h>
 
 namespace sfe {
 
@@ -436,8 +437,12 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
             ta.e_max = pl->e_max;
             // shapes outside the compiled tables that mostly read, odd input step, cf32, fused arithmetic: the LDS-DMA form (poly_rt_dma.hip)
             rc = SFE_ESTATE;
-            if (r->data_complex && !r->exact_stream && !r->in_u8 && !poly_tiled_is_compiled(pl->SP, pl->UP, pl->Lp))
-                rc = launch_poly_rt_dma(*pl, ta, r->n_channels, s);
+            bool try_dma = r->data_complex && !r->exact_stream && !r->in_u8 && !poly_tiled_is_compiled(pl->SP, pl->UP, pl->Lp);
+#ifdef SFE_DIAG
+            if (const char *e = getenv("SFE_RT_DMA_FORCE"))        // scripts/ab_dec8_dma.py: the LDS-DMA form also where a compile-time kernel exists
+                if (atoi(e) && r->data_complex && !r->exact_stream && !r->in_u8) try_dma = true;
+#endif
+            if (try_dma) rc = launch_poly_rt_dma(*pl, ta, r->n_channels, s);
             if (rc == SFE_ESTATE) rc = launch_poly_tiled(*pl, ta, r->data_complex, r->exact_stream, r->in_u8, r->n_channels, s);
         } else {
             if (r->in_u8) {
