@@ -8,7 +8,7 @@ cd $R
 for D in 1 0; do
   export SFE_RT_DMA=$D
   echo "== SFE_RT_DMA=$D" >> $O/shapes_rt_dma.txt
-  BARE=1 EXTRA=2 SHAPES="by 6,by 10,by 12,by 16,by 24,by 32,by 48,6/5,10/3,by 7,7/4" timeout -k 10 400 python3 scripts/time_shapes.py >> $O/shapes_rt_dma.txt 2>&1 || echo failed $D
+  BARE=1 EXTRA=2 SHAPES="4/5,6/5,5/6,7/8,3/5,2/5,9/5,11/8,7/3,by 7" timeout -k 10 400 python3 scripts/time_shapes.py >> $O/shapes_rt_dma.txt 2>&1 || echo failed $D
 done
 unset SFE_RT_DMA
 cut -c1-125 $O/shapes_rt_dma.txt

@@ -14,8 +14,8 @@
 // 2 SP dwords, which over a half-wave of 32 lanes visits every even bank once (gcd(SP, 32) = 1): conflict-free 8-byte reads.  A
 // contiguous tile is exactly what LDS-DMA lands (global_load_lds_dwordx4: 64 lanes x 16 bytes = 1 KiB per instruction, no VGPR
 // destination, no scatter): interior tiles are fetched that way, tiles at a stream's ends by guarded loads into the same layout.
-// EVEN SP: see PAIR below.  Shapes: complex float32 streams, fused arithmetic, SP >= 3, UP = 1 ... 8 with UP < SP (the shapes that mostly read);
-// everything else keeps poly_rt_kernel.  VERDICT r4 item 6; profiles/r05/shapes_rt_dma.txt: /7 0.54 -> 0.43 ms, 7/4 0.72 -> 0.59,
+// EVEN SP: see PAIR below.  Shapes: complex float32 streams, fused arithmetic, SP >= 2, UP = 1 ... 8 (three or more outputs per m leave
+// through the waves' LDS regions as contiguous kilobytes); SP = 1, exact mode, real and u8 streams keep poly_rt_kernel / poly_rt1_kernel.  VERDICT r4 item 6; profiles/r05/shapes_rt_dma.txt: /7 0.54 -> 0.43 ms, 7/4 0.72 -> 0.59,
 // /9 0.48 -> 0.38, /13 0.50 -> 0.40, /15 0.52 -> 0.39, 9/4 0.73 -> 0.58, 9/2 0.56 -> 0.46 (2^28 cf32, two processes each way).
 #include <stdint.h>
 #ifdef SFE_DIAG
@@ -148,6 +148,31 @@ __global__ __launch_bounds__(256) void poly_rt_dma_kernel(PolyTiledArgs a)
 #pragma unroll
         for (int j = 0; j < MB; j++) {
             const int mi = mi0 + 256 * j;
+            if constexpr (UPM >= 3) {
+                // Three or more outputs per m: a lane's UP results are 8 UP bytes from its neighbour's -- 8- or 16-byte pieces at that
+                // stride, the worst pattern there is for a launch that writes much.  A wave's 64 m are 64 UP CONSECUTIVE outputs: laid out in
+                // a region of LDS of the wave's own (rows of UP + 1 cells: the writes spread over the banks) and read back pair by pair
+                // they leave as whole contiguous kilobytes; nothing but the wave touches the region and a wave's LDS operations
+                // execute in order: no barrier (poly_rt_kernel, DESIGN.md 4.2d, has the same).
+                const int mi_w = ((int)(tid & ~63u)) + (mi0 - (int)tid) + 256 * j;       // the wave's first m of this round
+                const long long kw = (long long)UP * (m0 + mi_w);
+                if (a.y_off && (reinterpret_cast<uintptr_t>(out) & 15u) == 0 && mi_w + 64 <= TMr && kw + 64LL * UP <= a.n_out) {      // uniform over the wave
+                    v2f *Yw = reinterpret_cast<v2f *>(smem + a.y_off) + (tid >> 6) * (64u * (UPM + 1));
+                    const unsigned lane = tid & 63u;
+#pragma unroll
+                    for (int r = 0; r < UPM; r++) Yw[lane * (UPM + 1) + r] = acc[j][r];
+#pragma unroll
+                    for (int i = 0; i < (32 * UPM + 63) / 64; i++) {
+                        const unsigned pi = lane + 64u * i;                              // pair of outputs 2 pi, 2 pi + 1
+                        if ((32 * UPM) % 64 == 0 || pi < 32u * UPM) {
+                            const unsigned o0 = 2u * pi, o1 = o0 + 1u;
+                            const v2f lo2 = Yw[(o0 / UPM) * (UPM + 1) + o0 % UPM], hi2 = Yw[(o1 / UPM) * (UPM + 1) + o1 % UPM];
+                            __builtin_nontemporal_store((v4f){lo2.x, lo2.y, hi2.x, hi2.y}, reinterpret_cast<v4f *>(out + kw + o0));
+                        }
+                    }
+                    continue;
+                }
+            }
             if (mi >= TMr) continue;
             const long long k = (long long)UP * (m0 + mi);
             if constexpr (UPM >= 2) {
@@ -182,11 +207,9 @@ int rt_dma_tile_m(int SP, int UP)
 int launch_poly_rt_dma(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int n_channels, hipStream_t s)
 {
     const int SP = plan.SP, UP = plan.UP;
-    if (SP < 3 || SP > 64 || UP < 1 || UP > 8 || UP >= SP || plan.Lp <= 0 || !plan.d_Gt) return SFE_ESTATE;
+    // SP = 1 (the pure interpolators) stays with poly_rt1_kernel: there the LDS bandwidth binds and that kernel's pairs of m halve it
+    if (SP < 2 || SP > 64 || UP < 1 || UP > 8 || plan.Lp <= 0 || !plan.d_Gt) return SFE_ESTATE;
     if (!(SP & 1) && (plan.Lp & 1)) return SFE_ESTATE;             // (the pairs want an even tap count: the planner's rows are multiples of SP)
-    // an ODD number of outputs per m leaves here as 8-byte pieces at a stride of 8 UP bytes: fine while the launch mostly reads (7/3, 9/5:
-    // +5 ... +15 %), a loss where it writes nearly as much (6/5: -4.5 %) -- there poly_rt_kernel's lane-paired stores stay
-    if ((UP & 1) && UP >= 3 && 5 * UP > 3 * SP) return SFE_ESTATE;
     // 16-byte lanes: every channel's first sample on a 16-byte boundary
     if ((reinterpret_cast<uintptr_t>(a0.in) & 15u) || (n_channels > 1 && (a0.in_stride & 1))) return SFE_ESTATE;
 #ifdef SFE_DIAG
@@ -197,8 +220,13 @@ int launch_poly_rt_dma(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int n
     a.SP = SP;
     a.UP = UP;
     a.tm = rt_dma_tile_m(SP, UP);
-    const size_t lds = ((((size_t)SP * a.tm + plan.Lp + 1) * 8 + 1023) >> 10) << 10;        // whole 1 KiB pieces
+    size_t lds = ((((size_t)SP * a.tm + plan.Lp + 1) * 8 + 1023) >> 10) << 10;        // whole 1 KiB pieces
+    a.y_off = 0;
     if (lds > 60 * 1024) return SFE_ESTATE;
+    if (UP >= 3 && lds + (size_t)4 * 64 * (UP + 1) * 8 <= 60 * 1024) {      // + the four waves' output regions: 64 rows of UP + 1 cells each
+        a.y_off = (unsigned)lds;                                          // (where they do not fit -- 11/8 -- the outputs leave lane by lane)
+        lds += (size_t)4 * 64 * (UP + 1) * 8;
+    }
     const long long mtot = (a.n_out + UP - 1) / UP;
     const long long tiles = (mtot + a.tm - 1) / a.tm;
     if (tiles > 0x7fffffffLL) return SFE_ESTATE;

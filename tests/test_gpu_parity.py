@@ -755,10 +755,12 @@ def test_rs_shapes_outside_the_compiled_tables(api, L, orc, name, U, step, cplx)
 @pytest.mark.parametrize("name,U,step", [("/3", 1, 3), ("/5", 1, 5), ("/7", 1, 7), ("/9", 1, 9), ("/15", 1, 15), ("/63", 1, 63), ("5/2", 2, 5), ("7/4", 4, 7),
                                          ("9/4", 4, 9), ("9/2", 2, 9), ("7/3", 3, 7), ("9/5", 5, 9), ("13/6", 6, 13), ("9/7", 7, 9), ("11/8", 8, 11),
                                          ("/6", 1, 6), ("/10", 1, 10), ("/12", 1, 12), ("/16", 1, 16), ("/24", 1, 24), ("/48", 1, 48), ("/64", 1, 64),
-                                         ("6/5", 5, 6), ("10/3", 3, 10), ("12/5", 5, 12), ("14/4", 4, 14)])
+                                         ("6/5", 5, 6), ("10/3", 3, 10), ("12/5", 5, 12), ("14/4", 4, 14),
+                                         ("4/5", 5, 4), ("5/6", 6, 5), ("7/8", 8, 7), ("9/8", 8, 9), ("2/5", 5, 2), ("3/5", 5, 3), ("3/7", 7, 3), ("3/8", 8, 3), ("2/7", 7, 2)])
 def test_rt_shapes_fetched_by_lds_dma_and_read_in_place(api, L, orc, name, U, step):
-    """Round 5 (poly_rt_dma.hip): complex float32 streams whose input step SP exceeds UP = 1 ... 8 (odd SP: 8-byte reads at a
-    conflict-free stride; even SP: two taps per aligned 16-byte read), fused arithmetic, take the
+    """Round 5 (poly_rt_dma.hip): complex float32 streams at an input step SP >= 2 with UP = 1 ... 8 outputs per SP inputs (odd SP: 8-byte
+    reads at a conflict-free stride; even SP: two taps per aligned 16-byte read; UP >= 3: outputs through the waves' LDS regions), fused
+    arithmetic, take the
     runtime-shape kernel whose tile lands in the LDS contiguously by LDS-DMA (lane m reads sample SP m + qt at a conflict-free
     stride).  Same law, same accumulation order as poly_rt_kernel: held to the same bar -- within 1e-5 of the oracle
     (libdsp/decimate.cxx:132-140 through orc.Resample), equal to the exact kernel's length, and BIT-IDENTICAL to the runtime-shape
