@@ -559,7 +559,7 @@ def make_rs_leg(ctx, which, log2n, in_fmt="f32", short_proto=False):
     return leg
 
 
-def make_general_rate_leg(ctx, log2n=28, rate=1.77, interpolate=0):
+def make_general_rate_leg(ctx, log2n=28, rate=1.77, interpolate=0, decimate=0):
     """the general (non-integer-step) rate at bulk size -- BASELINE cfg3's 381-tap prototype in 3 phases at
     rate 1.77 (the rate of the reference's own driver, libdsp/test/test_decimate.py:24), 2^28 cf32 in.  The library's default
     dispatch takes the transform-domain kernel (poly_gen.hip).  Not a BASELINE config: an other_configs row.
@@ -585,6 +585,15 @@ def make_general_rate_leg(ctx, log2n=28, rate=1.77, interpolate=0):
         leg.name = "interpolate_x%d" % U
         leg.workload = "interpolate x%d (resample at rate 1/%d), %d-tap prototype (32 per arm), 2^%d cf32 in" % (U, U, len(taps), log2n)
         leg.key = "resample_x%d_cf32_2p%d" % (U, log2n)
+    if decimate:
+        # an integer step with no compile-time kernel (round 5): the runtime-shape kernel whose tile arrives by LDS-DMA and is read in place
+        # (poly_rt_dma.hip) -- decimate by `decimate`, 32 taps
+        U = 1
+        taps = synth.lowpass_taps(32, 0.9 / decimate, gain=1.0)
+        rate = float(decimate)
+        leg.name = "decimate_by_%d" % decimate
+        leg.workload = "decimate by %d, 32-tap anti-alias FIR (a shape outside the compiled tables), 2^%d cf32 in" % (decimate, log2n)
+        leg.key = "decimate%d_cf32_2p%d" % (decimate, log2n)
     x = torch.empty(n * 2, dtype=torch.float32, device=dev)
     api.check(L.sfe_dsp_synth_fill(x.data_ptr(), 2 * n, synth.SEED, 0, 0, stream))
     out_cap = int(n / rate) + 4096
@@ -592,7 +601,7 @@ def make_general_rate_leg(ctx, log2n=28, rate=1.77, interpolate=0):
     leg.y = torch.empty(out_cap * 2, dtype=torch.float32, device=dev)
     leg.input_spec = [(0, 2 * n, 0)]
     leg.obj = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=True, n_channels=1, device=ctx["local_rank"])
-    leg.kernel = "poly_rt1_kernel" if interpolate else "poly_gen4096_kernel"
+    leg.kernel = "poly_rt1_kernel" if interpolate else ("poly_rt_dma_kernel" if decimate else "poly_gen4096_kernel")
     leg.n_out = 0
     sp, yp = x.data_ptr(), leg.y.data_ptr()
 
@@ -606,7 +615,7 @@ def make_general_rate_leg(ctx, log2n=28, rate=1.77, interpolate=0):
         from oracle import binding as orc
         m = 1 << 20
         r = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=True, n_channels=1, device=ctx["local_rank"])
-        if not interpolate:
+        if not interpolate and not decimate:
             r.set_algo(lib.RS_ALGO_FFT)         # the kernel the timed leg's bulk calls take, also at this size
         y = torch.empty((int(m / rate) + 64) * 2, dtype=torch.float32, device=dev)
         k = r.process_stream(sp, m, y.data_ptr(), y.numel() // 2, rate, stream=stream)
@@ -906,6 +915,7 @@ def main():
                   lambda: make_rs_leg(ctx, "decimate", 30),
                   lambda: make_general_rate_leg(ctx),
                   lambda: make_general_rate_leg(ctx, interpolate=2),
+                  lambda: make_general_rate_leg(ctx, decimate=7),
                   lambda: make_fir_leg(ctx, "fir_64ch", synth.taps_cfg2(), 1 << 24, 64),
                   lambda: make_fir_leg(ctx, "fir_64ch_pctaps", synth.taps_per_channel(64), 1 << 24, 64, per_channel=True,
                                        x_share=next(l.x for l in others if l.name == "fir_64ch")),

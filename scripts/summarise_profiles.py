@@ -13,7 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from simplefe_amd.build import csrc_hash  # noqa: E402
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = next((a for a in sys.argv[1:] if not a.startswith("--")), "r05")
+# --tables-only: copy the bench lines and tables of gpurun_out/prof_<tag>_tables/ only -- the counter summaries (profiles/pmc_<tag>_*.json) are left as
+# committed (round 5: a second run of this script over the same gpurun_out/ re-stamped them with the hash file of the collection)
+TABLES_ONLY = "--tables-only" in sys.argv
 KEYS = {"fir": ("fir256_cf32_2p28", "fir_fft4096", 16 * 2 ** 28),
         "decimate": ("decimate8_cf32_2p30", "poly_tiled", 9 * 2 ** 30),
         "resample": ("resample5o3_cf32_2p28", "poly_fft256", None),
@@ -21,7 +24,7 @@ KEYS = {"fir": ("fir256_cf32_2p28", "fir_fft4096", 16 * 2 ** 28),
         "fir_64ch": ("fir256_cf32_2p30_64ch", "fir_fft4096", 16 * 2 ** 30), "fir_32ch": ("fir256_cf32_2p29_32ch", "fir_fft4096", 16 * 2 ** 29),
         "fir_16ch": ("fir256_cf32_2p28_16ch", "fir_fft4096", 16 * 2 ** 28), "fir_8ch": ("fir256_cf32_2p27_8ch", "fir_fft4096", 16 * 2 ** 27)}
 os.makedirs(os.path.join(ROOT, "profiles", tag), exist_ok=True)
-for wl, (key, ksub, alg) in KEYS.items():
+for wl, (key, ksub, alg) in ({} if TABLES_ONLY else KEYS).items():
     d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{wl}")
     if not os.path.isdir(d):
         continue
