@@ -435,14 +435,14 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
             ta.hl = r->hl;
             ta.Lp = pl->Lp;
             ta.e_max = pl->e_max;
-            // shapes outside the compiled tables that mostly read, odd input step, cf32, fused arithmetic: the LDS-DMA form (poly_rt_dma.hip)
+            // shapes outside the compiled tables, float32 streams (complex or real), fused arithmetic: the tile by LDS-DMA, read in place (poly_rt_dma.hip)
             rc = SFE_ESTATE;
-            bool try_dma = r->data_complex && !r->exact_stream && !r->in_u8 && !poly_tiled_is_compiled(pl->SP, pl->UP, pl->Lp);
+            bool try_dma = !r->exact_stream && !r->in_u8 && !poly_tiled_is_compiled(pl->SP, pl->UP, pl->Lp);
 #ifdef SFE_DIAG
             if (const char *e = getenv("SFE_RT_DMA_FORCE"))        // scripts/ab_dec8_dma.py: the LDS-DMA form also where a compile-time kernel exists
-                if (atoi(e) && r->data_complex && !r->exact_stream && !r->in_u8) try_dma = true;
+                if (atoi(e) && !r->exact_stream && !r->in_u8) try_dma = true;
 #endif
-            if (try_dma) rc = launch_poly_rt_dma(*pl, ta, r->n_channels, s);
+            if (try_dma) rc = launch_poly_rt_dma(*pl, ta, r->data_complex, r->n_channels, s);
             if (rc == SFE_ESTATE) rc = launch_poly_tiled(*pl, ta, r->data_complex, r->exact_stream, r->in_u8, r->n_channels, s);
         } else {
             if (r->in_u8) {

@@ -757,46 +757,49 @@ def test_rs_shapes_outside_the_compiled_tables(api, L, orc, name, U, step, cplx)
                                          ("/6", 1, 6), ("/10", 1, 10), ("/12", 1, 12), ("/16", 1, 16), ("/24", 1, 24), ("/48", 1, 48), ("/64", 1, 64),
                                          ("6/5", 5, 6), ("10/3", 3, 10), ("12/5", 5, 12), ("14/4", 4, 14),
                                          ("4/5", 5, 4), ("5/6", 6, 5), ("7/8", 8, 7), ("9/8", 8, 9), ("2/5", 5, 2), ("3/5", 5, 3), ("3/7", 7, 3), ("3/8", 8, 3), ("2/7", 7, 2)])
-def test_rt_shapes_fetched_by_lds_dma_and_read_in_place(api, L, orc, name, U, step):
-    """Round 5 (poly_rt_dma.hip): complex float32 streams at an input step SP >= 2 with UP = 1 ... 8 outputs per SP inputs (odd SP: 8-byte
-    reads at a conflict-free stride; even SP: two taps per aligned 16-byte read; UP >= 3: outputs through the waves' LDS regions), fused
-    arithmetic, take the
-    runtime-shape kernel whose tile lands in the LDS contiguously by LDS-DMA (lane m reads sample SP m + qt at a conflict-free
-    stride).  Same law, same accumulation order as poly_rt_kernel: held to the same bar -- within 1e-5 of the oracle
-    (libdsp/decimate.cxx:132-140 through orc.Resample), equal to the exact kernel's length, and BIT-IDENTICAL to the runtime-shape
-    kernel it replaces, which still serves (a) a stream whose first sample is not on a 16-byte boundary and (b) channels at an odd
-    stride -- so the same samples through those two calls must give the same bits.  Lengths that end inside a tile, two
-    calls with carried state, three channels."""
+@pytest.mark.parametrize("cplx", [True, False])
+def test_rt_shapes_fetched_by_lds_dma_and_read_in_place(api, L, orc, name, U, step, cplx):
+    """Round 5 (poly_rt_dma.hip): float32 streams -- complex, and real (libdsp's native type) -- at an input step SP >= 2 with UP = 1 ... 8
+    outputs per SP inputs (odd SP: single-sample reads at a conflict-free stride; even SP: 2 or 4 taps per aligned wide read; UP >= 3:
+    outputs through the waves' LDS regions), fused arithmetic, take the runtime-shape kernel whose tile lands in the LDS contiguously
+    by LDS-DMA and is read in place.  Same law, same accumulation order as poly_rt_kernel: held to the same bar -- within 1e-5 of the
+    oracle (libdsp/decimate.cxx:132-140 through orc.Resample), equal to the exact kernel's length, and BIT-IDENTICAL to the
+    runtime-shape kernel it replaces, which still serves (a) a stream whose first sample is not on a 16-byte boundary and (b)
+    channels at a stride that is not a multiple of 16 bytes -- so the same samples through those two calls must give the same bits.
+    Lengths that end inside a tile, two calls with carried state, three channels."""
     rate = float(np.float32(step) / np.float32(U))
     taps = synth.lowpass_taps(32 * U - (1 if U > 1 else 0), 0.9 * min(1.0 / U, 1.0 / step), gain=float(U))
+    w = 2 if cplx else 1
     n, nch = 5 * 4096 * max(1, step // 4) + 1235, 3
-    x = np.stack([synth.synth_cf32(n, ch=70 + c) for c in range(nch)])
-    refs = [[orc.Resample(taps, U, 4096).stream(np.ascontiguousarray(x[c, part::2]), rate)[0] for part in (0, 1)] for c in range(nch)]
+    x = np.stack([synth.synth_f32(w * n, ch=70 + c) for c in range(nch)])
+    refs = [[orc.Resample(taps, U, 4096).stream(np.ascontiguousarray(x[c, part::w]), rate)[0] for part in range(w)] for c in range(nch)]
     cap = int(n / rate) + 16
+    cap += (-cap) % 4                               # channels of the output 16 bytes apart
 
     def run(offset_floats, stride):
         """the three channels at `stride` samples apart, the buffer shifted by `offset_floats` floats; two calls"""
-        buf = np.zeros(offset_floats + 2 * stride * nch, np.float32)
+        buf = np.zeros(offset_floats + w * stride * nch, np.float32)
         for c in range(nch):
-            buf[offset_floats + 2 * stride * c: offset_floats + 2 * stride * c + 2 * n] = x[c]
+            buf[offset_floats + w * stride * c: offset_floats + w * stride * c + w * n] = x[c]
         d = api.DeviceArray.from_numpy(buf)
-        d_out = api.DeviceArray(2 * cap * nch)
-        r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=True, n_channels=nch)
+        d_out = api.DeviceArray(w * cap * nch)
+        r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=cplx, n_channels=nch)
         r.set_algo(L.RS_ALGO_DIRECT)
         cut = (n // 2) // 4096 * 4096
         k1 = r.process_stream(d.ptr + 4 * offset_floats, cut, d_out, cap, rate, in_stride=stride, out_stride=cap)
-        k2 = r.process_stream(d.ptr + 4 * offset_floats + 8 * cut, n - cut, d_out.ptr + 8 * k1, cap - k1, rate, in_stride=stride, out_stride=cap)
-        y = d_out.to_numpy().reshape(nch, 2 * cap)[:, : 2 * (k1 + k2)]
+        k2 = r.process_stream(d.ptr + 4 * offset_floats + 4 * w * cut, n - cut, d_out.ptr + 4 * w * k1, cap - k1, rate, in_stride=stride, out_stride=cap)
+        y = d_out.to_numpy().reshape(nch, w * cap)[:, : w * (k1 + k2)]
         return k1 + k2, y
 
-    k, y = run(0, n + (n & 1))                       # 16-byte aligned channels: the LDS-DMA kernel
-    ku, yu = run(2, n + 1 - (n & 1))                 # first sample 8 bytes off a 16-byte boundary, odd stride: poly_rt_kernel
+    al = (n + 3) // 4 * 4
+    k, y = run(0, al)                                # 16-byte aligned channels: the LDS-DMA kernel
+    ku, yu = run(w, al + 1)                          # first sample one sample off a 16-byte boundary, an odd stride: poly_rt_kernel
     assert k == ku and np.array_equal(y, yu), name
     for c in range(nch):
-        for part in (0, 1):
+        for part in range(w):
             ref = refs[c][part]
             assert len(ref) - k in (0, 1), (name, len(ref), k)
-            assert synth.rel_rms(y[c, part::2], ref[:k]) <= TOL, (name, c, part)
+            assert synth.rel_rms(y[c, part::w], ref[:k]) <= TOL, (name, c, part)
 
 
 # ----------------------------------------------------------------- edge cases / misuse
