@@ -8,12 +8,16 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from simplefe_amd import lib  # noqa: E402
+from simplefe_amd import build, lib  # noqa: E402
+if os.environ.get("DIAG") == "1":          # the diagnostic library: honours SFE_RT_DMA / SFE_RT_DMA_SP1 / SFE_RT_DMA_FORCE
+    lib.LIB_PATH = build.build_lib(diag=True)
 from simplefe_amd import api, synth  # noqa: E402
 
 n = 1 << int(os.environ.get("LOG2N", "29"))
 SHAPES = [("decimate by 6", 1, 6), ("decimate by 7", 1, 7), ("decimate by 8", 1, 8), ("decimate by 12", 1, 12), ("decimate by 16", 1, 16), ("7/4", 4, 7), ("7/3", 3, 7),
-          ("4/5", 5, 4), ("interpolate x2", 2, 1)]
+          ("4/5", 5, 4), ("interpolate x2", 2, 1), ("interpolate x3", 3, 1), ("interpolate x4", 4, 1), ("interpolate x8", 8, 1)]
+if os.environ.get("SHAPES"):
+    SHAPES = [s for s in SHAPES if any(w in s[0] for w in os.environ["SHAPES"].split(","))]
 x = api.DeviceArray(n)
 x.fill_synth(synth.SEED)
 t = api.Timer()

@@ -39,6 +39,8 @@ if os.environ.get("EXTRA") == "2":          # round 5: odd input steps, for the 
                ("11/8 (8 out per 11 in)", 8, 11), ("decimate by 10", 1, 10), ("decimate by 12", 1, 12), ("decimate by 24", 1, 24),
                ("decimate by 32", 1, 32), ("decimate by 48", 1, 48), ("6/5 (5 out per 6 in)", 5, 6), ("10/3 (3 out per 10 in)", 3, 10),
                ("5/6 (6 out per 5 in)", 6, 5), ("7/8 (8 out per 7 in)", 8, 7), ("3/5 (5 out per 3 in)", 5, 3), ("2/5 (5 out per 2 in)", 5, 2)]
+if os.environ.get("EXTRA") == "3":          # round 5: the interpolators between x4 and x8 (where does the LDS-DMA form overtake poly_rt1_kernel?)
+    SHAPES += [("interpolate x5 (rate 1/5)", 5, 1), ("interpolate x6 (rate 1/6)", 6, 1), ("interpolate x7 (rate 1/7)", 7, 1)]
 if os.environ.get("SHAPES"):
     want = os.environ["SHAPES"].split(",")
     SHAPES = [s for s in SHAPES if any(w in s[0] for w in want)]

@@ -437,7 +437,7 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
             ta.e_max = pl->e_max;
             // shapes outside the compiled tables, float32 streams (complex or real), fused arithmetic: the tile by LDS-DMA, read in place (poly_rt_dma.hip)
             rc = SFE_ESTATE;
-            bool try_dma = !r->exact_stream && !r->in_u8 && !poly_tiled_is_compiled(pl->SP, pl->UP, pl->Lp);
+            bool try_dma = !r->exact_stream && !r->in_u8 && (!poly_tiled_is_compiled(pl->SP, pl->UP, pl->Lp) || (pl->SP == 1 && !r->data_complex));
 #ifdef SFE_DIAG
             if (const char *e = getenv("SFE_RT_DMA_FORCE"))        // scripts/ab_dec8_dma.py: the LDS-DMA form also where a compile-time kernel exists
                 if (atoi(e) && !r->exact_stream && !r->in_u8) try_dma = true;

@@ -19,9 +19,9 @@
 // A contiguous tile is exactly what LDS-DMA lands (global_load_lds_dwordx4: 64 lanes x 16 bytes = 1 KiB per instruction, no VGPR
 // destination, no scatter): interior tiles are fetched that way -- from the 16-byte boundary at or below the tile's first sample --
 // tiles at a stream's ends by guarded loads into the same layout.
-// Shapes: complex AND real float32 streams (real: libdsp's native type), fused arithmetic, SP >= 2, UP = 1 ... 8; three or more outputs
-// per m leave through the waves' LDS regions as contiguous kilobytes.  SP = 1, exact mode and u8 streams keep poly_rt_kernel /
-// poly_rt1_kernel, and so do calls whose channels do not start on 16-byte boundaries.  VERDICT r4 item 6; profiles/r05/shapes_rt_dma.txt
+// Shapes: complex AND real float32 streams (real: libdsp's native type), fused arithmetic, SP >= 2 (real streams and complex x6 / x8: SP = 1
+// too), UP = 1 ... 8; three or more outputs per m leave through the waves' LDS regions as contiguous kilobytes.  Exact mode, u8 streams and
+// the other complex interpolators keep poly_rt_kernel / poly_rt1_kernel, and so do calls whose channels do not start on 16-byte boundaries.  VERDICT r4 item 6; profiles/r05/shapes_rt_dma.txt
 // (complex: /7 0.54 -> 0.43 ms, 7/4 0.72 -> 0.59, /13 0.50 -> 0.40, /48 0.49 -> 0.37, 10/3 0.71 -> 0.50 ...), profiles/r05/shapes_real.txt.
 #include <stdint.h>
 #ifdef SFE_DIAG
@@ -290,8 +290,17 @@ int launch_poly_rt_dma(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int d
 {
     const int SP = plan.SP, UP = plan.UP;
     const int esz = data_complex ? 8 : 4, a16 = 16 / esz;
-    // SP = 1 (the pure interpolators) stays with poly_rt1_kernel: there the LDS bandwidth binds and that kernel's pairs of m halve it
-    if (SP < 2 || SP > 64 || UP < 1 || UP > 8 || plan.Lp <= 0 || !plan.d_Gt) return SFE_ESTATE;
+    // SP = 1, the pure interpolators: REAL streams run here too (poly_rt1_kernel / poly_tiled_kernel<1, UP> on 4-byte samples: x3 0.33, x4 0.27, x8
+    // 0.13 of the roofline against 0.44, 0.53, 0.57 here); complex ones keep poly_rt1_kernel, whose pairs of m halve the LDS reads (x2 ... x5
+    // 2-17 % ahead of this kernel, x7 level), except x6 and x8 (+6 % here: rows of 48 / 64 bytes leave as whole 16-byte stores):
+    // profiles/r05/shapes_interpolators.txt
+    int sp_min = data_complex ? 2 : 1;
+    if (data_complex && SP == 1 && (UP == 6 || UP == 8)) sp_min = 1;
+#ifdef SFE_DIAG
+    if (const char *e = getenv("SFE_RT_DMA_SP1"))      // experiment: every pure interpolator here (scripts/collect_r05_p.sh)
+        if (atoi(e)) sp_min = 1;
+#endif
+    if (SP < sp_min || SP > 64 || UP < 1 || UP > 8 || plan.Lp <= 0 || !plan.d_Gt) return SFE_ESTATE;
     // 16-byte lanes: every channel's first sample on a 16-byte boundary
     if ((reinterpret_cast<uintptr_t>(a0.in) & 15u) || (n_channels > 1 && (a0.in_stride % a16))) return SFE_ESTATE;
 #ifdef SFE_DIAG

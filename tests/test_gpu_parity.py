@@ -756,7 +756,8 @@ def test_rs_shapes_outside_the_compiled_tables(api, L, orc, name, U, step, cplx)
                                          ("9/4", 4, 9), ("9/2", 2, 9), ("7/3", 3, 7), ("9/5", 5, 9), ("13/6", 6, 13), ("9/7", 7, 9), ("11/8", 8, 11),
                                          ("/6", 1, 6), ("/10", 1, 10), ("/12", 1, 12), ("/16", 1, 16), ("/24", 1, 24), ("/48", 1, 48), ("/64", 1, 64),
                                          ("6/5", 5, 6), ("10/3", 3, 10), ("12/5", 5, 12), ("14/4", 4, 14),
-                                         ("4/5", 5, 4), ("5/6", 6, 5), ("7/8", 8, 7), ("9/8", 8, 9), ("2/5", 5, 2), ("3/5", 5, 3), ("3/7", 7, 3), ("3/8", 8, 3), ("2/7", 7, 2)])
+                                         ("4/5", 5, 4), ("5/6", 6, 5), ("7/8", 8, 7), ("9/8", 8, 9), ("2/5", 5, 2), ("3/5", 5, 3), ("3/7", 7, 3), ("3/8", 8, 3), ("2/7", 7, 2),
+                                         ("x2", 2, 1), ("x3", 3, 1), ("x4", 4, 1), ("x5", 5, 1), ("x8", 8, 1)])
 @pytest.mark.parametrize("cplx", [True, False])
 def test_rt_shapes_fetched_by_lds_dma_and_read_in_place(api, L, orc, name, U, step, cplx):
     """Round 5 (poly_rt_dma.hip): float32 streams -- complex, and real (libdsp's native type) -- at an input step SP >= 2 with UP = 1 ... 8
