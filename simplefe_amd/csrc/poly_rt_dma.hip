@@ -57,32 +57,14 @@ template <> struct Wide<false, 4> {
     __device__ static __forceinline__ float get(const v4f &p, int w) { return w == 0 ? p.x : (w == 1 ? p.y : (w == 2 ? p.z : p.w)); }
 };
 
-// UPM = phase sums compiled in (= UP), MB = m per thread run together, W = samples per LDS read (1: odd SP)
-template <bool CPLX, int UPM, int MB, int W>
-__global__ __launch_bounds__(256) void poly_rt_dma_kernel(PolyTiledArgs a)
+// A tile of n_tile samples from stream index n_org on, into X from the 16-byte boundary at or below n_org (returns sh = the tile's first
+// sample's place in X): interior tiles by LDS-DMA, tiles at a stream's ends by guarded loads into the same layout.  The caller synchronises.
+template <bool CPLX>
+__device__ __forceinline__ unsigned fetch_tile(const PolyTiledArgs &a, const typename El<CPLX>::T *in, const typename El<CPLX>::T *hist,
+                                               typename El<CPLX>::T *X, char *smem, long long n_org, unsigned n_tile, unsigned tid)
 {
     typedef typename El<CPLX>::T T;
-    constexpr int ESZ = CPLX ? 8 : 4, A16 = 16 / ESZ;       // samples per 16 bytes
-    static_assert(W * ESZ <= 16, "a wide read is at most 16 bytes");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    T *X = reinterpret_cast<T *>(smem);
-    const unsigned tid = threadIdx.x;
-    const int ch = blockIdx.y;
-    const T *in = static_cast<const T *>(a.in) + (size_t)ch * a.in_stride;
-    const T *hist = static_cast<const T *>(a.hist) + (size_t)ch * a.hl;
-    T *out = static_cast<T *>(a.out) + (size_t)ch * a.out_stride;
-
-    if (a.hist_out && blockIdx.x == a.tiles) {        // the history workgroup (poly_tiled_kernel has the reasoning)
-        T *ho = static_cast<T *>(a.hist_out) + (size_t)ch * a.hl;
-#pragma unroll 1
-        for (unsigned i = tid; i < (unsigned)a.hl; i += 256u) ho[i] = in[a.n_in - a.hl + i];
-        return;
-    }
-    const unsigned SP = (unsigned)a.SP;
-    const int UP = a.UP, TMr = a.tm;
-    const long long m0 = (long long)blockIdx.x * TMr;
-    const long long n_org = (long long)SP * m0 + a.e_max - (a.Lp - 1);   // stream index of local sample 0
-    const unsigned n_tile = SP * (unsigned)TMr + (unsigned)a.Lp;
+    constexpr int ESZ = CPLX ? 8 : 4, A16 = 16 / ESZ;
     // the fetch starts on the 16-byte boundary at or below the tile's first sample (the channel's base is aligned: launcher)
     const unsigned sh = (unsigned)(((n_org % A16) + A16) % A16);
     const long long g0 = n_org - (long long)sh;
@@ -108,6 +90,35 @@ __global__ __launch_bounds__(256) void poly_rt_dma_kernel(PolyTiledArgs a)
             X[s] = i >= 0 ? (i < a.n_in ? in[i] : T{}) : (i >= -(long long)a.hl ? hist[a.hl + i] : T{});
         }
     }
+    return sh;
+}
+
+// UPM = phase sums compiled in (= UP), MB = m per thread run together, W = samples per LDS read (1: odd SP)
+template <bool CPLX, int UPM, int MB, int W>
+__global__ __launch_bounds__(256) void poly_rt_dma_kernel(PolyTiledArgs a)
+{
+    typedef typename El<CPLX>::T T;
+    constexpr int ESZ = CPLX ? 8 : 4, A16 = 16 / ESZ;       // samples per 16 bytes
+    static_assert(W * ESZ <= 16, "a wide read is at most 16 bytes");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T *X = reinterpret_cast<T *>(smem);
+    const unsigned tid = threadIdx.x;
+    const int ch = blockIdx.y;
+    const T *in = static_cast<const T *>(a.in) + (size_t)ch * a.in_stride;
+    const T *hist = static_cast<const T *>(a.hist) + (size_t)ch * a.hl;
+    T *out = static_cast<T *>(a.out) + (size_t)ch * a.out_stride;
+
+    if (a.hist_out && blockIdx.x == a.tiles) {        // the history workgroup (poly_tiled_kernel has the reasoning)
+        T *ho = static_cast<T *>(a.hist_out) + (size_t)ch * a.hl;
+#pragma unroll 1
+        for (unsigned i = tid; i < (unsigned)a.hl; i += 256u) ho[i] = in[a.n_in - a.hl + i];
+        return;
+    }
+    const unsigned SP = (unsigned)a.SP;
+    const int UP = a.UP, TMr = a.tm;
+    const long long m0 = (long long)blockIdx.x * TMr;
+    const long long n_org = (long long)SP * m0 + a.e_max - (a.Lp - 1);   // stream index of local sample 0
+    const unsigned sh = fetch_tile<CPLX>(a, in, hist, X, smem, n_org, SP * (unsigned)TMr + (unsigned)a.Lp, tid);
     __syncthreads();
 
     // taps: row qt of Gt holds the UP phases' taps at local time qt (padded to 8 floats): ONE scalar load per tap
@@ -239,6 +250,109 @@ __global__ __launch_bounds__(256) void poly_rt_dma_kernel(PolyTiledArgs a)
     }
 }
 
+// The pure interpolators (SP = 1) on REAL streams: a register window.  Lane t takes FOUR consecutive m, 4 t ... 4 t + 3: their 4 Lp samples
+// are Lp + 3 consecutive ones, read as whole aligned 16-byte groups (lane stride 16 bytes: no bank conflicts) from the highest local time
+// down -- one new group per four taps, the two above it kept in registers -- 40 bytes of LDS reads per m where one sample per tap and m
+// is 128.  That form (poly_rt_dma_kernel<false, UPM, MB, 1>) spends its time in the LDS pipe up to x4: 4 reads of 4 bytes a lane for
+// 2 UP packed multiply-adds per four m and tap.  SH = the place of the tile's first sample in its 16-byte group (the same in every tile of a
+// call: tiles are multiples of 4 m), compiled in so that the window is indexed by constants.  Accumulation order per output: tap index
+// ascending, fused -- the bits of poly_rt_kernel.  A lane's 4 UP outputs are consecutive; a wave's 256 UP leave through its LDS region
+// (rows of 4 UP + 4 or + 8 floats) as whole kilobytes.
+template <int UPM, int SH>
+__global__ __launch_bounds__(256) void poly_int4_dma_kernel(PolyTiledArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *X = reinterpret_cast<float *>(smem);
+    const unsigned tid = threadIdx.x;
+    const int ch = blockIdx.y;
+    const float *in = static_cast<const float *>(a.in) + (size_t)ch * a.in_stride;
+    const float *hist = static_cast<const float *>(a.hist) + (size_t)ch * a.hl;
+    float *out = static_cast<float *>(a.out) + (size_t)ch * a.out_stride;
+
+    if (a.hist_out && blockIdx.x == a.tiles) {        // the history workgroup
+        float *ho = static_cast<float *>(a.hist_out) + (size_t)ch * a.hl;
+#pragma unroll 1
+        for (unsigned i = tid; i < (unsigned)a.hl; i += 256u) ho[i] = in[a.n_in - a.hl + i];
+        return;
+    }
+    const int TMr = a.tm, Lp = a.Lp, Q = Lp >> 2;
+    const long long m0 = (long long)blockIdx.x * TMr;
+    const long long n_org = m0 + a.e_max - (Lp - 1);
+    fetch_tile<false>(a, in, hist, X, smem, n_org, (unsigned)TMr + (unsigned)Lp, tid);      // returns SH (launcher)
+    __syncthreads();
+
+    const __attribute__((address_space(4))) float *gt = (const __attribute__((address_space(4))) float *)a.Gt;
+    const v4f *XW = reinterpret_cast<const v4f *>(smem);
+    const bool out_al = (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+#pragma unroll 1
+    for (int t = (int)tid; 4 * t < TMr; t += 256) {
+        float acc[4][UPM];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int r = 0; r < UPM; r++) acc[i][r] = 0.0f;
+        // sample (m = 4 t + i, local time qt) sits at SH + 4 t + i + qt; local time descending = tap index ascending.
+        // Lp % 4 taps in front of the whole groups of four, one sample per read
+#pragma unroll 1
+        for (int qt = Lp - 1; qt >= 4 * Q; --qt) {
+            float tp[UPM];
+#pragma unroll
+            for (int r = 0; r < UPM; r++) tp[r] = gt[8 * qt + r];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float x = X[SH + 4 * t + i + qt];
+#pragma unroll
+                for (int r = 0; r < UPM; r++) acc[i][r] = __builtin_fmaf(tp[r], x, acc[i][r]);
+            }
+        }
+        // taps 4 q ... 4 q + 3 meet samples SH + 4 (t + q) + (0 ... 6): groups t + q, t + q + 1 and, from SH = 2 on, t + q + 2
+        constexpr int UNR = SH < 2 ? 2 : 3;            // the period of the window's rotation: no register moves
+        v4f g1 = XW[t + Q], g2 = XW[t + Q + 1];
+#pragma unroll UNR
+        for (int q = Q - 1; q >= 0; --q) {
+            const v4f g0 = XW[t + q];
+            const float e[12] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w};
+#pragma unroll
+            for (int w = 3; w >= 0; --w) {
+                float tp[UPM];
+#pragma unroll
+                for (int r = 0; r < UPM; r++) tp[r] = gt[8 * (4 * q + w) + r];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int r = 0; r < UPM; r++) acc[i][r] = __builtin_fmaf(tp[r], e[SH + i + w], acc[i][r]);
+            }
+            g2 = g1;
+            g1 = g0;
+        }
+        const int t_w = t - (int)(tid & 63u);                                    // the wave's first lane's t
+        const long long kw = (long long)UPM * (m0 + 4LL * t_w);
+        if (a.y_off && out_al && 4 * (t_w + 64) <= TMr && kw + 256LL * UPM <= a.n_out) {      // uniform over the wave
+            constexpr int ROW = 4 * UPM + (UPM % 2 ? 8 : 4);       // an ODD number of 16-byte cells per lane: the lanes' cells spread over the banks
+            float *Yw = reinterpret_cast<float *>(smem + a.y_off) + (tid >> 6) * (64u * ROW);
+            const unsigned lane = tid & 63u;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int r = 0; r < UPM; r++) Yw[lane * ROW + i * UPM + r] = acc[i][r];
+#pragma unroll
+            for (int ii = 0; ii < UPM; ii++) {                                   // 64 UPM groups of 16 bytes, lanes side by side
+                const unsigned gi = lane + 64u * ii;
+                const v4f qv = *reinterpret_cast<const v4f *>(Yw + (gi / UPM) * ROW + 4u * (gi % UPM));
+                __builtin_nontemporal_store(qv, reinterpret_cast<v4f *>(out + kw + 4u * gi));
+            }
+            continue;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const long long k = (long long)UPM * (m0 + 4LL * t + i);
+#pragma unroll
+            for (int r = 0; r < UPM; r++)
+                if (k + r < a.n_out) out[k + r] = acc[i][r];
+        }
+    }
+}
+
 // poly_rt_kernel's tile rule (polyphase.hip: rt_tile_m): the larger of the input and the output tile ~32 KiB -- 4096 complex samples, or
 // 8192 real ones (a real stream's tile of 4096 samples is half the bytes behind the same per-tile costs: /7 0.55 against 0.42 ms)
 int rt_dma_tile_m(int SP, int UP, int samples)
@@ -283,6 +397,18 @@ void launch_c(int UP, int W, const dim3 &grid, size_t lds, hipStream_t s, const 
     }
 }
 
+template <int UPM>
+void launch_int4(int sh, const dim3 &grid, size_t lds, hipStream_t s, const PolyTiledArgs &a)
+{
+    const dim3 block(256);
+    switch (sh) {
+    case 0: hipLaunchKernelGGL((poly_int4_dma_kernel<UPM, 0>), grid, block, lds, s, a); break;
+    case 1: hipLaunchKernelGGL((poly_int4_dma_kernel<UPM, 1>), grid, block, lds, s, a); break;
+    case 2: hipLaunchKernelGGL((poly_int4_dma_kernel<UPM, 2>), grid, block, lds, s, a); break;
+    default: hipLaunchKernelGGL((poly_int4_dma_kernel<UPM, 3>), grid, block, lds, s, a); break;
+    }
+}
+
 }  // namespace
 
 // SFE_ESTATE: the shape or the buffers are outside what this kernel takes (the caller runs launch_poly_tiled)
@@ -321,13 +447,40 @@ int launch_poly_rt_dma(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int d
         a.y_off = (unsigned)lds;                                          // (where they do not fit -- 11/8 -- the outputs leave lane by lane)
         lds += (size_t)4 * 64 * (UP + 1) * esz;
     }
+    // real interpolators up to x7: poly_int4_dma_kernel (x2 ... x5 13-24 % ahead of the one-sample-per-read form, x6 / x7 5-7 %; x8 -- 256
+    // multiply-adds per input sample: arithmetic, not the LDS -- 9 % behind it and stays: profiles/r05/shapes_interpolators.txt)
+    bool window = !data_complex && SP == 1 && UP <= 7;
+#ifdef SFE_DIAG
+    if (const char *e = getenv("SFE_RT_DMA_WINDOW")) window = window && atoi(e);
+#endif
+    if (window) {
+        a.y_off = 0;
+        lds = ((((size_t)a.tm + plan.Lp + 8) * 4 + 1023) >> 10) << 10;          // groups up to (tm + Lp) / 4 + 1 are read
+        if (UP >= 2) {
+            a.y_off = (unsigned)lds;
+            lds += (size_t)4 * 64 * (4 * UP + (UP % 2 ? 8 : 4)) * 4;
+        }
+        if (lds > 60 * 1024) return SFE_ESTATE;
+    }
     const long long mtot = (a.n_out + UP - 1) / UP;
     const long long tiles = (mtot + a.tm - 1) / a.tm;
     if (tiles > 0x7fffffffLL) return SFE_ESTATE;
     a.tiles = (unsigned)tiles;
     const dim3 grid((unsigned)tiles + (a.hist_out ? 1u : 0u), (unsigned)n_channels);
     const int per_thread = (a.tm + 255) / 256;
-    if (data_complex) launch_c<true>(UP, W, grid, lds, s, a, per_thread);
+    if (window) {
+        const int sh = (int)((((long long)a.e_max - (plan.Lp - 1)) % 4 + 4) % 4);
+        switch (UP) {
+        case 1: launch_int4<1>(sh, grid, lds, s, a); break;
+        case 2: launch_int4<2>(sh, grid, lds, s, a); break;
+        case 3: launch_int4<3>(sh, grid, lds, s, a); break;
+        case 4: launch_int4<4>(sh, grid, lds, s, a); break;
+        case 5: launch_int4<5>(sh, grid, lds, s, a); break;
+        case 6: launch_int4<6>(sh, grid, lds, s, a); break;
+        case 7: launch_int4<7>(sh, grid, lds, s, a); break;
+        default: launch_int4<8>(sh, grid, lds, s, a); break;
+        }
+    } else if (data_complex) launch_c<true>(UP, W, grid, lds, s, a, per_thread);
     else launch_c<false>(UP, W, grid, lds, s, a, per_thread);
     SFE_HIP(hipGetLastError());
     return SFE_OK;

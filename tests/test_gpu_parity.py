@@ -803,6 +803,44 @@ def test_rt_shapes_fetched_by_lds_dma_and_read_in_place(api, L, orc, name, U, st
             assert synth.rel_rms(y[c, part::w], ref[:k]) <= TOL, (name, c, part)
 
 
+@pytest.mark.parametrize("U", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("arm", [32, 31, 30, 29, 6, 3])
+def test_real_interpolators_by_register_window(api, L, orc, U, arm):
+    """Round 5 (poly_rt_dma.hip: poly_int4_dma_kernel): a REAL float32 stream interpolated by U (input step 1) -- each lane takes four
+    consecutive input positions and reads their samples as whole 16-byte groups into a register window.  Arms of 32, 31, 30 and 29 taps move
+    the tile's first sample through all four places of its 16-byte group (one compiled form each) and leave 0 ... 3 taps in front of the
+    whole groups of four; arms of 6 and 3 taps: one group, none.  Same law (libdsp/resample.cxx:100-114 at an integer step), same
+    accumulation order: within 1e-5 of the oracle and BIT-IDENTICAL to poly_rt1_kernel / poly_tiled_kernel<1, U>, which still serve a
+    stream that does not start on a 16-byte boundary.  A length that ends inside a tile, two calls with carried state, three channels."""
+    taps = synth.lowpass_taps(arm * U - (1 if U > 1 and arm % 2 == 0 else 0), 0.9 / U, gain=float(U))
+    rate = float(np.float32(1.0) / np.float32(U))
+    n, nch = 3 * 4096 + 1235, 3
+    x = np.stack([synth.synth_f32(n, ch=90 + c) for c in range(nch)])
+    refs = [orc.Resample(taps, U, 4096).stream(x[c], rate)[0] for c in range(nch)]
+    cap = n * U + 16
+
+    def run(offset_floats, stride):
+        buf = np.zeros(offset_floats + stride * nch, np.float32)
+        for c in range(nch):
+            buf[offset_floats + stride * c: offset_floats + stride * c + n] = x[c]
+        d = api.DeviceArray.from_numpy(buf)
+        d_out = api.DeviceArray(cap * nch)
+        r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=False, n_channels=nch)
+        r.set_algo(L.RS_ALGO_DIRECT)
+        cut = 2 * 4096 + 4 * 37
+        k1 = r.process_stream(d.ptr + 4 * offset_floats, cut, d_out, cap, rate, in_stride=stride, out_stride=cap)
+        k2 = r.process_stream(d.ptr + 4 * offset_floats + 4 * cut, n - cut, d_out.ptr + 4 * k1, cap - k1, rate, in_stride=stride, out_stride=cap)
+        return k1 + k2, d_out.to_numpy().reshape(nch, cap)[:, : k1 + k2]
+
+    al = (n + 3) // 4 * 4
+    k, y = run(0, al)                                # 16-byte aligned channels: the register-window kernel
+    ku, yu = run(1, al + 1)                          # one float off, an odd stride: the kernels it replaces
+    assert k == ku and np.array_equal(y, yu), (U, arm)
+    for c in range(nch):
+        assert len(refs[c]) - k in (0, 1), (U, arm, len(refs[c]), k)
+        assert synth.rel_rms(y[c], refs[c][:k]) <= TOL, (U, arm, c)
+
+
 # ----------------------------------------------------------------- edge cases / misuse
 def test_empty_and_tiny_inputs(api, L, orc):
     """n = 0 is a no-op; n < n_taps works and carries state; 1-tap filter is a gain."""
