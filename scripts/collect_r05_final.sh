@@ -8,5 +8,8 @@ O=$R/gpurun_out/prof_r05_tables
 BARE=1 timeout -k 10 600 python3 scripts/time_shapes.py > $O/shapes_main.txt 2>&1 || echo shapes failed
 BARE=1 EXTRA=1 SHAPES="by 12,by 13,by 24,by 32,by 48" timeout -k 10 300 python3 scripts/time_shapes.py > $O/shapes_long.txt 2>&1 || echo long failed
 timeout -k 10 300 python3 scripts/time_real_shapes.py > $O/shapes_real_final.txt 2>&1 || echo real failed
+EXTRA=3 SHAPES="interpolate" timeout -k 10 300 python3 scripts/time_shapes.py > $O/shapes_interp_cplx.txt 2>&1 || echo interp failed
+timeout -k 10 300 python3 scripts/time_real_baseline.py > $O/baseline_real.txt 2>&1 || echo real baseline failed
+cat $O/baseline_real.txt
 cut -c1-110 $O/shapes_main.txt; cat $O/shapes_real_final.txt
 echo collected final

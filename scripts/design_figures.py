@@ -2,7 +2,8 @@
 """Print the figures DESIGN.md quotes from profiles/<tag>/ in one place, so that a re-collection can be
 followed through the prose quickly (tests/test_design_numbers.py then checks the result).
 usage: scripts/design_figures.py [tag] [--write]
---write also regenerates DESIGN.md's block of the collection's own figures (between the collection:begin / :end markers):
+--write also regenerates DESIGN.md's block of the collection's own figures (between the collection:begin / :end markers)
+and the runtime shapes' table of 4.2d (shapes:begin / :end, from profiles/<tag>/shapes.txt):
 after a re-collection (scripts/collect_profiles.sh, scripts/summarise_profiles.py, the two bench lines) that is the only
 edit the prose needs."""
 import csv
@@ -128,11 +129,26 @@ def collection_block():
     return head + "\n\n" + table + "\n\n" + tail
 
 
+def shapes_block():
+    """DESIGN.md 4.2d's table (between the shapes:begin / :end markers) from profiles/<tag>/shapes.txt (BARE=1 scripts/time_shapes.py)"""
+    rows = ["| shape | U | step | ms (default dispatch) | `frac` | ms, exact mode | the shape's bare read : write mix |", "|---|---|---|---|---|---|---|"]
+    for line in open(os.path.join(P, "shapes.txt")):
+        m = re.match(r"(.{28}) +(\d+) +(\d+) +[\d.]+ +([\d.]+) +[\d.]+ +([\d.]+) +([\d.]+) ", line)
+        if not m or line.startswith(("#", "shape")):
+            continue
+        bare = re.search(r"bare ([\d.]+) / ([\d.]+) / (\d+) %", line)
+        mix = f"{bare.group(1)} ms, `frac` {bare.group(2)}: the kernel at {bare.group(3)} % of it" if bare else "n/a (the probe's mixes end at 8 : 1)"
+        rows.append(f"| {m.group(1).strip()} | {m.group(2)} | {m.group(3)} | {m.group(4)} | {m.group(5)} | {m.group(6)} | {mix} |")
+    return "\n" + "\n".join(rows)
+
+
 if "--write" in sys.argv:
     path = os.path.join(ROOT, "DESIGN.md")
     text = open(path).read()
-    b, e = "<!-- collection:begin -->", "<!-- collection:end -->"
-    i, j = text.index(b) + len(b), text.index(e)
-    block = collection_block()                  # may raise: nothing has been opened for writing yet
-    open(path, "w").write(text[:i] + "\n" + block + "\n" + text[j:])
-    print("DESIGN.md: collection block rewritten")
+    for (b, e), make in ((("<!-- collection:begin -->", "<!-- collection:end -->"), collection_block),
+                         (("<!-- shapes:begin -->", "<!-- shapes:end -->"), shapes_block)):
+        i, j = text.index(b) + len(b), text.index(e)
+        block = make()                          # may raise: nothing has been opened for writing yet
+        text = text[:i] + "\n" + block + "\n" + text[j:]
+    open(path, "w").write(text)
+    print("DESIGN.md: collection and shapes blocks rewritten")

@@ -47,6 +47,7 @@ if os.environ.get("SHAPES"):
 x = api.DeviceArray(2 * n)
 x.fill_synth(synth.SEED)
 t = api.Timer()
+warm = False
 print(f"# 2^{log2n} cf32 in, 32 taps per polyphase arm; kernel = what the default dispatch ran; exact = the bit-exact mode's time")
 print(f"{'shape':28s} {'U':>2s} {'step':>4s} {'out/in':>7s} {'ms':>8s} {'GB':>6s} {'frac':>6s} {'exact ms':>9s} {'rel-RMS vs f64':>15s}" + ("   bare mix ms / frac / kernel as a share of it" if BARE else ""))
 for name, U, step in SHAPES:
@@ -67,8 +68,9 @@ for name, U, step in SHAPES:
         r.set_exact(exact is True)
         if exact in ("direct", "fft"):
             r.set_algo(lib.RS_ALGO_DIRECT if exact == "direct" else lib.RS_ALGO_FFT)
-        for _ in range(4):
+        for _ in range(4 if warm else 150):        # the first shape also carries the chip past its first ~100 ms after idling (5-6 % slow)
             k = r.process_stream(x, n, y, cap, rate)
+        warm = True
         v = []
         for _ in range(9 if exact is False else 3):
             t.start()
