@@ -122,6 +122,58 @@ def test_general_rate_random_shapes_every_bit(api, L, orc, seed):
         assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(ref[: len(got)]).view(np.uint32)), (seed, U, n_taps, B, rate, cplx, chunk)
 
 
+@pytest.mark.parametrize("seed", range(48))
+def test_integer_step_fused_kernels_random_shapes(api, L, orc, seed):
+    """Round 5's kernels for integer-valued steps (poly_rt_dma.hip: the tile by LDS-DMA read in place; the register-window form for real
+    interpolators) on RANDOM shapes: 1-8 phases, input steps 1-40, 1-70 taps per phase with ragged last rows, real and complex streams,
+    1-3 channels, ragged cuts with carried state -- the same samples once from 16-byte-aligned channels (those kernels) and once shifted
+    by one sample at an odd stride (the kernels they replace: poly_rt_kernel, poly_rt1_kernel, poly_tiled_kernel): the same number of
+    outputs per call and the same BITS; and one channel against the oracle (libdsp/resample.cxx:100-114 at an integer step)."""
+    rng = np.random.default_rng(7000 + seed)
+    U = int(rng.integers(1, 9))
+    step = 1 if seed % 3 == 0 else int(rng.integers(1, 41))
+    plen = int(rng.integers(1, 71))
+    n_taps = max(U, U * plen - int(rng.integers(0, U)))
+    taps = (rng.standard_normal(n_taps) / np.sqrt(plen)).astype(np.float32)
+    rate = float(np.float32(step) / np.float32(U))
+    cplx = bool(rng.integers(0, 2))
+    w = 2 if cplx else 1
+    nch = int(rng.choice([1, 2, 3]))
+    n = int(rng.choice([5000, 12345, 40000, 70001])) * max(1, step // 8)
+    B = 4096
+    x = np.stack([synth.synth_f32(w * n, ch=300 + seed * 4 + c) for c in range(nch)])
+    cuts = sorted(set([0, n] + [int(v) // B * B for v in rng.integers(B, n, size=int(rng.integers(0, 3)))]))      # whole blocks: bulk calls
+    cap = n * U // step + 64
+    cap += (-cap) % 4
+
+    def run(offset_samples, stride):
+        buf = np.zeros(w * (offset_samples + stride * nch), np.float32)
+        for c in range(nch):
+            buf[w * (offset_samples + stride * c): w * (offset_samples + stride * c) + w * n] = x[c]
+        d = api.DeviceArray.from_numpy(buf)
+        d_out = api.DeviceArray(w * cap * nch)
+        r = api.Rs(taps, U, B, mode=L.RS_RESAMPLE, data_complex=cplx, n_channels=nch)
+        r.set_algo(L.RS_ALGO_DIRECT)
+        ks, k = [], 0
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            kk = r.process_stream(d.ptr + 4 * w * (offset_samples + a), b - a, d_out.ptr + 4 * w * k, cap - k, rate, in_stride=stride, out_stride=cap)
+            ks.append(kk)
+            k += kk
+        return ks, d_out.to_numpy().reshape(nch, w * cap)[:, : w * k]
+
+    al = (n + 3) // 4 * 4
+    ks, y = run(0, al)
+    ku, yu = run(1, al + 1)
+    assert ks == ku, (seed, U, step, n_taps, cplx, nch, n, cuts)
+    assert np.array_equal(y.view(np.uint32), yu.view(np.uint32)), (seed, U, step, n_taps, cplx, nch, n, cuts)
+    c = nch - 1
+    for part in range(w):
+        ref, _ = orc.Resample(taps, U, B).stream(np.ascontiguousarray(x[c, part::w]), rate)
+        got = y[c, part::w]
+        assert len(ref) - len(got) in (0, 1), (seed, U, step, len(ref), len(got))
+        assert synth.rel_rms(got, ref[: len(got)]) <= 1e-5, (seed, U, step, n_taps, cplx)
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_rs_fft_path_random_shapes(api, L, monkeypatch, seed):
     """Transform-domain kernel forced on, random instantiated (U, step) pairs, tap counts up to
