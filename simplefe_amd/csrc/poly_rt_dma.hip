@@ -1,4 +1,4 @@
-// poly_rt_dma.hip -- the runtime-shape tiled polyphase kernel with its tile fetched by LDS-DMA and read in place (round 5).
+// poly_rt_dma.hip -- the runtime-shape tiled polyphase kernels with their tile fetched by LDS-DMA and read in place (round 5).
 //
 // The law is poly_rt_kernel's (polyphase.hip): s(p) = sum_j taps[p % U + j U] x[p / U - j] (libdsp/decimate.cxx:132-140; value for
 // value the m_out[phase][n] of libdsp/resample.cxx:100-114) at positions p = pos0 + k step with an integer-valued step; with
@@ -19,10 +19,13 @@
 // A contiguous tile is exactly what LDS-DMA lands (global_load_lds_dwordx4: 64 lanes x 16 bytes = 1 KiB per instruction, no VGPR
 // destination, no scatter): interior tiles are fetched that way -- from the 16-byte boundary at or below the tile's first sample --
 // tiles at a stream's ends by guarded loads into the same layout.
-// Shapes: complex AND real float32 streams (real: libdsp's native type), fused arithmetic, SP >= 2 (real streams and complex x6 / x8: SP = 1
-// too), UP = 1 ... 8; three or more outputs per m leave through the waves' LDS regions as contiguous kilobytes.  Exact mode, u8 streams and
-// the other complex interpolators keep poly_rt_kernel / poly_rt1_kernel, and so do calls whose channels do not start on 16-byte boundaries.  VERDICT r4 item 6; profiles/r05/shapes_rt_dma.txt
-// (complex: /7 0.54 -> 0.43 ms, 7/4 0.72 -> 0.59, /13 0.50 -> 0.40, /48 0.49 -> 0.37, 10/3 0.71 -> 0.50 ...), profiles/r05/shapes_real.txt.
+// Shapes: complex AND real float32 streams (real: libdsp's native type), fused arithmetic, SP >= 2, UP = 1 ... 8; three or more outputs
+// per m leave through the waves' LDS regions as contiguous kilobytes.  SP = 1, the pure interpolators: real streams up to x7 run the second
+// kernel of this file, poly_int4_dma_kernel (the same fetch; four consecutive m per lane, their samples read as 16-byte groups into a register
+// window), real x8 and complex x6 / x8 the first one.  Exact mode, u8 streams and the other complex interpolators keep poly_rt_kernel /
+// poly_rt1_kernel, and so do calls whose channels do not start on 16-byte boundaries.  VERDICT r4 item 6; profiles/r05/shapes_rt_dma.txt
+// (complex: /7 0.54 -> 0.43 ms, 7/4 0.72 -> 0.59, /13 0.50 -> 0.40, /48 0.49 -> 0.37, 10/3 0.71 -> 0.50 ...), profiles/r05/shapes_real.txt,
+// profiles/r05/shapes_interpolators.txt.
 #include <stdint.h>
 #ifdef SFE_DIAG
 #include <stdlib.h>
