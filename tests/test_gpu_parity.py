@@ -777,25 +777,27 @@ def test_rt_shapes_fetched_by_lds_dma_and_read_in_place(api, L, orc, name, U, st
     cap = int(n / rate) + 16
     cap += (-cap) % 4                               # channels of the output 16 bytes apart
 
-    def run(offset_floats, stride):
-        """the three channels at `stride` samples apart, the buffer shifted by `offset_floats` floats; two calls"""
+    def run(offset_floats, stride, out_shift=0):
+        """the three channels at `stride` samples apart, the buffer shifted by `offset_floats` floats, the output by `out_shift` floats; two calls"""
         buf = np.zeros(offset_floats + w * stride * nch, np.float32)
         for c in range(nch):
             buf[offset_floats + w * stride * c: offset_floats + w * stride * c + w * n] = x[c]
         d = api.DeviceArray.from_numpy(buf)
-        d_out = api.DeviceArray(w * cap * nch)
+        d_out = api.DeviceArray(out_shift + w * cap * nch)
         r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=cplx, n_channels=nch)
         r.set_algo(L.RS_ALGO_DIRECT)
         cut = (n // 2) // 4096 * 4096
-        k1 = r.process_stream(d.ptr + 4 * offset_floats, cut, d_out, cap, rate, in_stride=stride, out_stride=cap)
-        k2 = r.process_stream(d.ptr + 4 * offset_floats + 4 * w * cut, n - cut, d_out.ptr + 4 * w * k1, cap - k1, rate, in_stride=stride, out_stride=cap)
-        y = d_out.to_numpy().reshape(nch, w * cap)[:, : w * (k1 + k2)]
+        k1 = r.process_stream(d.ptr + 4 * offset_floats, cut, d_out.ptr + 4 * out_shift, cap, rate, in_stride=stride, out_stride=cap)
+        k2 = r.process_stream(d.ptr + 4 * offset_floats + 4 * w * cut, n - cut, d_out.ptr + 4 * (out_shift + w * k1), cap - k1, rate, in_stride=stride, out_stride=cap)
+        y = d_out.to_numpy()[out_shift:].reshape(nch, w * cap)[:, : w * (k1 + k2)]
         return k1 + k2, y
 
     al = (n + 3) // 4 * 4
     k, y = run(0, al)                                # 16-byte aligned channels: the LDS-DMA kernel
     ku, yu = run(w, al + 1)                          # first sample one sample off a 16-byte boundary, an odd stride: poly_rt_kernel
     assert k == ku and np.array_equal(y, yu), name
+    ko, yo = run(0, al, out_shift=w)                 # the LDS-DMA kernel storing to an output one sample off a 16-byte boundary (no wide stores)
+    assert k == ko and np.array_equal(y, yo), name
     for c in range(nch):
         for part in range(w):
             ref = refs[c][part]
@@ -819,23 +821,25 @@ def test_real_interpolators_by_register_window(api, L, orc, U, arm):
     refs = [orc.Resample(taps, U, 4096).stream(x[c], rate)[0] for c in range(nch)]
     cap = n * U + 16
 
-    def run(offset_floats, stride):
+    def run(offset_floats, stride, out_shift=0):
         buf = np.zeros(offset_floats + stride * nch, np.float32)
         for c in range(nch):
             buf[offset_floats + stride * c: offset_floats + stride * c + n] = x[c]
         d = api.DeviceArray.from_numpy(buf)
-        d_out = api.DeviceArray(cap * nch)
+        d_out = api.DeviceArray(out_shift + cap * nch)
         r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=False, n_channels=nch)
         r.set_algo(L.RS_ALGO_DIRECT)
         cut = 2 * 4096 + 4 * 37
-        k1 = r.process_stream(d.ptr + 4 * offset_floats, cut, d_out, cap, rate, in_stride=stride, out_stride=cap)
-        k2 = r.process_stream(d.ptr + 4 * offset_floats + 4 * cut, n - cut, d_out.ptr + 4 * k1, cap - k1, rate, in_stride=stride, out_stride=cap)
-        return k1 + k2, d_out.to_numpy().reshape(nch, cap)[:, : k1 + k2]
+        k1 = r.process_stream(d.ptr + 4 * offset_floats, cut, d_out.ptr + 4 * out_shift, cap, rate, in_stride=stride, out_stride=cap)
+        k2 = r.process_stream(d.ptr + 4 * offset_floats + 4 * cut, n - cut, d_out.ptr + 4 * (out_shift + k1), cap - k1, rate, in_stride=stride, out_stride=cap)
+        return k1 + k2, d_out.to_numpy()[out_shift:].reshape(nch, cap)[:, : k1 + k2]
 
     al = (n + 3) // 4 * 4
     k, y = run(0, al)                                # 16-byte aligned channels: the register-window kernel
     ku, yu = run(1, al + 1)                          # one float off, an odd stride: the kernels it replaces
     assert k == ku and np.array_equal(y, yu), (U, arm)
+    ko, yo = run(0, al, out_shift=1)                 # the same kernel storing to an output that is NOT on a 16-byte boundary (lane-by-lane stores)
+    assert k == ko and np.array_equal(y, yo), (U, arm)
     for c in range(nch):
         assert len(refs[c]) - k in (0, 1), (U, arm, len(refs[c]), k)
         assert synth.rel_rms(y[c], refs[c][:k]) <= TOL, (U, arm, c)
