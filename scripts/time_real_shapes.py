@@ -15,7 +15,7 @@ from simplefe_amd import api, synth  # noqa: E402
 
 n = 1 << int(os.environ.get("LOG2N", "29"))
 SHAPES = [("decimate by 6", 1, 6), ("decimate by 7", 1, 7), ("decimate by 8", 1, 8), ("decimate by 12", 1, 12), ("decimate by 16", 1, 16), ("7/4", 4, 7), ("7/3", 3, 7),
-          ("4/5", 5, 4), ("interpolate x2", 2, 1), ("interpolate x3", 3, 1), ("interpolate x4", 4, 1), ("interpolate x5", 5, 1), ("interpolate x6", 6, 1), ("interpolate x7", 7, 1), ("interpolate x8", 8, 1)]
+          ("4/5", 5, 4), ("2/5", 5, 2), ("3/5", 5, 3), ("interpolate x2", 2, 1), ("interpolate x3", 3, 1), ("interpolate x4", 4, 1), ("interpolate x5", 5, 1), ("interpolate x6", 6, 1), ("interpolate x7", 7, 1), ("interpolate x8", 8, 1)]
 if os.environ.get("SHAPES"):
     SHAPES = [s for s in SHAPES if any(w in s[0] for w in os.environ["SHAPES"].split(","))]
 x = api.DeviceArray(n)

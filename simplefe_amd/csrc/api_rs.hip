@@ -437,7 +437,11 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
             ta.e_max = pl->e_max;
             // shapes outside the compiled tables, float32 streams (complex or real), fused arithmetic: the tile by LDS-DMA, read in place (poly_rt_dma.hip)
             rc = SFE_ESTATE;
-            bool try_dma = !r->exact_stream && !r->in_u8 && (!poly_tiled_is_compiled(pl->SP, pl->UP, pl->Lp) || (pl->SP == 1 && !r->data_complex));
+            bool window_shape = !r->data_complex && poly_rt_dma_window_shape(pl->SP, pl->UP);      // real streams at small steps: the register-window kernel
+#ifdef SFE_DIAG
+            if (const char *e = getenv("SFE_RT_DMA_WINDOW")) window_shape = window_shape && pl->SP <= atoi(e);
+#endif
+            bool try_dma = !r->exact_stream && !r->in_u8 && (!poly_tiled_is_compiled(pl->SP, pl->UP, pl->Lp) || window_shape);
 #ifdef SFE_DIAG
             if (const char *e = getenv("SFE_RT_DMA_FORCE"))        // scripts/ab_dec8_dma.py: the LDS-DMA form also where a compile-time kernel exists
                 if (atoi(e) && !r->exact_stream && !r->in_u8) try_dma = true;

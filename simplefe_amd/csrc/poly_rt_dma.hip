@@ -253,15 +253,16 @@ __global__ __launch_bounds__(256) void poly_rt_dma_kernel(PolyTiledArgs a)
     }
 }
 
-// The pure interpolators (SP = 1) on REAL streams: a register window.  Lane t takes FOUR consecutive m, 4 t ... 4 t + 3: their 4 Lp samples
-// are Lp + 3 consecutive ones, read as whole aligned 16-byte groups (lane stride 16 bytes: no bank conflicts) from the highest local time
-// down -- one new group per four taps, the two above it kept in registers -- 40 bytes of LDS reads per m where one sample per tap and m
-// is 128.  That form (poly_rt_dma_kernel<false, UPM, MB, 1>) spends its time in the LDS pipe up to x4: 4 reads of 4 bytes a lane for
-// 2 UP packed multiply-adds per four m and tap.  SH = the place of the tile's first sample in its 16-byte group (the same in every tile of a
-// call: tiles are multiples of 4 m), compiled in so that the window is indexed by constants.  Accumulation order per output: tap index
-// ascending, fused -- the bits of poly_rt_kernel.  A lane's 4 UP outputs are consecutive; a wave's 256 UP leave through its LDS region
-// (rows of 4 UP + 4 or + 8 floats) as whole kilobytes.
-template <int UPM, int SH>
+// REAL streams at SMALL input steps (SP = 1 ... 5; SP = 1: the pure interpolators): a register window.  Lane t takes FOUR consecutive m,
+// 4 t ... 4 t + 3: their 4 Lp samples are Lp + 3 SP consecutive ones, read as whole aligned 16-byte groups (lane stride 16 SP bytes: no bank
+// conflicts for an odd SP) from the highest local time down -- one new group per four taps, the (3 SP + 6) / 4 above it kept in registers --
+// 40 bytes of LDS reads per m at SP = 1 and 32 taps where one sample per tap and m is 128.  That form (poly_rt_dma_kernel<false, UPM, MB, 1>)
+// and the compile-time poly_tiled_kernel on 4-byte samples spend their time in the LDS pipe: 4 reads of 4 bytes a lane for 2 UP packed
+// multiply-adds per four m and tap.  SH = the place of the tile's first sample in its 16-byte group (the same in every tile of a call:
+// tiles are multiples of 4 m) and SPC = SP are compiled in, so that the window is indexed by constants.  Accumulation order per output: tap
+// index ascending, fused -- the bits of poly_rt_kernel.  A lane's 4 UP outputs are consecutive; a wave's 256 UP leave through its LDS
+// region (rows of 4 UP + 4 or + 8 floats) as whole kilobytes, or, UP = 1 and where the regions do not fit, as the lane's own 16-byte pieces.
+template <int UPM, int SH, int SPC>
 __global__ __launch_bounds__(256) void poly_int4_dma_kernel(PolyTiledArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -280,13 +281,16 @@ __global__ __launch_bounds__(256) void poly_int4_dma_kernel(PolyTiledArgs a)
     }
     const int TMr = a.tm, Lp = a.Lp, Q = Lp >> 2;
     const long long m0 = (long long)blockIdx.x * TMr;
-    const long long n_org = m0 + a.e_max - (Lp - 1);
-    fetch_tile<false>(a, in, hist, X, smem, n_org, (unsigned)TMr + (unsigned)Lp, tid);      // returns SH (launcher)
+    const long long n_org = (long long)SPC * m0 + a.e_max - (Lp - 1);
+    fetch_tile<false>(a, in, hist, X, smem, n_org, (unsigned)(SPC * TMr) + (unsigned)Lp, tid);      // returns SH (launcher)
     __syncthreads();
 
     const __attribute__((address_space(4))) float *gt = (const __attribute__((address_space(4))) float *)a.Gt;
     const v4f *XW = reinterpret_cast<const v4f *>(smem);
     const bool out_al = (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+    // taps 4 q ... 4 q + 3 of the lane's four m meet samples SH + 4 (SPC t + q) + (0 ... 3 SPC + 3): NG groups from SPC t + q on
+    constexpr int NG = (SH + 3 * SPC + 3) / 4 + 1;
+    constexpr int UNR = NG > 2 ? NG - 1 : 2;             // the period of the window's rotation: no register moves
 #pragma unroll 1
     for (int t = (int)tid; 4 * t < TMr; t += 256) {
         float acc[4][UPM];
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(256) void poly_int4_dma_kernel(PolyTiledArgs a)
         for (int i = 0; i < 4; i++)
 #pragma unroll
             for (int r = 0; r < UPM; r++) acc[i][r] = 0.0f;
-        // sample (m = 4 t + i, local time qt) sits at SH + 4 t + i + qt; local time descending = tap index ascending.
+        // sample (m = 4 t + i, local time qt) sits at SH + SPC (4 t + i) + qt; local time descending = tap index ascending.
         // Lp % 4 taps in front of the whole groups of four, one sample per read
 #pragma unroll 1
         for (int qt = Lp - 1; qt >= 4 * Q; --qt) {
@@ -303,18 +307,25 @@ __global__ __launch_bounds__(256) void poly_int4_dma_kernel(PolyTiledArgs a)
             for (int r = 0; r < UPM; r++) tp[r] = gt[8 * qt + r];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const float x = X[SH + 4 * t + i + qt];
+                const float x = X[SH + SPC * (4 * t + i) + qt];
 #pragma unroll
                 for (int r = 0; r < UPM; r++) acc[i][r] = __builtin_fmaf(tp[r], x, acc[i][r]);
             }
         }
-        // taps 4 q ... 4 q + 3 meet samples SH + 4 (t + q) + (0 ... 6): groups t + q, t + q + 1 and, from SH = 2 on, t + q + 2
-        constexpr int UNR = SH < 2 ? 2 : 3;            // the period of the window's rotation: no register moves
-        v4f g1 = XW[t + Q], g2 = XW[t + Q + 1];
+        v4f g[NG];
+#pragma unroll
+        for (int j = 1; j < NG; j++) g[j] = XW[SPC * t + Q - 1 + j];
 #pragma unroll UNR
         for (int q = Q - 1; q >= 0; --q) {
-            const v4f g0 = XW[t + q];
-            const float e[12] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w};
+            g[0] = XW[SPC * t + q];
+            float e[4 * NG];
+#pragma unroll
+            for (int j = 0; j < NG; j++) {
+                e[4 * j] = g[j].x;
+                e[4 * j + 1] = g[j].y;
+                e[4 * j + 2] = g[j].z;
+                e[4 * j + 3] = g[j].w;
+            }
 #pragma unroll
             for (int w = 3; w >= 0; --w) {
                 float tp[UPM];
@@ -323,10 +334,10 @@ __global__ __launch_bounds__(256) void poly_int4_dma_kernel(PolyTiledArgs a)
 #pragma unroll
                 for (int i = 0; i < 4; i++)
 #pragma unroll
-                    for (int r = 0; r < UPM; r++) acc[i][r] = __builtin_fmaf(tp[r], e[SH + i + w], acc[i][r]);
+                    for (int r = 0; r < UPM; r++) acc[i][r] = __builtin_fmaf(tp[r], e[SH + SPC * i + w], acc[i][r]);
             }
-            g2 = g1;
-            g1 = g0;
+#pragma unroll
+            for (int j = NG - 1; j >= 1; j--) g[j] = g[j - 1];
         }
         const int t_w = t - (int)(tid & 63u);                                    // the wave's first lane's t
         const long long kw = (long long)UPM * (m0 + 4LL * t_w);
@@ -343,6 +354,21 @@ __global__ __launch_bounds__(256) void poly_int4_dma_kernel(PolyTiledArgs a)
                 const unsigned gi = lane + 64u * ii;
                 const v4f qv = *reinterpret_cast<const v4f *>(Yw + (gi / UPM) * ROW + 4u * (gi % UPM));
                 __builtin_nontemporal_store(qv, reinterpret_cast<v4f *>(out + kw + 4u * gi));
+            }
+            continue;
+        }
+        const long long k0 = (long long)UPM * (m0 + 4LL * t);
+        if (out_al && 4 * t + 4 <= TMr && k0 + 4 * UPM <= a.n_out) {             // the lane's 4 UP consecutive outputs as 16-byte pieces
+            float f[4 * UPM];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int r = 0; r < UPM; r++) f[i * UPM + r] = acc[i][r];
+#pragma unroll
+            for (int c = 0; c < UPM; c++) {
+                const v4f qv = (v4f){f[4 * c], f[4 * c + 1], f[4 * c + 2], f[4 * c + 3]};
+                if (UPM == 1) __builtin_nontemporal_store(qv, reinterpret_cast<v4f *>(out + k0));
+                else *reinterpret_cast<v4f *>(out + k0 + 4 * c) = qv;
             }
             continue;
         }
@@ -400,19 +426,54 @@ void launch_c(int UP, int W, const dim3 &grid, size_t lds, hipStream_t s, const 
     }
 }
 
-template <int UPM>
-void launch_int4(int sh, const dim3 &grid, size_t lds, hipStream_t s, const PolyTiledArgs &a)
+template <int UPM, int SPC>
+void launch_int4_sh(int sh, const dim3 &grid, size_t lds, hipStream_t s, const PolyTiledArgs &a)
 {
     const dim3 block(256);
     switch (sh) {
-    case 0: hipLaunchKernelGGL((poly_int4_dma_kernel<UPM, 0>), grid, block, lds, s, a); break;
-    case 1: hipLaunchKernelGGL((poly_int4_dma_kernel<UPM, 1>), grid, block, lds, s, a); break;
-    case 2: hipLaunchKernelGGL((poly_int4_dma_kernel<UPM, 2>), grid, block, lds, s, a); break;
-    default: hipLaunchKernelGGL((poly_int4_dma_kernel<UPM, 3>), grid, block, lds, s, a); break;
+    case 0: hipLaunchKernelGGL((poly_int4_dma_kernel<UPM, 0, SPC>), grid, block, lds, s, a); break;
+    case 1: hipLaunchKernelGGL((poly_int4_dma_kernel<UPM, 1, SPC>), grid, block, lds, s, a); break;
+    case 2: hipLaunchKernelGGL((poly_int4_dma_kernel<UPM, 2, SPC>), grid, block, lds, s, a); break;
+    default: hipLaunchKernelGGL((poly_int4_dma_kernel<UPM, 3, SPC>), grid, block, lds, s, a); break;
+    }
+}
+
+// the compiled register-window shapes: SP = 1 with UP = 1 ... 7; SP = 2, 3 with UP = 1 ... 5; SP = 4, 5 with UP = 1; and 5/3.  (Measured against the
+// kernels they replace, real streams, profiles/r05/shapes_real_window.txt: /2 +26 %, /3 +29 %, /4 +10 %, /5 +3 %, 3/2 +16 %, 2/3 +26 %, 3/4 +13 %;
+// 5/3 +13 %; the other shapes at SP = 4, 5 with several outputs per m -- 4/3, 4/5, 5/2, 5/4 -- LOSE 2-8 % and keep theirs.)
+bool int4_shape(int SP, int UP)
+{
+    if (UP < 1) return false;
+    return SP == 1 ? UP <= 7 : (SP == 2 || SP == 3) ? UP <= 5 : SP == 4 ? UP == 1 : SP == 5 ? (UP == 1 || UP == 3) : false;
+}
+
+template <int SPC>
+void launch_int4(int UP, int sh, const dim3 &grid, size_t lds, hipStream_t s, const PolyTiledArgs &a)
+{
+    if constexpr (SPC >= 4) {
+        if (SPC == 5 && UP == 3) launch_int4_sh<3, 5>(sh, grid, lds, s, a);
+        else launch_int4_sh<1, SPC>(sh, grid, lds, s, a);
+    } else {
+        switch (UP) {
+        case 1: launch_int4_sh<1, SPC>(sh, grid, lds, s, a); break;
+        case 2: launch_int4_sh<2, SPC>(sh, grid, lds, s, a); break;
+        case 3: launch_int4_sh<3, SPC>(sh, grid, lds, s, a); break;
+        case 4: launch_int4_sh<4, SPC>(sh, grid, lds, s, a); break;
+        case 5: launch_int4_sh<5, SPC>(sh, grid, lds, s, a); break;
+        default:
+            if constexpr (SPC == 1) {
+                if (UP == 6) launch_int4_sh<6, 1>(sh, grid, lds, s, a);
+                else launch_int4_sh<7, 1>(sh, grid, lds, s, a);
+            }
+            break;
+        }
     }
 }
 
 }  // namespace
+
+// real streams: the (SP, UP) the register-window kernel is compiled for -- those calls come here even where a compile-time tiled kernel exists
+bool poly_rt_dma_window_shape(int SP, int UP) { return int4_shape(SP, UP); }
 
 // SFE_ESTATE: the shape or the buffers are outside what this kernel takes (the caller runs launch_poly_tiled)
 int launch_poly_rt_dma(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int data_complex, int n_channels, hipStream_t s)
@@ -450,20 +511,22 @@ int launch_poly_rt_dma(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int d
         a.y_off = (unsigned)lds;                                          // (where they do not fit -- 11/8 -- the outputs leave lane by lane)
         lds += (size_t)4 * 64 * (UP + 1) * esz;
     }
-    // real interpolators up to x7: poly_int4_dma_kernel (x2 ... x5 13-24 % ahead of the one-sample-per-read form, x6 / x7 5-7 %; x8 -- 256
-    // multiply-adds per input sample: arithmetic, not the LDS -- 9 % behind it and stays: profiles/r05/shapes_interpolators.txt)
-    bool window = !data_complex && SP == 1 && UP <= 7;
+    // real streams at small input steps: poly_int4_dma_kernel.  The interpolators up to x7 (x2 ... x5 13-24 % ahead of the one-sample-per-read
+    // form, x6 / x7 5-7 %; x8 -- 256 multiply-adds per input sample: arithmetic, not the LDS -- 9 % behind it and stays:
+    // profiles/r05/shapes_interpolators.txt) and SP = 2 ... 5 with up to five outputs per m (profiles/r05/shapes_real_window.txt)
+    bool window = !data_complex && int4_shape(SP, UP);
 #ifdef SFE_DIAG
-    if (const char *e = getenv("SFE_RT_DMA_WINDOW")) window = window && atoi(e);
+    if (const char *e = getenv("SFE_RT_DMA_WINDOW")) window = window && SP <= atoi(e);      // the largest SP that takes this form (0: none)
 #endif
     if (window) {
         a.y_off = 0;
-        lds = ((((size_t)a.tm + plan.Lp + 8) * 4 + 1023) >> 10) << 10;          // groups up to (tm + Lp) / 4 + 1 are read
-        if (UP >= 2) {
-            a.y_off = (unsigned)lds;
-            lds += (size_t)4 * 64 * (4 * UP + (UP % 2 ? 8 : 4)) * 4;
-        }
+        lds = ((((size_t)SP * a.tm + plan.Lp + 8) * 4 + 1023) >> 10) << 10;          // groups up to (SP tm + Lp) / 4 + 1 are read
         if (lds > 60 * 1024) return SFE_ESTATE;
+        const size_t regions = (size_t)4 * 64 * (4 * UP + (UP % 2 ? 8 : 4)) * 4;
+        if (UP >= 2 && lds + regions <= 60 * 1024) {                                 // (where they do not fit the outputs leave as the lanes' own pieces)
+            a.y_off = (unsigned)lds;
+            lds += regions;
+        }
     }
     const long long mtot = (a.n_out + UP - 1) / UP;
     const long long tiles = (mtot + a.tm - 1) / a.tm;
@@ -473,15 +536,12 @@ int launch_poly_rt_dma(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int d
     const int per_thread = (a.tm + 255) / 256;
     if (window) {
         const int sh = (int)((((long long)a.e_max - (plan.Lp - 1)) % 4 + 4) % 4);
-        switch (UP) {
-        case 1: launch_int4<1>(sh, grid, lds, s, a); break;
-        case 2: launch_int4<2>(sh, grid, lds, s, a); break;
-        case 3: launch_int4<3>(sh, grid, lds, s, a); break;
-        case 4: launch_int4<4>(sh, grid, lds, s, a); break;
-        case 5: launch_int4<5>(sh, grid, lds, s, a); break;
-        case 6: launch_int4<6>(sh, grid, lds, s, a); break;
-        case 7: launch_int4<7>(sh, grid, lds, s, a); break;
-        default: launch_int4<8>(sh, grid, lds, s, a); break;
+        switch (SP) {
+        case 1: launch_int4<1>(UP, sh, grid, lds, s, a); break;
+        case 2: launch_int4<2>(UP, sh, grid, lds, s, a); break;
+        case 3: launch_int4<3>(UP, sh, grid, lds, s, a); break;
+        case 4: launch_int4<4>(UP, sh, grid, lds, s, a); break;
+        default: launch_int4<5>(UP, sh, grid, lds, s, a); break;
         }
     } else if (data_complex) launch_c<true>(UP, W, grid, lds, s, a, per_thread);
     else launch_c<false>(UP, W, grid, lds, s, a, per_thread);

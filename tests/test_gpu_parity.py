@@ -845,6 +845,49 @@ def test_real_interpolators_by_register_window(api, L, orc, U, arm):
         assert synth.rel_rms(y[c], refs[c][:k]) <= TOL, (U, arm, c)
 
 
+@pytest.mark.parametrize("U,step", [(1, 2), (1, 3), (1, 4), (1, 5), (2, 3), (2, 5), (3, 2), (3, 4), (3, 5), (4, 3), (4, 5), (5, 2), (5, 3), (5, 4)])
+@pytest.mark.parametrize("arm", [32, 31, 30, 29, 6])
+def test_real_small_steps_by_register_window(api, L, orc, U, step, arm):
+    """Round 5 (poly_rt_dma.hip: poly_int4_dma_kernel<UP, SH, SP>): REAL float32 streams at input steps 2 ... 5 with 1 ... 5 outputs per
+    step -- decimate by 2 ... 5, 3/2, 5/3, 2/3, 4/5 ... -- through the register-window kernel (four consecutive m per lane, their samples read
+    as whole 16-byte groups), also where a compile-time tiled kernel exists (4/3, 4/5, 5/2 and 5/4 measured slower there, keep their kernels and are
+    here as controls).  Arms of 32 / 31 / 30 / 29 / 6 taps: all four places of the
+    tile's first sample in its 16-byte group, 0 ... 3 taps in front of the whole groups of four.  Same law (libdsp/decimate.cxx:132-140,
+    libdsp/resample.cxx:100-114 at an integer step), same accumulation order: within 1e-5 of the oracle and BIT-IDENTICAL to the kernels
+    that still serve a stream off a 16-byte boundary (poly_tiled_kernel where the shape has one, else poly_rt_kernel); an output off a
+    16-byte boundary; a length that ends inside a tile, two calls with carried state, three channels."""
+    taps = synth.lowpass_taps(arm * U - (1 if U > 1 and arm % 2 == 0 else 0), 0.9 * min(1.0 / U, 1.0 / step), gain=float(U))
+    rate = float(np.float32(step) / np.float32(U))
+    n, nch = 5 * 4096 + 1235, 3
+    x = np.stack([synth.synth_f32(n, ch=110 + c) for c in range(nch)])
+    refs = [orc.Resample(taps, U, 4096).stream(x[c], rate)[0] for c in range(nch)]
+    cap = n * U // step + 16
+    cap += (-cap) % 4
+
+    def run(offset_floats, stride, out_shift=0):
+        buf = np.zeros(offset_floats + stride * nch, np.float32)
+        for c in range(nch):
+            buf[offset_floats + stride * c: offset_floats + stride * c + n] = x[c]
+        d = api.DeviceArray.from_numpy(buf)
+        d_out = api.DeviceArray(out_shift + cap * nch)
+        r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=False, n_channels=nch)
+        r.set_algo(L.RS_ALGO_DIRECT)
+        cut = 3 * 4096
+        k1 = r.process_stream(d.ptr + 4 * offset_floats, cut, d_out.ptr + 4 * out_shift, cap, rate, in_stride=stride, out_stride=cap)
+        k2 = r.process_stream(d.ptr + 4 * offset_floats + 4 * cut, n - cut, d_out.ptr + 4 * (out_shift + k1), cap - k1, rate, in_stride=stride, out_stride=cap)
+        return k1 + k2, d_out.to_numpy()[out_shift:].reshape(nch, cap)[:, : k1 + k2]
+
+    al = (n + 3) // 4 * 4
+    k, y = run(0, al)                                # 16-byte aligned channels: the register-window kernel
+    ku, yu = run(1, al + 1)                          # one float off, an odd stride: the kernels it replaces
+    assert k == ku and np.array_equal(y, yu), (U, step, arm)
+    ko, yo = run(0, al, out_shift=1)                 # the same kernel, its output off a 16-byte boundary
+    assert k == ko and np.array_equal(y, yo), (U, step, arm)
+    for c in range(nch):
+        assert len(refs[c]) - k in (0, 1), (U, step, arm, len(refs[c]), k)
+        assert synth.rel_rms(y[c], refs[c][:k]) <= TOL, (U, step, arm, c)
+
+
 # ----------------------------------------------------------------- edge cases / misuse
 def test_empty_and_tiny_inputs(api, L, orc):
     """n = 0 is a no-op; n < n_taps works and carries state; 1-tap filter is a gain."""
