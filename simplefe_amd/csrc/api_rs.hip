@@ -441,12 +441,18 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
 #ifdef SFE_DIAG
             if (const char *e = getenv("SFE_RT_DMA_WINDOW")) window_shape = window_shape && pl->SP <= atoi(e);
 #endif
-            bool try_dma = !r->exact_stream && !r->in_u8 && (!poly_tiled_is_compiled(pl->SP, pl->UP, pl->Lp) || window_shape);
+            // wire-format input: four shapes have compile-time u8 kernels (/2, /4, /8, 5/3) and keep them; every other one -- the compile-time
+            // float shapes included -- ran poly_rt_kernel's sample-by-sample byte loads (/7 0.71 ms where the float32 stream takes 0.45) and now
+            // has its raw tile fetched by DMA and converted once (0.38 ms): profiles/r05/shapes_u8.txt
+            const bool compiled = r->in_u8 ? poly_tiled_u8_is_compiled(pl->SP, pl->UP, pl->Lp) : poly_tiled_is_compiled(pl->SP, pl->UP, pl->Lp);
+            bool try_dma = !r->exact_stream && (!compiled || (window_shape && !r->in_u8));
 #ifdef SFE_DIAG
             if (const char *e = getenv("SFE_RT_DMA_FORCE"))        // scripts/ab_dec8_dma.py: the LDS-DMA form also where a compile-time kernel exists
-                if (atoi(e) && !r->exact_stream && !r->in_u8) try_dma = true;
+                if (atoi(e) && !r->exact_stream) try_dma = true;
+            if (const char *e = getenv("SFE_RT_DMA_U8"))           // =0: wire-format input keeps poly_rt_kernel / the compile-time kernels (scripts/time_u8_shapes.py)
+                if (!atoi(e) && r->in_u8) try_dma = false;
 #endif
-            if (try_dma) rc = launch_poly_rt_dma(*pl, ta, r->data_complex, r->n_channels, s);
+            if (try_dma) rc = launch_poly_rt_dma(*pl, ta, r->data_complex, r->in_u8, r->n_channels, s);
             if (rc == SFE_ESTATE) rc = launch_poly_tiled(*pl, ta, r->data_complex, r->exact_stream, r->in_u8, r->n_channels, s);
         } else {
             if (r->in_u8) {

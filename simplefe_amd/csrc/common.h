@@ -158,6 +158,9 @@ struct PolyTiledArgs {
     int         SP = 0, UP = 0, tm = 0, rowlen = 0;
     unsigned    sp_inv = 0;           // ceil(2^32 / SP): floor(s / SP) = mulhi(s, sp_inv) for the s a tile meets
     unsigned    y_off = 0;            // byte offset in LDS of the waves' output regions (0: none; UP >= 3, complex)
+    // poly_rt_dma.hip: the input is the receive wire format (u8 offset binary; complex: byte pairs) -- the tile's raw bytes land at raw_off in LDS
+    int         in_u8 = 0;
+    unsigned    raw_off = 0;
 };
 // returns SFE_OK, or SFE_ESTATE when (SP, UP, Lp) has no tiled instantiation (caller falls
 // back to launch_poly_int)
@@ -165,6 +168,7 @@ int launch_poly_tiled(const PolyTiledPlan &plan, const PolyTiledArgs &a, int dat
                       int in_u8, int n_channels, hipStream_t s);
 bool poly_tiled_supported(int SP, int UP, int Lp);     // a compile-time instantiation, or the runtime-shape kernel
 bool poly_tiled_is_compiled(int SP, int UP, int Lp);    // a compile-time instantiation of poly_tiled_kernel
+bool poly_tiled_u8_is_compiled(int SP, int UP, int Lp); // ... that also has a u8-input form
 
 // f32-MFMA form of the same integer-step law (fused multiply-add numerics only).  Outputs are
 // taken in groups of RG = UP*DM consecutive outputs (DM consecutive m, RG <= 16) that read a

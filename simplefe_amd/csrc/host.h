@@ -188,7 +188,7 @@ void rs_free(Rs *r);
 
 // poly_rt_dma.hip (round 5): the runtime-shape tiled kernel for odd input steps, its tile fetched by LDS-DMA.  SFE_ESTATE: the shape or
 // the buffers are outside what it takes -- the caller runs launch_poly_tiled.  (Declared here, not in common.h: host-side plumbing.)
-int launch_poly_rt_dma(const PolyTiledPlan &plan, const PolyTiledArgs &a, int data_complex, int n_channels, hipStream_t s);
+int launch_poly_rt_dma(const PolyTiledPlan &plan, const PolyTiledArgs &a, int data_complex, int in_u8, int n_channels, hipStream_t s);
 bool poly_rt_dma_window_shape(int SP, int UP);
 
 }  // namespace sfe

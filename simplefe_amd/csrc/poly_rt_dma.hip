@@ -62,30 +62,71 @@ template <> struct Wide<false, 4> {
 
 // A tile of n_tile samples from stream index n_org on, into X from the 16-byte boundary at or below n_org (returns sh = the tile's first
 // sample's place in X): interior tiles by LDS-DMA, tiles at a stream's ends by guarded loads into the same layout.  The caller synchronises.
+// a.in_u8 (the receive wire format, gr-simplefe/lib/source_c_impl.cc / source_f_impl.cc: u8 offset binary, a complex sample = two bytes): the
+// tile's RAW bytes land by the same DMA at a.raw_off -- 512 complex or 1024 real samples per kilobyte piece -- and are converted ONCE,
+// four bytes = one 16-byte group of float32 per step, into the same X the float32 path fills: everything after the fetch is unchanged,
+// and so are the bits ((b - 128) * (1 / 127): common.h u8_to_f32, what poly_rt_kernel's u8 path applies sample by sample).
 template <bool CPLX>
-__device__ __forceinline__ unsigned fetch_tile(const PolyTiledArgs &a, const typename El<CPLX>::T *in, const typename El<CPLX>::T *hist,
+__device__ __forceinline__ unsigned fetch_tile(const PolyTiledArgs &a, int ch, const typename El<CPLX>::T *hist,
                                                typename El<CPLX>::T *X, char *smem, long long n_org, unsigned n_tile, unsigned tid)
 {
     typedef typename El<CPLX>::T T;
     constexpr int ESZ = CPLX ? 8 : 4, A16 = 16 / ESZ;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+    const unsigned wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane16 = (tid & 63u) * 16u;
     // the fetch starts on the 16-byte boundary at or below the tile's first sample (the channel's base is aligned: launcher)
     const unsigned sh = (unsigned)(((n_org % A16) + A16) % A16);
-    const long long g0 = n_org - (long long)sh;
-    constexpr unsigned PIECE = 1024 / ESZ;                               // samples per wave instruction (1 KiB)
-    const unsigned pieces = (n_tile + sh + PIECE - 1u) / PIECE;
-    if (g0 >= 0 && g0 + (long long)pieces * PIECE <= a.n_in) {
-        const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
-        const unsigned wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane16 = (tid & 63u) * 16u;
-        const char *g = reinterpret_cast<const char *>(in + g0);             // uniform
+    auto dma = [&](const char *g, unsigned dst0, unsigned pieces) {          // pieces of 1 KiB from g (uniform) to LDS byte dst0 on
 #pragma unroll 1
         for (unsigned p = wv; p < pieces; p += 4u) {
-            const unsigned dst = lds_base + (p << 10);
+            const unsigned dst = dst0 + (p << 10);
             const char *gp = g + ((size_t)p << 10);
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(lane16), "s"(gp), "s"(dst) : "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    if (a.in_u8) {
+        constexpr int BSZ = CPLX ? 2 : 1, A16R = 16 / BSZ;                  // bytes per sample, samples per 16 raw bytes
+        const unsigned char *in8 = static_cast<const unsigned char *>(a.in) + (size_t)ch * a.in_stride * BSZ;
+        const unsigned shr = (unsigned)(((n_org % A16R) + A16R) % A16R);
+        const long long g0 = n_org - (long long)shr;
+        constexpr unsigned PIECE = 1024 / BSZ;
+        const unsigned pieces = (n_tile + shr + PIECE - 1u) / PIECE;
+        if (g0 >= 0 && g0 + (long long)pieces * PIECE <= a.n_in) {
+            dma(reinterpret_cast<const char *>(in8 + g0 * BSZ), lds_base + a.raw_off, pieces);
+            __syncthreads();                                                 // every wave's pieces have landed
+            const unsigned d = shr - sh;                                     // raw sample of float sample s: s + d (d BSZ is a multiple of 4)
+            const char *raw = smem + a.raw_off;
+            const unsigned groups = (n_tile + sh + A16 - 1u) / A16;
+#pragma unroll 1
+            for (unsigned gi = tid; gi < groups; gi += 256u) {
+                const unsigned w = *reinterpret_cast<const unsigned *>(raw + ((unsigned)A16 * gi + d) * BSZ);      // 2 complex or 4 real samples
+                reinterpret_cast<v4f *>(smem)[gi] = (v4f){u8_to_f32(w & 255u), u8_to_f32((w >> 8) & 255u), u8_to_f32((w >> 16) & 255u), u8_to_f32(w >> 24)};
+            }
+        } else {
+#pragma unroll 1
+            for (unsigned s = tid; s < n_tile + sh; s += 256u) {
+                const long long i = n_org - (long long)sh + s;
+                T v = T{};
+                if (i >= 0) {
+                    if (i < a.n_in) {
+                        if constexpr (CPLX) v = (v2f){u8_to_f32(in8[2 * i]), u8_to_f32(in8[2 * i + 1])};
+                        else v = u8_to_f32(in8[i]);
+                    }
+                } else if (i >= -(long long)a.hl) v = hist[a.hl + i];
+                X[s] = v;
+            }
+        }
+        return sh;
+    }
+    const T *in = static_cast<const T *>(a.in) + (size_t)ch * a.in_stride;
+    const long long g0 = n_org - (long long)sh;
+    constexpr unsigned PIECE = 1024 / ESZ;                               // samples per wave instruction (1 KiB)
+    const unsigned pieces = (n_tile + sh + PIECE - 1u) / PIECE;
+    if (g0 >= 0 && g0 + (long long)pieces * PIECE <= a.n_in) {
+        dma(reinterpret_cast<const char *>(in + g0), lds_base, pieces);
     } else {
 #pragma unroll 1
         for (unsigned s = tid; s < n_tile + sh; s += 256u) {
@@ -94,6 +135,27 @@ __device__ __forceinline__ unsigned fetch_tile(const PolyTiledArgs &a, const typ
         }
     }
     return sh;
+}
+
+// the history workgroup's copy: the last hl samples of the call's input, converted where the input is u8
+template <bool CPLX>
+__device__ __forceinline__ void carry_history(const PolyTiledArgs &a, int ch, unsigned tid)
+{
+    typedef typename El<CPLX>::T T;
+    T *ho = static_cast<T *>(a.hist_out) + (size_t)ch * a.hl;
+    if (a.in_u8) {
+        constexpr int BSZ = CPLX ? 2 : 1;
+        const unsigned char *in8 = static_cast<const unsigned char *>(a.in) + ((size_t)ch * a.in_stride + (a.n_in - a.hl)) * BSZ;
+#pragma unroll 1
+        for (unsigned i = tid; i < (unsigned)a.hl; i += 256u) {
+            if constexpr (CPLX) ho[i] = (v2f){u8_to_f32(in8[2 * i]), u8_to_f32(in8[2 * i + 1])};
+            else ho[i] = u8_to_f32(in8[i]);
+        }
+        return;
+    }
+    const T *in = static_cast<const T *>(a.in) + (size_t)ch * a.in_stride;
+#pragma unroll 1
+    for (unsigned i = tid; i < (unsigned)a.hl; i += 256u) ho[i] = in[a.n_in - a.hl + i];
 }
 
 // UPM = phase sums compiled in (= UP), MB = m per thread run together, W = samples per LDS read (1: odd SP)
@@ -107,21 +169,18 @@ __global__ __launch_bounds__(256) void poly_rt_dma_kernel(PolyTiledArgs a)
     T *X = reinterpret_cast<T *>(smem);
     const unsigned tid = threadIdx.x;
     const int ch = blockIdx.y;
-    const T *in = static_cast<const T *>(a.in) + (size_t)ch * a.in_stride;
     const T *hist = static_cast<const T *>(a.hist) + (size_t)ch * a.hl;
     T *out = static_cast<T *>(a.out) + (size_t)ch * a.out_stride;
 
     if (a.hist_out && blockIdx.x == a.tiles) {        // the history workgroup (poly_tiled_kernel has the reasoning)
-        T *ho = static_cast<T *>(a.hist_out) + (size_t)ch * a.hl;
-#pragma unroll 1
-        for (unsigned i = tid; i < (unsigned)a.hl; i += 256u) ho[i] = in[a.n_in - a.hl + i];
+        carry_history<CPLX>(a, ch, tid);
         return;
     }
     const unsigned SP = (unsigned)a.SP;
     const int UP = a.UP, TMr = a.tm;
     const long long m0 = (long long)blockIdx.x * TMr;
     const long long n_org = (long long)SP * m0 + a.e_max - (a.Lp - 1);   // stream index of local sample 0
-    const unsigned sh = fetch_tile<CPLX>(a, in, hist, X, smem, n_org, SP * (unsigned)TMr + (unsigned)a.Lp, tid);
+    const unsigned sh = fetch_tile<CPLX>(a, ch, hist, X, smem, n_org, SP * (unsigned)TMr + (unsigned)a.Lp, tid);
     __syncthreads();
 
     // taps: row qt of Gt holds the UP phases' taps at local time qt (padded to 8 floats): ONE scalar load per tap
@@ -269,20 +328,17 @@ __global__ __launch_bounds__(256) void poly_int4_dma_kernel(PolyTiledArgs a)
     float *X = reinterpret_cast<float *>(smem);
     const unsigned tid = threadIdx.x;
     const int ch = blockIdx.y;
-    const float *in = static_cast<const float *>(a.in) + (size_t)ch * a.in_stride;
     const float *hist = static_cast<const float *>(a.hist) + (size_t)ch * a.hl;
     float *out = static_cast<float *>(a.out) + (size_t)ch * a.out_stride;
 
     if (a.hist_out && blockIdx.x == a.tiles) {        // the history workgroup
-        float *ho = static_cast<float *>(a.hist_out) + (size_t)ch * a.hl;
-#pragma unroll 1
-        for (unsigned i = tid; i < (unsigned)a.hl; i += 256u) ho[i] = in[a.n_in - a.hl + i];
+        carry_history<false>(a, ch, tid);
         return;
     }
     const int TMr = a.tm, Lp = a.Lp, Q = Lp >> 2;
     const long long m0 = (long long)blockIdx.x * TMr;
     const long long n_org = (long long)SPC * m0 + a.e_max - (Lp - 1);
-    fetch_tile<false>(a, in, hist, X, smem, n_org, (unsigned)(SPC * TMr) + (unsigned)Lp, tid);      // returns SH (launcher)
+    fetch_tile<false>(a, ch, hist, X, smem, n_org, (unsigned)(SPC * TMr) + (unsigned)Lp, tid);      // returns SH (launcher)
     __syncthreads();
 
     const __attribute__((address_space(4))) float *gt = (const __attribute__((address_space(4))) float *)a.Gt;
@@ -476,7 +532,7 @@ void launch_int4(int UP, int sh, const dim3 &grid, size_t lds, hipStream_t s, co
 bool poly_rt_dma_window_shape(int SP, int UP) { return int4_shape(SP, UP); }
 
 // SFE_ESTATE: the shape or the buffers are outside what this kernel takes (the caller runs launch_poly_tiled)
-int launch_poly_rt_dma(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int data_complex, int n_channels, hipStream_t s)
+int launch_poly_rt_dma(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int data_complex, int in_u8, int n_channels, hipStream_t s)
 {
     const int SP = plan.SP, UP = plan.UP;
     const int esz = data_complex ? 8 : 4, a16 = 16 / esz;
@@ -491,8 +547,9 @@ int launch_poly_rt_dma(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int d
         if (atoi(e)) sp_min = 1;
 #endif
     if (SP < sp_min || SP > 64 || UP < 1 || UP > 8 || plan.Lp <= 0 || !plan.d_Gt) return SFE_ESTATE;
-    // 16-byte lanes: every channel's first sample on a 16-byte boundary
-    if ((reinterpret_cast<uintptr_t>(a0.in) & 15u) || (n_channels > 1 && (a0.in_stride % a16))) return SFE_ESTATE;
+    // 16-byte lanes: every channel's first sample on a 16-byte boundary (u8 input: 8 complex or 16 real samples per lane)
+    const int in_a16 = in_u8 ? (data_complex ? 8 : 16) : a16;
+    if ((reinterpret_cast<uintptr_t>(a0.in) & 15u) || (n_channels > 1 && (a0.in_stride % in_a16))) return SFE_ESTATE;
 #ifdef SFE_DIAG
     if (const char *e = getenv("SFE_RT_DMA"))        // A/B against poly_rt_kernel in one process (scripts/time_shapes.py)
         if (!atoi(e)) return SFE_ESTATE;
@@ -527,6 +584,13 @@ int launch_poly_rt_dma(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int d
             a.y_off = (unsigned)lds;
             lds += regions;
         }
+    }
+    a.in_u8 = in_u8;
+    a.raw_off = 0;
+    if (in_u8) {                                     // + the tile's raw bytes: whole 1 KiB pieces from the 16-byte boundary below its first sample, 16 bytes of slack
+        a.raw_off = (unsigned)lds;
+        lds += (((size_t)SP * a.tm + plan.Lp + 16) * (data_complex ? 2 : 1) + 1023) / 1024 * 1024 + 16;
+        if (lds > 60 * 1024) return SFE_ESTATE;
     }
     const long long mtot = (a.n_out + UP - 1) / UP;
     const long long tiles = (mtot + a.tm - 1) / a.tm;

@@ -1186,6 +1186,12 @@ bool poly_tiled_supported(int SP, int UP, int Lp)
     return poly_tiled_compiled(SP, UP, Lp) || poly_rt_supported(SP, UP, Lp, 8);
 }
 bool poly_tiled_is_compiled(int SP, int UP, int Lp) { return poly_tiled_compiled(SP, UP, Lp); }
+// ... and, for wire-format (u8) input, the four of them that have a u8 form (launch_poly_tiled: SFE_U8); the other shapes' u8 streams run the
+// runtime-shape kernels
+bool poly_tiled_u8_is_compiled(int SP, int UP, int Lp)
+{
+    return poly_tiled_compiled(SP, UP, Lp) && ((UP == 1 && (SP == 2 || SP == 4 || SP == 8)) || (SP == 5 && UP == 3));
+}
 
 static int launch_poly_rt(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int data_complex, int exact, int in_u8,
                           int n_channels, hipStream_t s)

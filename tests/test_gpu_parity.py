@@ -888,6 +888,51 @@ def test_real_small_steps_by_register_window(api, L, orc, U, step, arm):
         assert synth.rel_rms(y[c], refs[c][:k]) <= TOL, (U, step, arm, c)
 
 
+@pytest.mark.parametrize("U,step", [(1, 7), (1, 16), (4, 7), (1, 6), (5, 4), (3, 10), (2, 1), (3, 1), (8, 1), (1, 2), (1, 3), (2, 3), (3, 5), (3, 2)])
+@pytest.mark.parametrize("cplx", [True, False])
+def test_u8_streams_by_lds_dma(api, L, orc, U, step, cplx):
+    """Round 5: the receive wire format (u8 offset binary; a complex sample = two bytes: gr-simplefe/lib/source_c_impl.cc, source_f_impl.cc) into
+    the LDS-DMA kernels -- the tile's raw bytes fetched by DMA and converted once, four bytes per step, into the float32 tile the kernels
+    read in place.  Three ways to the same bits: (a) u8 channels on 16-byte boundaries (the new path), (b) the same bytes one sample off
+    at an odd stride (poly_rt_kernel's u8 form, byte loads sample by sample; the compile-time kernels' where the shape has one), (c) the
+    float32 path fed the converted samples.  Two calls with carried state, three channels, a length that ends inside a tile."""
+    taps = synth.lowpass_taps(32 * U - (1 if U > 1 else 0), 0.9 * min(1.0 / U, 1.0 / step), gain=float(U))
+    rate = float(np.float32(step) / np.float32(U))
+    w = 2 if cplx else 1
+    n, nch = 5 * 4096 * max(1, step // 4) + 1235, 3
+    b = np.stack([_u8_stream(w * n, 40 + c) for c in range(nch)])
+    cap = n * U // step + 16
+    cap += (-cap) % 4
+    cut = (n // 2) // 4096 * 4096
+
+    def run_u8(offset_samples, stride):
+        buf = np.zeros(w * (offset_samples + stride * nch), np.uint8)
+        for c in range(nch):
+            buf[w * (offset_samples + stride * c): w * (offset_samples + stride * c) + w * n] = b[c]
+        d = api.DeviceArray.from_bytes(buf)
+        d_out = api.DeviceArray(w * cap * nch)
+        r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=cplx, n_channels=nch)
+        r.set_algo(L.RS_ALGO_DIRECT)
+        r.set_input_format(L.FMT_U8)
+        k1 = r.process_stream(d.ptr + w * offset_samples, cut, d_out, cap, rate, in_stride=stride, out_stride=cap)
+        k2 = r.process_stream(d.ptr + w * (offset_samples + cut), n - cut, d_out.ptr + 4 * w * k1, cap - k1, rate, in_stride=stride, out_stride=cap)
+        return k1 + k2, d_out.to_numpy().reshape(nch, w * cap)[:, : w * (k1 + k2)]
+
+    al = (n + 15) // 16 * 16
+    k, y = run_u8(0, al)
+    ku, yu = run_u8(1, al + 1)
+    assert k == ku and np.array_equal(y, yu), (U, step, cplx)
+    xf = np.stack([orc.rx_u8_to_f32(b[c]) for c in range(nch)])
+    rf = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=cplx, n_channels=nch)
+    rf.set_algo(L.RS_ALGO_DIRECT)
+    d = api.DeviceArray.from_numpy(np.ascontiguousarray(np.pad(xf, ((0, 0), (0, w * (al - n))))))
+    d_out = api.DeviceArray(w * cap * nch)
+    k1 = rf.process_stream(d, cut, d_out, cap, rate, in_stride=al, out_stride=cap)
+    k2 = rf.process_stream(d.ptr + 4 * w * cut, n - cut, d_out.ptr + 4 * w * k1, cap - k1, rate, in_stride=al, out_stride=cap)
+    yf = d_out.to_numpy().reshape(nch, w * cap)[:, : w * (k1 + k2)]
+    assert k1 + k2 == k and np.array_equal(y, yf), (U, step, cplx)
+
+
 # ----------------------------------------------------------------- edge cases / misuse
 def test_empty_and_tiny_inputs(api, L, orc):
     """n = 0 is a no-op; n < n_taps works and carries state; 1-tap filter is a gain."""
