@@ -22,7 +22,7 @@
 // Shapes: complex AND real float32 streams (real: libdsp's native type), fused arithmetic, SP >= 2, UP = 1 ... 8; three or more outputs
 // per m leave through the waves' LDS regions as contiguous kilobytes.  SP = 1, the pure interpolators: real streams up to x7 run the second
 // kernel of this file, poly_int4_dma_kernel (the same fetch; four consecutive m per lane, their samples read as 16-byte groups into a register
-// window), real x8 and complex x6 / x8 the first one.  Exact mode, u8 streams and the other complex interpolators keep poly_rt_kernel /
+// window), real x8 and complex x6 / x8 the first one.  Wire-format (u8) input: fetch_tile.  Exact mode and the other complex interpolators keep poly_rt_kernel /
 // poly_rt1_kernel, and so do calls whose channels do not start on 16-byte boundaries.  VERDICT r4 item 6; profiles/r05/shapes_rt_dma.txt
 // (complex: /7 0.54 -> 0.43 ms, 7/4 0.72 -> 0.59, /13 0.50 -> 0.40, /48 0.49 -> 0.37, 10/3 0.71 -> 0.50 ...), profiles/r05/shapes_real.txt,
 // profiles/r05/shapes_interpolators.txt.
