@@ -559,7 +559,7 @@ def make_rs_leg(ctx, which, log2n, in_fmt="f32", short_proto=False):
     return leg
 
 
-def make_general_rate_leg(ctx, log2n=28, rate=1.77, interpolate=0, decimate=0):
+def make_general_rate_leg(ctx, log2n=28, rate=1.77, interpolate=0, decimate=0, real=False, u8=False):
     """the general (non-integer-step) rate at bulk size -- BASELINE cfg3's 381-tap prototype in 3 phases at
     rate 1.77 (the rate of the reference's own driver, libdsp/test/test_decimate.py:24), 2^28 cf32 in.  The library's default
     dispatch takes the transform-domain kernel (poly_gen.hip).  Not a BASELINE config: an other_configs row.
@@ -594,14 +594,30 @@ def make_general_rate_leg(ctx, log2n=28, rate=1.77, interpolate=0, decimate=0):
         leg.name = "decimate_by_%d" % decimate
         leg.workload = "decimate by %d, 32-tap anti-alias FIR (a shape outside the compiled tables), 2^%d cf32 in" % (decimate, log2n)
         leg.key = "decimate%d_cf32_2p%d" % (decimate, log2n)
-    x = torch.empty(n * 2, dtype=torch.float32, device=dev)
-    api.check(L.sfe_dsp_synth_fill(x.data_ptr(), 2 * n, synth.SEED, 0, 0, stream))
+    # the same 2^(log2n + 3) bytes of synthetic float32 stream serve every form of the input: complex samples, (real) twice as many real
+    # samples -- libdsp's native type, the reference's classes take float* --, or (u8) its first 2^(log2n + 1) bytes read as the receive
+    # wire format, u8 offset-binary (I, Q) pairs (gr-simplefe/lib/source_c_impl.cc)
+    w = 1 if real else 2
+    if real:
+        n = 2 * n
+        leg.n = leg.n_gpu = n
+        leg.name += "_real"
+        leg.workload = "decimate by %d, 32-tap anti-alias FIR, REAL float32 stream (libdsp's native type), 2^%d real samples in" % (decimate, log2n + 1)
+        leg.key = "decimate%d_f32_2p%d" % (decimate, log2n + 1)
+    if u8:
+        leg.name += "_u8"
+        leg.workload = "decimate by %d, 32-tap anti-alias FIR, u8 wire-format input (I, Q byte pairs) -> cf32, 2^%d complex samples in" % (decimate, log2n)
+        leg.key = "decimate%d_u8_2p%d" % (decimate, log2n)
+    x = torch.empty((1 << log2n) * 2, dtype=torch.float32, device=dev)
+    api.check(L.sfe_dsp_synth_fill(x.data_ptr(), x.numel(), synth.SEED, 0, 0, stream))
     out_cap = int(n / rate) + 4096
     leg.x = x
-    leg.y = torch.empty(out_cap * 2, dtype=torch.float32, device=dev)
-    leg.input_spec = [(0, 2 * n, 0)]
-    leg.obj = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=True, n_channels=1, device=ctx["local_rank"])
-    leg.kernel = "poly_rt1_kernel" if interpolate else ("poly_rt_dma_kernel" if decimate else "poly_gen4096_kernel")
+    leg.y = torch.empty(out_cap * w, dtype=torch.float32, device=dev)
+    leg.input_spec = [(0, x.numel(), 0)]
+    leg.obj = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=not real, n_channels=1, device=ctx["local_rank"])
+    if u8:
+        leg.obj.set_input_format(lib.FMT_U8)
+    leg.kernel = "poly_rt1_kernel" if interpolate else (("poly_int4_dma_kernel" if real else "poly_rt_dma_kernel") if decimate else "poly_gen4096_kernel")
     leg.n_out = 0
     sp, yp = x.data_ptr(), leg.y.data_ptr()
 
@@ -609,24 +625,30 @@ def make_general_rate_leg(ctx, log2n=28, rate=1.77, interpolate=0, decimate=0):
         leg.n_out = leg.obj.process_stream(sp, n, yp, out_cap, rate, stream=stream)
     leg.step = step
     step()
-    leg.bytes_per_launch = 8.0 * n + 8.0 * leg.n_out
+    leg.bytes_per_launch = (2.0 if u8 else 4.0 * w) * n + 4.0 * w * leg.n_out
 
     def check(full):
         from oracle import binding as orc
         m = 1 << 20
-        r = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=True, n_channels=1, device=ctx["local_rank"])
+        r = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=not real, n_channels=1, device=ctx["local_rank"])
+        if u8:
+            r.set_input_format(lib.FMT_U8)
         if not interpolate and not decimate:
             r.set_algo(lib.RS_ALGO_FFT)         # the kernel the timed leg's bulk calls take, also at this size
-        y = torch.empty((int(m / rate) + 64) * 2, dtype=torch.float32, device=dev)
-        k = r.process_stream(sp, m, y.data_ptr(), y.numel() // 2, rate, stream=stream)
+        y = torch.empty((int(m / rate) + 64) * w, dtype=torch.float32, device=dev)
+        k = r.process_stream(sp, m, y.data_ptr(), y.numel() // w, rate, stream=stream)
         torch.cuda.synchronize()
-        got, xin = y[: 2 * k].cpu().numpy(), x[: 2 * m].cpu().numpy()
+        got = y[: w * k].cpu().numpy()
+        if u8:                                  # the oracle's own converter over the same bytes (gr-simplefe/lib/source_c_impl.cc's (b - 128) / 127)
+            xin = orc.rx_u8_to_f32(x[: m // 2].cpu().numpy().view(np.uint8))
+        else:
+            xin = x[: w * m].cpu().numpy()
         worst = 0.0
-        for part in (0, 1):
-            ref, _ = orc.Resample(taps, U, 4096).stream(np.ascontiguousarray(xin[part::2]), rate)
+        for part in range(w):
+            ref, _ = orc.Resample(taps, U, 4096).stream(np.ascontiguousarray(xin[part::w]), rate)
             if len(ref) != k:
                 return 1.0, 1, k                # a different number of outputs is a failure whatever the values
-            worst = max(worst, synth.rel_rms(got[part::2], ref))
+            worst = max(worst, synth.rel_rms(got[part::w], ref))
         return worst, 1, k
     leg.check = check
     return leg
@@ -916,6 +938,8 @@ def main():
                   lambda: make_general_rate_leg(ctx),
                   lambda: make_general_rate_leg(ctx, interpolate=2),
                   lambda: make_general_rate_leg(ctx, decimate=7),
+                  lambda: make_general_rate_leg(ctx, decimate=3, real=True),
+                  lambda: make_general_rate_leg(ctx, decimate=7, u8=True),
                   lambda: make_fir_leg(ctx, "fir_64ch", synth.taps_cfg2(), 1 << 24, 64),
                   lambda: make_fir_leg(ctx, "fir_64ch_pctaps", synth.taps_per_channel(64), 1 << 24, 64, per_channel=True,
                                        x_share=next(l.x for l in others if l.name == "fir_64ch")),

@@ -122,3 +122,20 @@ def test_bench_default_line_small():
         assert "error" in row or "buffers" not in row
     cb = j["cpu_baseline"]
     assert cb["cores"] == 1 and cb["all_cores"]["cores"] == cb["host_cores"] >= 1
+
+
+def test_bench_driver_shape_line_carries_every_row_checked():
+    """The driver's own command shape at full size (fewer steps): the headline and EVERY other_configs row -- the BASELINE configs, the general
+    rate, and round 5's rows for the kernels of poly_rt_dma.hip: a complex decimation outside the compiled tables, a REAL float32 stream
+    (libdsp's native type) through the register-window kernel, the u8 receive wire format through the LDS-DMA fetch -- parity-checked against
+    the oracle on the box that timed it; no row missing, none in error."""
+    r, j = _bench("--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu", timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert j["parity"]["ok"]
+    rows = j["other_configs"]
+    assert all("error" not in row for row in rows), rows
+    assert len(rows) == 11 and all(row["parity"]["ok"] for row in rows), [row.get("workload") for row in rows]
+    kernels = {row["kernel"] for row in rows}
+    assert {"poly_fft256_kernel", "poly_tiled_kernel", "poly_gen4096_kernel", "poly_rt1_kernel", "poly_rt_dma_kernel", "poly_int4_dma_kernel",
+            "fir_fft4096_kernel"} <= kernels, kernels
+    assert any("REAL float32 stream" in row["workload"] for row in rows) and any("u8 wire-format input" in row["workload"] for row in rows)
