@@ -15,23 +15,27 @@ if os.environ.get("DIAG") == "1":          # the diagnostic library: SFE_RT_DMA_
 from simplefe_amd import api, synth  # noqa: E402
 
 n = 1 << int(os.environ.get("LOG2N", "28"))
+REAL = os.environ.get("REAL") == "1"          # real u8 streams (source_f_impl.cc: one byte per sample): 2^29 samples from the same bytes
+if REAL:
+    n *= 2
+w = 1 if REAL else 2
 SHAPES = [("decimate by 2", 1, 2, 32), ("decimate by 4", 1, 4, 32), ("decimate by 8 (64 taps)", 1, 8, 64), ("decimate by 7", 1, 7, 32), ("decimate by 16", 1, 16, 32),
           ("5/3", 3, 5, 30), ("7/4", 4, 7, 32), ("3/2", 2, 3, 36), ("decimate by 6", 1, 6, 32), ("decimate by 12", 1, 12, 32), ("7/3", 3, 7, 32), ("4/5", 5, 4, 32),
           ("interpolate x2", 2, 1, 32), ("interpolate x4", 4, 1, 32), ("decimate by 3", 1, 3, 36), ("decimate by 5", 1, 5, 30), ("2/3", 3, 2, 32), ("3/4", 4, 3, 36)]
-x = api.DeviceArray(2 * n)            # float32 stream; its first 2^29 bytes double as the u8 stream
+x = api.DeviceArray(w * n)            # float32 stream; its first 2^29 bytes double as the u8 stream
 x.fill_synth(synth.SEED)
 t = api.Timer()
 warm = False
-print(f"# 2^{n.bit_length() - 1} complex samples in; SFE_RT_DMA_U8={os.environ.get('SFE_RT_DMA_U8', '1')}")
+print(f"# 2^{n.bit_length() - 1} {'real' if REAL else 'complex'} samples in; SFE_RT_DMA_U8={os.environ.get('SFE_RT_DMA_U8', '1')}")
 print(f"{'shape':26s} {'U':>2s} {'step':>4s} {'u8 ms':>8s} {'frac':>6s} {'f32 ms':>8s} {'frac':>6s}")
 for name, U, step, lp in SHAPES:
     rate = float(np.float32(step) / np.float32(U))
     taps = synth.lowpass_taps(lp * U, 0.9 * min(1.0 / U, 1.0 / step), gain=float(U))
     cap = n * U // step + 64
-    y = api.DeviceArray(2 * cap)
+    y = api.DeviceArray(w * cap)
     res = []
     for u8 in (True, False):
-        r = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=True)
+        r = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=not REAL)
         if u8:
             r.set_input_format(lib.FMT_U8)
         for _ in range(4 if warm else 150):
@@ -45,7 +49,7 @@ for name, U, step, lp in SHAPES:
             t.stop()
             v.append(t.elapsed_ms() / 3)
         ms = float(np.median(v))
-        res += [ms, ((2.0 if u8 else 8.0) * n + 8.0 * k) / 1e9 / ms / 8.0]
+        res += [ms, ((0.5 if u8 else 2.0) * w * 2 * n + 4.0 * w * k) / 1e9 / ms / 8.0]
         r.close()
     y.free()
     print(f"{name:26s} {U:2d} {step:4d} {res[0]:8.4f} {res[1]:6.3f} {res[2]:8.4f} {res[3]:6.3f}", flush=True)

@@ -445,7 +445,7 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
             // float shapes included -- ran poly_rt_kernel's sample-by-sample byte loads (/7 0.71 ms where the float32 stream takes 0.45) and now
             // has its raw tile fetched by DMA and converted once (0.38 ms): profiles/r05/shapes_u8.txt
             const bool compiled = r->in_u8 ? poly_tiled_u8_is_compiled(pl->SP, pl->UP, pl->Lp) : poly_tiled_is_compiled(pl->SP, pl->UP, pl->Lp);
-            bool try_dma = !r->exact_stream && (!compiled || (window_shape && !r->in_u8));
+            bool try_dma = !r->exact_stream && (!compiled || window_shape);       // (real u8 streams at the window form's shapes: /2 0.72 -> 0.6 ms, profiles/r05/shapes_u8.txt)
 #ifdef SFE_DIAG
             if (const char *e = getenv("SFE_RT_DMA_FORCE"))        // scripts/ab_dec8_dma.py: the LDS-DMA form also where a compile-time kernel exists
                 if (atoi(e) && !r->exact_stream) try_dma = true;
