@@ -11,5 +11,8 @@ timeout -k 10 300 python3 scripts/time_real_shapes.py > $O/shapes_real_final.txt
 EXTRA=3 SHAPES="interpolate" timeout -k 10 300 python3 scripts/time_shapes.py > $O/shapes_interp_cplx.txt 2>&1 || echo interp failed
 timeout -k 10 300 python3 scripts/time_real_baseline.py > $O/baseline_real.txt 2>&1 || echo real baseline failed
 cat $O/baseline_real.txt
+timeout -k 10 300 python3 scripts/time_u8_shapes.py > $O/shapes_u8_final.txt 2>&1 || echo u8 failed
+REAL=1 timeout -k 10 300 python3 scripts/time_u8_shapes.py >> $O/shapes_u8_final.txt 2>&1 || echo u8 real failed
+timeout -k 10 400 python3 scripts/time_real_compiled.py > $O/shapes_real_compiled_final.txt 2>&1 || echo real compiled failed
 cut -c1-110 $O/shapes_main.txt; cat $O/shapes_real_final.txt
 echo collected final

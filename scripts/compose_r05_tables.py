@@ -19,6 +19,14 @@ s = open(P + "shapes_real.txt").read()
 marker = "#### the LAST GPU call"
 s = s[:s.index(marker)] + marker + " (final tree -- the window kernel at input steps 1 ... 5 included; the first shape is preceded by 150 warm-up launches)\n" + open(T + "shapes_real_final.txt").read()
 open(P + "shapes_real.txt", "w").write(s)
+for dst, src, what in (("shapes_u8.txt", "shapes_u8_final.txt", "u8 wire-format input, complex then real streams, the product library's default dispatch"),
+                       ("shapes_real_window.txt", "shapes_real_compiled_final.txt", "the ratios with compile-time kernels, real and complex streams, the product library's default dispatch")):
+    if os.path.exists(T + src):
+        s = open(P + dst).read()
+        if marker in s:
+            s = s[:s.index(marker)]
+        open(P + dst, "w").write(s.rstrip("\n") + "\n" + marker + " (final tree): " + what + "\n" + open(T + src).read())
+        os.remove(T + src)
 for f in ("shapes_main.txt", "shapes_long.txt", "shapes_interp_cplx.txt", "shapes_real_final.txt"):
     os.remove(T + f)
 b = open(T + "baseline_real.txt").read()
