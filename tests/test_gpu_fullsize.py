@@ -506,3 +506,72 @@ def test_general_rate_real_and_u8_streams_at_2pow26(api, L, orc, fmt):
     n = 1 << 26
     k, worst = _general_rate_windows(api, L, orc, synth.taps_cfg3(), 3, 1.77, n, [(1 << 25) + 3 * 4096], fmt, 12, 5, 30)
     print(f"general rate 1.77, {fmt}: {k} outputs, worst rel-RMS {worst:.2e}")
+
+
+def _windows_any_format(orc, y, taps, U, S, k0s, W, n_in, fmt, hist_samples):
+    """_rs_windows_vs_oracle for the three input forms of ONE buffer of synthetic float32: "cf32" (complex samples), "f32" (real samples:
+    float i of the stream) and "u8" (the stream's bytes read as (I, Q) byte pairs, converted by the oracle's own rx converter); the
+    fused default kernels, so within TOL.  Returns the worst rel-RMS."""
+    w = 1 if fmt == "f32" else 2
+    g = int(np.gcd(S, U))
+    per = S // g
+    rate = float(np.float32(S) / np.float32(U))
+    worst = 0.0
+    for k0 in k0s:
+        nin0 = (k0 * S) // U
+        a0 = max(0, ((nin0 - hist_samples - per) // per) * per)
+        if fmt == "u8":
+            a0 -= a0 % (2 * per)                   # whole floats: two complex u8 samples each
+        j0 = k0 - a0 * U // S
+        n_span = min(((k0 + W) * S) // U + 2 - a0, n_in - a0)
+        if fmt == "u8":
+            n_span -= n_span % 2
+            seg = orc.rx_u8_to_f32(synth.synth_f32(n_span // 2, first=a0 // 2).view(np.uint8))
+        else:
+            seg = synth.synth_f32(w * n_span, first=w * a0)
+        got = y.to_numpy(w * W, offset=w * k0)
+        for part in range(w):
+            ref, _ = orc.Resample(taps, U, 4096).stream(np.ascontiguousarray(seg[part::w]), rate)
+            m = min(W, len(ref) - j0)
+            assert m > W // 2, (fmt, k0, m)
+            e = synth.rel_rms(got[part::w][:m], ref[j0:j0 + m])
+            worst = max(worst, e)
+            assert e <= TOL, (fmt, U, S, k0, part, e)
+    return worst
+
+
+def test_round5_kernels_parity_at_scale(api, L, orc):
+    """SURVEY.md 8(d) "parity check at scale" for the kernels of poly_rt_dma.hip, at the sizes bench.py times them: 2^31 bytes of synthetic
+    stream read as 2^28 complex samples (decimate by 7, 7/4: the LDS-DMA kernel), as 2^29 real samples (decimate by 3, 2/3, interpolate x4:
+    the register-window kernel) and as u8 (I, Q) byte pairs (decimate by 7 from the first 2^29 bytes: the raw tile by DMA, converted once) --
+    16 windows of 2^15 outputs each: the stream's start and end, tile seams, seeded random places; the oracle fed the window's input span
+    plus history (libdsp/decimate.cxx:132-140, libdsp/resample.cxx:100-114 at an integer step)."""
+    rng = np.random.default_rng(synth.SEED + 5)
+    W = 1 << 15
+    nf = 1 << 29                                   # floats in the buffer
+    x = api.DeviceArray(nf)
+    x.fill_synth(synth.SEED)
+    for fmt, U, S in (("cf32", 1, 7), ("cf32", 4, 7), ("f32", 1, 3), ("f32", 3, 2), ("f32", 4, 1), ("u8", 1, 7)):
+        w = 1 if fmt == "f32" else 2
+        n = nf if fmt == "f32" else (nf // 2 if fmt == "cf32" else nf // 2)      # samples: u8 reads the first 2^29 bytes = 2^28 complex samples
+        if fmt == "u8":
+            n = nf // 2
+        taps = synth.lowpass_taps(32 * U - (1 if U > 1 else 0), 0.9 * min(1.0 / U, 1.0 / S), gain=float(U))
+        rate = float(np.float32(S) / np.float32(U))
+        cap = n * U // S + 64
+        y = api.DeviceArray(w * cap)
+        r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=fmt != "f32")
+        if fmt == "u8":
+            r.set_input_format(L.FMT_U8)
+        k = r.process_stream(x, n, y, cap, rate)
+        assert abs(k - n * U // S) <= 1, (fmt, U, S, k)
+        per_out = U // int(np.gcd(S, U))
+        starts = [0, k - 2 - W, (k // 2), 4096 * per_out * 1000 - W // 2, 2048 * per_out * 33333 + 5]
+        while len(starts) < 16:
+            starts.append(int(rng.integers(0, k - 2 - W)))
+        k0s = sorted({max(0, min(s0, k - 2 - W) - min(s0, k - 2 - W) % (12 * per_out)) for s0 in starts})       # inside the stream, on whole phase periods
+        worst = _windows_any_format(orc, y, taps, U, S, k0s, W, n, fmt, hist_samples=40)
+        print(f"{fmt} {S}/{U}: {len(k0s)} windows of 2^15 outputs at n = 2^{n.bit_length() - 1}, worst rel-RMS {worst:.2e}")
+        r.close()
+        y.free()
+    x.free()
