@@ -994,6 +994,10 @@ def main():
             # happen to be backed physically, not to the kernel (profiles/r04/NOTES.md): plain allocations, so the row is
             # whichever of the two this process was handed
             row["note"] = "plain allocations: one of two placement modes ~6 % apart (profiles/r04/NOTES.md)"
+        if leg.name.endswith("_u8"):
+            # 2 bytes per input sample: a quarter of the float32 row's input, in the same or less time -- this launch is bound ON the chip (the
+            # tile's conversion and its LDS reads), so its fraction of the HBM roofline says little about it
+            row["note"] = "u8 input moves a quarter of the float32 row's input bytes: bound on the chip, compare ms with the float32 row of the same ratio"
         if world > 1:
             row["scaling"] = "weak"
             row["workload"] += " -- per rank, %d ranks (weak scaling: the per-GPU launch is the same at every N)" % world
