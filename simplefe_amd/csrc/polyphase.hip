@@ -82,8 +82,12 @@ __device__ __forceinline__ typename Elem<CPLX>::T vload_u8(const unsigned char *
 
 // ------------------------------------------------------------------ integer-step law
 // One workgroup = TILE consecutive outputs.  LDS: [tile_in_cap] samples + [U*plen] taps.
+// sparse (round 5; the launcher sets it when step >= U * plen: every output's plen samples are its own): the LDS holds the tile's WINDOWS
+// back to back -- plen samples per output -- instead of the whole span between the first and the last, which at a step of 128 or 1000
+// neither fits nor is needed (until round 5 the bulk call REFUSED steps beyond ~117: "step too large for the LDS tile"; the
+// reference's decimate takes any rate >= 1, libdsp/decimate.cxx:75-78).  Same sums in the same order.
 template <bool CPLX, bool EXACT>
-__global__ __launch_bounds__(256) void poly_int_kernel(PolyArgs a, int tile_out, int tile_in_cap)
+__global__ __launch_bounds__(256) void poly_int_kernel(PolyArgs a, int tile_out, int tile_in_cap, int sparse)
 {
     typedef typename Elem<CPLX>::T T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -104,7 +108,14 @@ __global__ __launch_bounds__(256) void poly_int_kernel(PolyArgs a, int tile_out,
     const long long n_hi = floordiv(p_last, a.U);
     const int tile_len = (int)(n_hi - n_lo + 1);
 
-    if (n_lo >= 0 && n_lo + tile_len <= a.n_in) {
+    if (sparse) {
+        const unsigned cnt = (unsigned)(k1 - k0) * (unsigned)a.plen;
+        for (unsigned idx = threadIdx.x; idx < cnt; idx += 256u) {
+            const unsigned w = idx / (unsigned)a.plen, j = idx - w * (unsigned)a.plen;        // window w, its j-th sample in time order
+            const long long n = floordiv(a.pos0 + (k0 + w) * a.step, a.U);
+            xs[idx] = vload<CPLX>(in, hist, n - (a.plen - 1) + j, a.n_in, a.hl);
+        }
+    } else if (n_lo >= 0 && n_lo + tile_len <= a.n_in) {
         // an interior tile: eight requests per thread in flight at a time (the guarded loop below is one load -> wait ->
         // LDS write per iteration, one memory latency after the other; poly_seg_kernel has the measurement)
         const T *src = in + n_lo;
@@ -124,17 +135,22 @@ __global__ __launch_bounds__(256) void poly_int_kernel(PolyArgs a, int tile_out,
     } else {
         for (int i = threadIdx.x; i < tile_len; i += 256) xs[i] = vload<CPLX>(in, hist, n_lo + i, a.n_in, a.hl);
     }
-    for (int i = threadIdx.x; i < a.U * a.plen; i += 256) ts[i] = a.taps[i];
+    // the taps TRANSPOSED, ts[j U + phase]: consecutive outputs sit in different phases (phase = (pos0 + k step) mod U), and phase-major rows
+    // plen floats apart put a wave's reads of tap j into ONE bank -- 10/9, 16/15, 25/24 ran at 0.05-0.10 of the roofline until round 5
+    for (int i = threadIdx.x; i < a.U * a.plen; i += 256) {
+        const int ph = i / a.plen, j = i - ph * a.plen;
+        ts[j * a.U + ph] = a.taps[i];
+    }
     __syncthreads();
 
     for (long long k = k0 + threadIdx.x; k < k1; k += 256) {
         const long long p = a.pos0 + k * a.step;
         const long long n = floordiv(p, a.U);
         const int ph = (int)(p - n * a.U);
-        const float *tp = ts + ph * a.plen;
-        const T *xp = xs + (n - n_lo);
+        const float *tp = ts + ph;
+        const T *xp = sparse ? xs + ((k - k0) * a.plen + (a.plen - 1)) : xs + (n - n_lo);      // the sample at time n
         T acc = Elem<CPLX>::zero();
-        for (int j = 0; j < a.plen; j++) acc = mac<EXACT>(acc, tp[j], xp[-j]);
+        for (int j = 0; j < a.plen; j++) acc = mac<EXACT>(acc, tp[j * a.U], xp[-j]);
         out[k] = acc;
     }
 }
@@ -1095,8 +1111,10 @@ int launch_poly_int(const PolyArgs &a, int data_complex, int /*taps_complex*/, i
         return SFE_EINVAL;
     }
     long long tile_out = 2048;
-    auto need = [&](long long to) { return (to * a.step) / a.U + a.plen + 3; };
-    while (tile_out > 64 && need(tile_out) * esz > budget) tile_out >>= 1;
+    // windows that do not overlap (step >= U plen): the tile holds the outputs' own plen samples each and nothing between them
+    const int sparse = (long long)a.step >= (long long)a.U * a.plen;
+    auto need = [&](long long to) { return sparse ? to * a.plen : (to * a.step) / a.U + a.plen + 3; };
+    while (tile_out > 1 && need(tile_out) * esz > budget) tile_out >>= 1;      // (down to ONE output per workgroup: slow and correct)
     if (need(tile_out) * esz > budget) {
         set_error("polyphase: step %d too large for the LDS tile", a.step);
         return SFE_EINVAL;
@@ -1109,7 +1127,7 @@ int launch_poly_int(const PolyArgs &a, int data_complex, int /*taps_complex*/, i
         return SFE_EINVAL;
     }
     dim3 grid((unsigned)nb, (unsigned)n_channels), block(256);
-#define LAUNCH(C, E) hipLaunchKernelGGL((poly_int_kernel<C, E>), grid, block, shmem, s, a, (int)tile_out, tile_in_cap)
+#define LAUNCH(C, E) hipLaunchKernelGGL((poly_int_kernel<C, E>), grid, block, shmem, s, a, (int)tile_out, tile_in_cap, sparse)
     if (data_complex) { if (exact) LAUNCH(true, true); else LAUNCH(true, false); }
     else { if (exact) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH

@@ -933,6 +933,35 @@ def test_u8_streams_by_lds_dma(api, L, orc, U, step, cplx):
     assert k1 + k2 == k and np.array_equal(y, yf), (U, step, cplx)
 
 
+@pytest.mark.parametrize("U,step,n_taps", [(1, 128, 32), (1, 250, 64), (1, 1000, 32), (1, 4000, 16), (3, 128, 96), (1, 100, 128), (2, 129, 300), (1, 117, 32), (5, 512, 40),
+                                            (9, 10, 285), (15, 16, 477), (24, 25, 768), (10, 9, 317), (160, 147, 5117), (32, 33, 1024), (64, 66, 2040)])
+@pytest.mark.parametrize("cplx", [True, False])
+def test_steps_beyond_the_tiled_kernels(api, L, orc, U, step, n_taps, cplx):
+    """Round 5: the reference's decimate / resample take ANY rate >= 1 resp. >= 1 / upsample (libdsp/decimate.cxx:75-78, resample.cxx:91);
+    until now the bulk call refused integer steps beyond ~117 ("step too large for the LDS tile").  The generic kernel now holds, where the
+    outputs' windows do not overlap (step >= upsample * taps per phase), each output's own samples and nothing between them, and shrinks
+    its tile where they do overlap; and ratios with more than eight outputs per period (10/9, 16/15, 25/24, 147/160 ...: the same generic kernel,
+    its taps transposed in the LDS so that a wave's lanes -- consecutive outputs, consecutive phases -- read different banks).  Exact mode: the oracle's bits (itself bit-exact with the compiled reference); default mode: within
+    1e-5; two calls with carried state; decimate mode where upsample is 1."""
+    rate = float(np.float32(step) / np.float32(U))
+    taps = synth.lowpass_taps(n_taps, 0.9 * min(1.0 / U, 1.0 / step), gain=float(U))
+    w = 2 if cplx else 1
+    n = 24 * 4096
+    x = synth.synth_f32(w * n, ch=77)
+    refs = [orc.Resample(taps, U, 4096).stream(np.ascontiguousarray(x[part::w]), rate)[0] for part in range(w)]
+    for exact in (True, False):
+        r = api.Rs(taps, U, 4096, mode=L.RS_DECIMATE if U == 1 else L.RS_RESAMPLE, data_complex=cplx)
+        r.set_exact(exact)
+        y = r.resample_array(x, rate, chunk=10 * 4096)[0]
+        for part in range(w):
+            got, ref = y[part::w], refs[part]
+            assert len(ref) - len(got) in (0, 1) and len(got) > 0, (U, step, len(ref), len(got))
+            if exact:
+                assert np.array_equal(got, ref[: len(got)]), (U, step, n_taps, cplx)
+            else:
+                assert synth.rel_rms(got, ref[: len(got)]) <= TOL, (U, step, n_taps, cplx)
+
+
 # ----------------------------------------------------------------- edge cases / misuse
 def test_empty_and_tiny_inputs(api, L, orc):
     """n = 0 is a no-op; n < n_taps works and carries state; 1-tap filter is a gain."""
