@@ -317,7 +317,10 @@ int sfe_dsp_rs_process(sfe_rs_t h, const float *in, int n_in, float *out, int ou
  * input and output byte ranges -- (n_channels-1)*stride + n_in resp. out_cap elements -- must
  * not overlap; violations return SFE_EINVAL before anything is launched.  Any such alignment gives the same bits; channels whose
  * first sample sits on a 16-byte boundary (sfe_dsp_malloc memory, strides that are multiples of 16 bytes) take the kernels that fetch
- * their tiles by 16-byte DMA lanes -- 15-35 % faster at ratios without a compile-time kernel, up to 3x for u8 input. */
+ * their tiles by 16-byte DMA lanes -- 15-35 % faster at ratios without a compile-time kernel, up to 3x for u8 input.
+ * SFE_FMT_U8 input is accepted at every rate the float32 path takes: where no kernel converts on load (steps of more than 64 samples, more
+ * than 8 outputs per period, a general rate with a small blksize) the call converts its bytes once into a scratch buffer the handle owns and
+ * grows (4 x the call's input bytes; not while the stream is being captured) and runs the float32 path -- the same bits. */
 int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t in_stride,
                               void *d_out, size_t out_cap, size_t out_stride, float rate,
                               size_t *n_out, sfe_stream_t stream);

@@ -35,6 +35,7 @@ void rs_free(Rs *r)
     if (r->d_pos) (void)hipFree(r->d_pos);
     if (r->d_mu) (void)hipFree(r->d_mu);
     if (r->h_stage) (void)hipHostFree(r->h_stage);
+    if (r->d_u8f) (void)hipFree(r->d_u8f);
     if (r->h_pos) (void)hipHostFree(r->h_pos);
     if (r->h_mu) (void)hipHostFree(r->h_mu);
     if (r->d_segs) (void)hipFree(r->d_segs);
@@ -291,9 +292,52 @@ int sfe_dsp_rs_process(sfe_rs_t h, const float *in, int n_in, float *out, int ou
     return SFE_OK;
 }
 
+static int rs_process_stream_impl(sfe_rs_t h, const void *d_in, size_t n_in, size_t in_stride,
+                                  void *d_out, size_t out_cap, size_t out_stride, float rate,
+                                  size_t *n_out, sfe_stream_t stream);
+
 int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t in_stride,
                               void *d_out, size_t out_cap, size_t out_stride, float rate,
                               size_t *n_out, sfe_stream_t stream)
+{
+    Rs *r = as_rs(h);
+    if (r) r->u8_refused = false;
+    int rc = rs_process_stream_impl(h, d_in, n_in, in_stride, d_out, out_cap, out_stride, rate, n_out, stream);
+    if (rc != SFE_ESTATE || !r || !r->in_u8 || !r->u8_refused) return rc;
+    // Wire-format input on a shape that has no fused u8 kernel (integer steps beyond the tiled kernels' -- more than 64 samples or 8 outputs per
+    // period --, a general rate the transform-domain kernel does not take): until round 5 such a call was REFUSED.  Nothing has been launched and
+    // no state touched: convert the call's bytes once (the same (b - 128) * (1 / 127) as every fused path: the same bits) and run the float path.
+    SFE_ON_DEVICE(r->device);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t w = r->data_complex ? 2 : 1, floats = (size_t)r->n_channels * n_in * w;
+    if (floats > r->d_u8f_floats) {
+        if (stream_is_capturing(s)) {
+            set_error("rs_process_stream: this u8 call needs %zu bytes of conversion scratch, which cannot be allocated while the stream is being captured",
+                      floats * 4);
+            return SFE_ESTATE;
+        }
+        if (r->d_u8f) (void)hipFree(r->d_u8f);
+        r->d_u8f = nullptr;
+        r->d_u8f_floats = 0;
+        SFE_HIP(hipMalloc(&r->d_u8f, floats * sizeof(float)));
+        r->d_u8f_floats = floats;
+    } else if (r->u8f_stream != s && r->u8f_stream) {
+        SFE_HIP(hipStreamSynchronize(r->u8f_stream));         // the previous call on another stream may still read the scratch
+    }
+    r->u8f_stream = s;
+    for (int c = 0; c < r->n_channels; c++) {
+        rc = launch_rx_u8_to_f32(static_cast<const uint8_t *>(d_in) + (size_t)c * in_stride * w, r->d_u8f + (size_t)c * n_in * w, n_in * w, s);
+        if (rc != SFE_OK) return rc;
+    }
+    r->in_u8 = 0;
+    rc = rs_process_stream_impl(h, r->d_u8f, n_in, n_in, d_out, out_cap, out_stride, rate, n_out, stream);
+    r->in_u8 = 1;
+    return rc;
+}
+
+static int rs_process_stream_impl(sfe_rs_t h, const void *d_in, size_t n_in, size_t in_stride,
+                                  void *d_out, size_t out_cap, size_t out_stride, float rate,
+                                  size_t *n_out, sfe_stream_t stream)
 {
     Rs *r = as_rs(h);
     if (!r || !n_out) return SFE_EINVAL;
@@ -456,6 +500,7 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
             if (rc == SFE_ESTATE) rc = launch_poly_tiled(*pl, ta, r->data_complex, r->exact_stream, r->in_u8, r->n_channels, s);
         } else {
             if (r->in_u8) {
+                r->u8_refused = true;          // (the public entry converts the bytes and comes back with float32)
                 set_error("rs_process_stream: u8 input needs a tiled kernel for this rate/tap shape");
                 return SFE_ESTATE;
             }
@@ -671,6 +716,7 @@ int sfe_dsp_rs_process_stream(sfe_rs_t h, const void *d_in, size_t n_in, size_t 
             }
         }
         if (rc == SFE_ESTATE && r->in_u8) {
+            r->u8_refused = true;              // (the public entry converts the bytes and comes back with float32)
             set_error("rs_process_stream: u8 input at a non-integer step: this call is outside what the transform-domain kernel takes "
                       "(more than 2032 taps per phase, more than 32 phases, blksize below a block's advance, or a call in the "
                       "reference's out_len-exhausted state)");

@@ -156,6 +156,12 @@ struct Rs {
     size_t out_cap = 0, sched_cap = 0;
     void *h_stage = nullptr;               // pinned: in/out staging
     size_t h_stage_bytes = 0;
+    // wire-format input on a shape no fused u8 kernel takes (steps beyond the tiled kernels, a general rate outside the transform kernel):
+    // the call's bytes are converted ONCE into this grow-only float32 buffer and the float path runs (api_rs.hip: sfe_dsp_rs_process_stream)
+    float *d_u8f = nullptr;
+    size_t d_u8f_floats = 0;
+    hipStream_t u8f_stream = nullptr;
+    bool u8_refused = false;               // set by the implementation where it would have refused a u8 call, nothing launched, no state touched
     long long *h_pos = nullptr;            // pinned schedule staging
     float *h_mu = nullptr;
     void *d_segs = nullptr, *d_chunks = nullptr, *h_segs = nullptr, *h_chunks = nullptr;   // run-length plans

@@ -87,7 +87,7 @@ __device__ __forceinline__ typename Elem<CPLX>::T vload_u8(const unsigned char *
 // neither fits nor is needed (until round 5 the bulk call REFUSED steps beyond ~117: "step too large for the LDS tile"; the
 // reference's decimate takes any rate >= 1, libdsp/decimate.cxx:75-78).  Same sums in the same order.
 template <bool CPLX, bool EXACT>
-__global__ __launch_bounds__(256) void poly_int_kernel(PolyArgs a, int tile_out, int tile_in_cap, int sparse)
+__global__ __launch_bounds__(256) void poly_int_kernel(PolyArgs a, int tile_out, int tile_in_cap, int sparse, int taps_global)
 {
     typedef typename Elem<CPLX>::T T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -137,20 +137,24 @@ __global__ __launch_bounds__(256) void poly_int_kernel(PolyArgs a, int tile_out,
     }
     // the taps TRANSPOSED, ts[j U + phase]: consecutive outputs sit in different phases (phase = (pos0 + k step) mod U), and phase-major rows
     // plen floats apart put a wave's reads of tap j into ONE bank -- 10/9, 16/15, 25/24 ran at 0.05-0.10 of the roofline until round 5
-    for (int i = threadIdx.x; i < a.U * a.plen; i += 256) {
-        const int ph = i / a.plen, j = i - ph * a.plen;
-        ts[j * a.U + ph] = a.taps[i];
-    }
+    // (taps_global: more taps than the LDS holds beside a tile -- 160 phases of 127 -- stay where they are, phase-major in memory, and are read
+    // through the caches; until round 5 such a filter was refused: "taps do not fit the LDS tile")
+    if (!taps_global)
+        for (int i = threadIdx.x; i < a.U * a.plen; i += 256) {
+            const int ph = i / a.plen, j = i - ph * a.plen;
+            ts[j * a.U + ph] = a.taps[i];
+        }
     __syncthreads();
 
     for (long long k = k0 + threadIdx.x; k < k1; k += 256) {
         const long long p = a.pos0 + k * a.step;
         const long long n = floordiv(p, a.U);
         const int ph = (int)(p - n * a.U);
-        const float *tp = ts + ph;
+        const float *tp = taps_global ? a.taps + (size_t)ph * a.plen : ts + ph;
+        const int tstr = taps_global ? 1 : a.U;
         const T *xp = sparse ? xs + ((k - k0) * a.plen + (a.plen - 1)) : xs + (n - n_lo);      // the sample at time n
         T acc = Elem<CPLX>::zero();
-        for (int j = 0; j < a.plen; j++) acc = mac<EXACT>(acc, tp[j * a.U], xp[-j]);
+        for (int j = 0; j < a.plen; j++) acc = mac<EXACT>(acc, tp[j * tstr], xp[-j]);
         out[k] = acc;
     }
 }
@@ -1104,10 +1108,11 @@ int launch_poly_int(const PolyArgs &a, int data_complex, int /*taps_complex*/, i
 {
     if (a.n_out <= 0) return SFE_OK;
     const int esz = data_complex ? 8 : 4;
-    // choose the output tile so that input tile + taps fit in 60 KiB of LDS
-    const long long budget = 60 * 1024 - (long long)a.U * a.plen * 4;
+    // choose the output tile so that input tile + taps fit in 60 KiB of LDS; taps that would leave less than half of it to the samples stay in memory
+    const int taps_global = (long long)a.U * a.plen * 4 > 30 * 1024;
+    const long long budget = 60 * 1024 - (taps_global ? 0 : (long long)a.U * a.plen * 4);
     if (budget < (long long)(a.plen + 64) * esz) {
-        set_error("polyphase: %d taps in %d phases do not fit the LDS tile", a.U * a.plen, a.U);
+        set_error("polyphase: %d taps per phase do not fit the LDS tile", a.plen);
         return SFE_EINVAL;
     }
     long long tile_out = 2048;
@@ -1120,14 +1125,14 @@ int launch_poly_int(const PolyArgs &a, int data_complex, int /*taps_complex*/, i
         return SFE_EINVAL;
     }
     const int tile_in_cap = (int)((need(tile_out) + 3) & ~3LL);
-    const size_t shmem = (size_t)tile_in_cap * esz + (size_t)a.U * a.plen * 4;
+    const size_t shmem = (size_t)tile_in_cap * esz + (taps_global ? 0 : (size_t)a.U * a.plen * 4);
     const long long nb = (a.n_out + tile_out - 1) / tile_out;
     if (nb > 0x7fffffffLL) {
         set_error("polyphase: too many tiles");
         return SFE_EINVAL;
     }
     dim3 grid((unsigned)nb, (unsigned)n_channels), block(256);
-#define LAUNCH(C, E) hipLaunchKernelGGL((poly_int_kernel<C, E>), grid, block, shmem, s, a, (int)tile_out, tile_in_cap, sparse)
+#define LAUNCH(C, E) hipLaunchKernelGGL((poly_int_kernel<C, E>), grid, block, shmem, s, a, (int)tile_out, tile_in_cap, sparse, taps_global)
     if (data_complex) { if (exact) LAUNCH(true, true); else LAUNCH(true, false); }
     else { if (exact) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH

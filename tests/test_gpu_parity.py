@@ -934,14 +934,15 @@ def test_u8_streams_by_lds_dma(api, L, orc, U, step, cplx):
 
 
 @pytest.mark.parametrize("U,step,n_taps", [(1, 128, 32), (1, 250, 64), (1, 1000, 32), (1, 4000, 16), (3, 128, 96), (1, 100, 128), (2, 129, 300), (1, 117, 32), (5, 512, 40),
-                                            (9, 10, 285), (15, 16, 477), (24, 25, 768), (10, 9, 317), (160, 147, 5117), (32, 33, 1024), (64, 66, 2040)])
+                                            (9, 10, 285), (15, 16, 477), (24, 25, 768), (10, 9, 317), (160, 147, 5117), (32, 33, 1024), (64, 66, 2040), (160, 147, 20320)])
 @pytest.mark.parametrize("cplx", [True, False])
 def test_steps_beyond_the_tiled_kernels(api, L, orc, U, step, n_taps, cplx):
     """Round 5: the reference's decimate / resample take ANY rate >= 1 resp. >= 1 / upsample (libdsp/decimate.cxx:75-78, resample.cxx:91);
     until now the bulk call refused integer steps beyond ~117 ("step too large for the LDS tile").  The generic kernel now holds, where the
     outputs' windows do not overlap (step >= upsample * taps per phase), each output's own samples and nothing between them, and shrinks
     its tile where they do overlap; and ratios with more than eight outputs per period (10/9, 16/15, 25/24, 147/160 ...: the same generic kernel,
-    its taps transposed in the LDS so that a wave's lanes -- consecutive outputs, consecutive phases -- read different banks).  Exact mode: the oracle's bits (itself bit-exact with the compiled reference); default mode: within
+    its taps transposed in the LDS so that a wave's lanes -- consecutive outputs, consecutive phases -- read different banks; 20 320 taps in 160
+    phases, more than the LDS holds beside a tile, stay in memory: refused until now).  Exact mode: the oracle's bits (itself bit-exact with the compiled reference); default mode: within
     1e-5; two calls with carried state; decimate mode where upsample is 1."""
     rate = float(np.float32(step) / np.float32(U))
     taps = synth.lowpass_taps(n_taps, 0.9 * min(1.0 / U, 1.0 / step), gain=float(U))
@@ -960,6 +961,40 @@ def test_steps_beyond_the_tiled_kernels(api, L, orc, U, step, n_taps, cplx):
                 assert np.array_equal(got, ref[: len(got)]), (U, step, n_taps, cplx)
             else:
                 assert synth.rel_rms(got, ref[: len(got)]) <= TOL, (U, step, n_taps, cplx)
+
+
+@pytest.mark.parametrize("U,rate,n_taps,B", [(1, 128.0, 32, 4096), (1, 1000.0, 16, 4096), (24, 25.0 / 24.0, 768, 4096), (9, 10.0 / 9.0, 285, 4096),
+                                             (1, 2.5, 32, 1000), (3, 1.77, 381, 256), (3, 0.77, 96, 1000), (12, 1.003, 84, 256)])
+@pytest.mark.parametrize("cplx", [True, False])
+def test_u8_input_is_never_refused(api, L, orc, U, rate, n_taps, B, cplx):
+    """Round 5: wire-format (u8) input on shapes that have no fused u8 kernel -- integer steps beyond the tiled kernels' reach, general rates
+    the transform-domain kernel does not take (small blksize) -- was REFUSED ("u8 input needs a tiled kernel", "outside what the
+    transform-domain kernel takes").  Such a call now converts its bytes once into a scratch buffer of the handle and runs the float32
+    path: the result equals, bit for bit and call for call, the float32 path fed the oracle's own conversion of the same bytes
+    (gr-simplefe/lib/source_c_impl.cc's (b - 128) / 127); two calls with carried state, two channels."""
+    rate = float(np.float32(rate))
+    taps = synth.lowpass_taps(n_taps, 0.9 * min(1.0 / U, 1.0 / max(rate * U, 1.0)), gain=float(U))
+    w = 2 if cplx else 1
+    n, nch = 40 * B, 2
+    b = np.stack([_u8_stream(w * n, 60 + c) for c in range(nch)])
+    xf = np.stack([orc.rx_u8_to_f32(b[c]) for c in range(nch)])
+    cap = int(n / rate) + 4 * (n // B) + 64
+    outs = []
+    for u8 in (True, False):
+        r = api.Rs(taps, U, B, mode=L.RS_RESAMPLE, data_complex=cplx, n_channels=nch)
+        if u8:
+            r.set_input_format(L.FMT_U8)
+            d = api.DeviceArray.from_bytes(b)
+        else:
+            d = api.DeviceArray.from_numpy(xf)
+        esz = w if u8 else 4 * w                       # bytes per sample of the input
+        d_out = api.DeviceArray(w * cap * nch)
+        cut = 16 * B
+        k1 = r.process_stream(d, cut, d_out, cap, rate, in_stride=n, out_stride=cap)
+        k2 = r.process_stream(d.ptr + esz * cut, n - cut, d_out.ptr + 4 * w * k1, cap - k1, rate, in_stride=n, out_stride=cap)
+        outs.append((k1, k2, d_out.to_numpy().reshape(nch, w * cap)[:, : w * (k1 + k2)]))
+    assert outs[0][:2] == outs[1][:2] and outs[0][0] + outs[0][1] > 0, (U, rate, outs[0][:2], outs[1][:2])
+    assert np.array_equal(outs[0][2].view(np.uint32), outs[1][2].view(np.uint32)), (U, rate, n_taps, B, cplx)
 
 
 # ----------------------------------------------------------------- edge cases / misuse
