@@ -1,0 +1,34 @@
+"""Round 5: wide sweeps over (upsample, rate, taps per phase, blksize, stream type, input format, mode) -- what SURVEY.md 8(c) calls the reference's
+parameter space: resample takes any rate >= 1 / upsample, decimate any rate >= 1 (libdsp/resample.cxx:91, decimate.cxx:75-78).  Three
+questions, one script each under scripts/probes/: does the bulk call REFUSE anything (it did: decimate by 128, u8 input without a fused
+kernel, tap tables beyond the LDS), does the bulk call give the oracle's bits (exact mode) / stay within 1e-5 (default mode), does the
+drop-in class path give the oracle's bits call for call.  `-m gpu`."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(script, timeout):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "probes", script)], capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+def test_the_bulk_resampler_call_refuses_nothing():
+    out = _run("find_refusals.py", 600)
+    assert "2016 combinations tried, 0 refused" in out, out[-3000:]
+
+
+def test_the_bulk_resampler_call_matches_the_oracle_over_the_matrix():
+    out = _run("sweep_bulk_path.py", 900)
+    assert "1152 combinations tried, 0 bad" in out, out[-3000:]
+
+
+def test_the_class_path_matches_the_oracle_over_the_matrix():
+    out = _run("sweep_class_path.py", 600)
+    assert "816 combinations tried, 0 bad" in out, out[-3000:]
