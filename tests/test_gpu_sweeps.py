@@ -32,3 +32,10 @@ def test_the_bulk_resampler_call_matches_the_oracle_over_the_matrix():
 def test_the_class_path_matches_the_oracle_over_the_matrix():
     out = _run("sweep_class_path.py", 600)
     assert "816 combinations tried, 0 bad" in out, out[-3000:]
+
+
+def test_the_bulk_fir_call_matches_float64_convolution_over_the_matrix():
+    """blkconv's law (libdsp/blkconv.cxx:77-110) on 1 728 combinations of (taps 1 ... 20 001, real / complex taps, real / complex data, channels,
+    stream length, chunking) against float64 convolution."""
+    out = _run("sweep_fir_bulk.py", 900)
+    assert "1728 combinations tried, 0 bad" in out, out[-3000:]
