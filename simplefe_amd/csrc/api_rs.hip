@@ -666,8 +666,12 @@ static int rs_process_stream_impl(sfe_rs_t h, const void *d_in, size_t n_in, siz
         // all U phases of every input by one forward and U inverse 4096-point transforms, outputs picked and blended from
         // LDS by the same runs.  sfe_dsp_rs_set_algo(SFE_RS_ALGO_DIRECT) and the exact mode keep poly_seg_kernel.
         rc = SFE_ESTATE;
+        // (1 + U) transforms per block against two dot products of plen taps per output: the transform kernel while U <= 2 + plen / 16 (measured at
+        // 2^26 samples and rate 1.77, profiles/r05/speed_sweep.txt: it takes 0.43 + 0.11 U ms, the direct kernel 0.69 + 0.0072 plen; until round 5
+        // the rule was "12 taps per phase or more" and 16 phases of 127 taps ran 2.2 ms where the direct kernel takes 1.6)
+        const bool gen_pays = r->plen >= 12 && r->U <= 2 + r->plen / 16;
         if (!exhausted && !r->exact_stream && r->fft_mode >= 0 &&
-            (r->fft_mode > 0 || r->in_u8 || (n_in >= ((size_t)1 << 16) && r->plen >= 12))) {
+            (r->fft_mode > 0 || r->in_u8 || (n_in >= ((size_t)1 << 16) && gen_pays))) {
             if (!r->gen_tried) {
                 // spectra of the U phase filters (taps[i U + j], i < plen; one zero behind so that the overlap the FIR
                 // planner picks covers plen samples, not plen - 1) through fir_build_tables: one "channel" per phase

@@ -248,6 +248,7 @@ struct PolySegArgs {
     const SegChunk *chunks;
     long long   n_in, in_stride, out_stride;
     int         hl, U, plen, n_chunks, max_m;
+    int         taps_global = 0;    // set by the launcher: the taps stay in memory (more of them than the LDS holds beside a call's samples)
 };
 // returns SFE_ESTATE when a call's tile does not fit in LDS (caller falls back to launch_poly_sched)
 int launch_poly_seg(const PolySegArgs &a, int data_complex, int exact, int n_channels, hipStream_t s);

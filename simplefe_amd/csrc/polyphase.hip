@@ -945,10 +945,14 @@ __global__ __launch_bounds__(256) void poly_seg_kernel(PolySegArgs a)
     // taps in LDS twice, rows padded to a multiple of four floats (16-byte rows): ts[ph][j] = taps[ph][j] and the same
     // rows one tap to the left, tsh[ph][j] = taps[ph][j + 1] -- whichever a lane's second dot product needs (below),
     // four taps come with one aligned 16-byte read
+    // (round 5: only phase 0's row is ever read shifted -- the second sum of an output in the LAST phase -- so tsh is ONE row, not U: 32 phases of
+    // 127 taps or 160 of 32 fit the LDS beside a call's samples; a.taps_global: filters that still do not -- 160 phases of 127 taps -- leave
+    // their taps in memory, read one at a time through the caches.  Until then such a call fell through to the host-scheduled path: a (position,
+    // weight) pair per OUTPUT over PCIe, 170-340 ms for 2^26 samples, profiles/r05/speed_sweep.txt)
     const int plp = seg_row(a.plen);
     float *ts = reinterpret_cast<float *>(smem + SEG_MAX_LDS * sizeof(DevSeg));
     float *tsh = ts + (size_t)a.U * plp;
-    T *xs = reinterpret_cast<T *>(smem + SEG_MAX_LDS * sizeof(DevSeg) + (size_t)2 * a.U * plp * 4);
+    T *xs = reinterpret_cast<T *>(smem + SEG_MAX_LDS * sizeof(DevSeg) + (a.taps_global ? 0 : (size_t)(a.U + 1) * plp * 4));
 
     const SegChunk c = a.chunks[blockIdx.x];
     const int ch = blockIdx.y;
@@ -959,10 +963,12 @@ __global__ __launch_bounds__(256) void poly_seg_kernel(PolySegArgs a)
 
     const int nsl = c.n_seg < SEG_MAX_LDS ? c.n_seg : SEG_MAX_LDS;
     for (int i = threadIdx.x; i < nsl; i += 256) sg[i] = gseg[i];
-    for (int i = threadIdx.x; i < a.U * plp; i += 256) {
-        const int ph = i / plp, j = i - ph * plp;
-        ts[i] = j < a.plen ? a.taps[ph * a.plen + j] : 0.0f;
-        tsh[i] = j + 1 < a.plen ? a.taps[ph * a.plen + j + 1] : 0.0f;
+    if (!a.taps_global) {
+        for (int i = threadIdx.x; i < a.U * plp; i += 256) {
+            const int ph = i / plp, j = i - ph * plp;
+            ts[i] = j < a.plen ? a.taps[ph * a.plen + j] : 0.0f;
+        }
+        for (int j = threadIdx.x; j < plp; j += 256) tsh[j] = j + 1 < a.plen ? a.taps[j + 1] : 0.0f;
     }
     // tile: samples in_off - plen .. in_off + m - 1   (pos >= -1 reaches back plen samples)
     const int n_tile = c.m + a.plen;
@@ -1029,15 +1035,15 @@ __global__ __launch_bounds__(256) void poly_seg_kernel(PolySegArgs a)
         const long long reach1 = reach + sh;
         const int J1 = reach1 < a.plen ? (reach1 > 0 ? (int)reach1 : 0) : a.plen;            // terms of s1
         const int L1 = J1 - (sh && J1 > 0 ? 1 : 0);                                          // ... of them over x[n - i]
-        const float *ta = ts + ph * plp;
-        const float *tb = (sh ? tsh : ts) + ph1 * plp;
+        const float *ta = a.taps_global ? a.taps + (size_t)ph * a.plen : ts + ph * plp;
+        const float *tb = a.taps_global ? a.taps + (size_t)ph1 * a.plen + sh : (sh ? tsh : ts + ph1 * plp);     // (sh: ph1 = 0)
         const T *xp = xs + (n + a.plen);
         s0 = Elem<CPLX>::zero();
         s1 = Elem<CPLX>::zero();
-        if (sh && J1 > 0) s1 = mac<EXACT>(s1, ts[0], xp[1]);     // taps[0][0] x[n + 1]
+        if (sh && J1 > 0) s1 = mac<EXACT>(s1, a.taps_global ? a.taps[0] : ts[0], xp[1]);     // taps[0][0] x[n + 1]
         const int common = L0 < L1 ? L0 : L1;
         int i = 0;
-        for (; i + 4 <= common; i += 4) {
+        for (; !a.taps_global && i + 4 <= common; i += 4) {      // (rows in memory are not padded to 16 bytes: one tap at a time there)
             const v4f a4 = *reinterpret_cast<const v4f *>(ta + i), b4 = *reinterpret_cast<const v4f *>(tb + i);
             const T x0 = xp[-i], x1 = xp[-i - 1], x2 = xp[-i - 2], x3 = xp[-i - 3];
             s0 = mac<EXACT>(s0, a4.x, x0);
@@ -1541,12 +1547,15 @@ int launch_poly_sched(const PolyArgs &a, int data_complex, int exact, int n_chan
     return SFE_OK;
 }
 
-int launch_poly_seg(const PolySegArgs &a, int data_complex, int exact, int n_channels, hipStream_t s)
+int launch_poly_seg(const PolySegArgs &a0, int data_complex, int exact, int n_channels, hipStream_t s)
 {
-    if (a.n_chunks <= 0) return SFE_OK;
+    if (a0.n_chunks <= 0) return SFE_OK;
     const size_t esz = data_complex ? 8 : 4;
-    const size_t sh = SEG_MAX_LDS * sizeof(DevSeg) + (size_t)2 * a.U * seg_row(a.plen) * 4 +
-                      (size_t)(a.max_m + a.plen + 1) * esz;
+    PolySegArgs a = a0;
+    const size_t fixed = SEG_MAX_LDS * sizeof(DevSeg) + (size_t)(a.max_m + a.plen + 1) * esz;
+    const size_t taps_b = (size_t)(a.U + 1) * seg_row(a.plen) * 4;
+    a.taps_global = fixed + taps_b > 64 * 1024;
+    const size_t sh = fixed + (a.taps_global ? 0 : taps_b);
     if (sh > 64 * 1024) return SFE_ESTATE;
     dim3 grid((unsigned)a.n_chunks, (unsigned)n_channels), block(256);
 #define LAUNCH(C, E) hipLaunchKernelGGL((poly_seg_kernel<C, E>), grid, block, sh, s, a)
