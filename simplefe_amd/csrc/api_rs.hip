@@ -614,6 +614,10 @@ static int rs_process_stream_impl(sfe_rs_t h, const void *d_in, size_t n_in, siz
         sa.plen = r->plen;
         sa.n_chunks = (int)chunks.size();
         sa.max_m = max_m;
+        sa.taps_global = 0;
+        sa.split = 1;
+        sa.tile_cap = 0;
+        sa.span_slack = (int)ceilf(rate) + 64;          // one output's step in samples + room for the float32 recurrence's wobble
         // plan tables: grow-only device arrays + pinned staging.  The previous call's UPLOADS may still be reading the
         // staging: wait for them -- the event behind them -- not for the stream: that call's kernel runs on while this
         // call is planned and queued (waiting for the stream here made every call a full host/device round trip).

@@ -249,6 +249,8 @@ struct PolySegArgs {
     long long   n_in, in_stride, out_stride;
     int         hl, U, plen, n_chunks, max_m;
     int         taps_global = 0;    // set by the launcher: the taps stay in memory (more of them than the LDS holds beside a call's samples)
+    int         split = 1, tile_cap = 0;   // set by the launcher: workgroups per reference call, samples a workgroup's tile holds
+    int         span_slack = 64;    // samples beyond max_m / split a part's outputs may reach: ceil(rate) + the recurrence's wobble (api_rs.hip)
 };
 // returns SFE_ESTATE when a call's tile does not fit in LDS (caller falls back to launch_poly_sched)
 int launch_poly_seg(const PolySegArgs &a, int data_complex, int exact, int n_channels, hipStream_t s);

@@ -954,7 +954,11 @@ __global__ __launch_bounds__(256) void poly_seg_kernel(PolySegArgs a)
     float *tsh = ts + (size_t)a.U * plp;
     T *xs = reinterpret_cast<T *>(smem + SEG_MAX_LDS * sizeof(DevSeg) + (a.taps_global ? 0 : (size_t)(a.U + 1) * plp * 4));
 
-    const SegChunk c = a.chunks[blockIdx.x];
+    // a.split > 1 (round 5; a reference call -- blksize samples -- larger than the LDS: blksize 8192 and up for complex streams): the call's outputs
+    // are dealt to `split` workgroups in equal runs, and each stages the input span ITS outputs reach (positions grow with the output index).
+    // Until then such a call fell through to the host-scheduled path: 37 ms for 2^24 samples where blksize 4096 takes 0.5.
+    const int chunk_i = (int)(blockIdx.x / (unsigned)a.split), part = (int)(blockIdx.x - (unsigned)chunk_i * (unsigned)a.split);
+    const SegChunk c = a.chunks[chunk_i];
     const int ch = blockIdx.y;
     const T *in = static_cast<const T *>(a.in) + (size_t)ch * a.in_stride;
     const T *hist = static_cast<const T *>(a.hist) + (size_t)ch * a.hl;
@@ -970,9 +974,28 @@ __global__ __launch_bounds__(256) void poly_seg_kernel(PolySegArgs a)
         }
         for (int j = threadIdx.x; j < plp; j += 256) tsh[j] = j + 1 < a.plen ? a.taps[j + 1] : 0.0f;
     }
-    // tile: samples in_off - plen .. in_off + m - 1   (pos >= -1 reaches back plen samples)
-    const int n_tile = c.m + a.plen;
-    const long long tile0 = c.in_off - a.plen;
+    // this workgroup's outputs [ka, kb) of the call and the first sample of its tile relative to the call's first (split == 1: all of them, - plen)
+    const int ka = (int)((long long)c.n_out * part / a.split), kb = (int)((long long)c.n_out * (part + 1) / a.split);
+    if (ka >= kb) return;
+    int rel0 = -a.plen, n_tile = c.m + a.plen;          // tile: samples in_off - plen .. in_off + m - 1   (pos >= -1 reaches back plen samples)
+    if (a.split > 1) {
+        auto sample_of = [&](int k) -> long long {      // floor(position of output k / U): every thread walks the same runs (uniform)
+            int q = 0;
+            DevSeg g;
+            for (;;) {
+                g = gseg[q];
+                if (k < g.k0 + g.count) break;
+                q++;
+            }
+            return floordiv((long long)floor(g.t0 + (double)(k - g.k0) * (double)g.d), a.U);
+        };
+        const long long n_first = sample_of(ka), n_last = sample_of(kb - 1) + 1;       // (+ 1: the second sum of an output in the last phase)
+        if (part > 0) rel0 = (int)n_first - a.plen;
+        long long span = n_last - rel0 + 1;
+        if (span > c.m - rel0) span = c.m - rel0;        // nothing beyond the call's own samples is ever read
+        n_tile = span > a.tile_cap ? a.tile_cap : (int)span;      // (the launcher sizes tile_cap with room to spare)
+    }
+    const long long tile0 = c.in_off + rel0;
     if (tile0 >= 0 && tile0 + n_tile <= a.n_in) {
         // an interior call: its samples are requested eight per thread at a time, all in flight together.  Through the
         // guarded loop below every iteration is a branchy load -> wait -> LDS write of its own, one memory latency after
@@ -1030,14 +1053,14 @@ __global__ __launch_bounds__(256) void poly_seg_kernel(PolySegArgs a)
         split(p, n, ph);
         const int sh = ph + 1 == a.U;
         const int ph1 = sh ? 0 : ph + 1;
-        const long long reach = n + a.plen + 1;                    // samples x[n], x[n-1], ... inside the tile
+        const long long reach = n - rel0 + 1;                      // samples x[n], x[n-1], ... inside the tile
         const int L0 = reach < a.plen ? (reach > 0 ? (int)reach : 0) : a.plen;               // terms of s0
         const long long reach1 = reach + sh;
         const int J1 = reach1 < a.plen ? (reach1 > 0 ? (int)reach1 : 0) : a.plen;            // terms of s1
         const int L1 = J1 - (sh && J1 > 0 ? 1 : 0);                                          // ... of them over x[n - i]
         const float *ta = a.taps_global ? a.taps + (size_t)ph * a.plen : ts + ph * plp;
         const float *tb = a.taps_global ? a.taps + (size_t)ph1 * a.plen + sh : (sh ? tsh : ts + ph1 * plp);     // (sh: ph1 = 0)
-        const T *xp = xs + (n + a.plen);
+        const T *xp = xs + (n - rel0);
         s0 = Elem<CPLX>::zero();
         s1 = Elem<CPLX>::zero();
         if (sh && J1 > 0) s1 = mac<EXACT>(s1, a.taps_global ? a.taps[0] : ts[0], xp[1]);     // taps[0][0] x[n + 1]
@@ -1065,7 +1088,7 @@ __global__ __launch_bounds__(256) void poly_seg_kernel(PolySegArgs a)
     };
 
     int s = 0;                                          // runs are visited in order by each thread
-    for (int k = threadIdx.x; k < c.n_out; k += 256) {
+    for (int k = ka + (int)threadIdx.x; k < kb; k += 256) {
         DevSeg g;
         for (;;) {
             g = s < nsl ? sg[s] : gseg[s];
@@ -1552,12 +1575,23 @@ int launch_poly_seg(const PolySegArgs &a0, int data_complex, int exact, int n_ch
     if (a0.n_chunks <= 0) return SFE_OK;
     const size_t esz = data_complex ? 8 : 4;
     PolySegArgs a = a0;
-    const size_t fixed = SEG_MAX_LDS * sizeof(DevSeg) + (size_t)(a.max_m + a.plen + 1) * esz;
     const size_t taps_b = (size_t)(a.U + 1) * seg_row(a.plen) * 4;
-    a.taps_global = fixed + taps_b > 64 * 1024;
-    const size_t sh = fixed + (a.taps_global ? 0 : taps_b);
-    if (sh > 64 * 1024) return SFE_ESTATE;
-    dim3 grid((unsigned)a.n_chunks, (unsigned)n_channels), block(256);
+    // a call's samples beside the runs and the taps; a call that does not fit is dealt to `split` workgroups, each with the span its outputs
+    // reach: max_m / split samples + what one output's step and the float32 recurrence's wobble can add (a.span_slack, api_rs.hip) + plen
+    a.split = 1;
+    auto tile = [&](int split) { return split == 1 ? (size_t)a.max_m + a.plen + 1 : (size_t)(a.max_m + split - 1) / split + a.span_slack + a.plen + 2; };
+    auto need = [&](int split, bool tg) { return SEG_MAX_LDS * sizeof(DevSeg) + (tg ? 0 : taps_b) + tile(split) * esz; };
+    a.taps_global = taps_b > 24 * 1024 && need(1, false) > 64 * 1024;
+    while (a.split < 64 && need(a.split, a.taps_global) > 64 * 1024) a.split *= 2;
+    if (need(a.split, a.taps_global) > 64 * 1024 && !a.taps_global) {
+        a.taps_global = 1;
+        a.split = 1;
+        while (a.split < 64 && need(a.split, true) > 64 * 1024) a.split *= 2;
+    }
+    const size_t sh = need(a.split, a.taps_global);
+    if (sh > 64 * 1024 || (long long)a.n_chunks * a.split > 0x7fffffffLL) return SFE_ESTATE;
+    a.tile_cap = (int)tile(a.split);
+    dim3 grid((unsigned)(a.n_chunks * a.split), (unsigned)n_channels), block(256);
 #define LAUNCH(C, E) hipLaunchKernelGGL((poly_seg_kernel<C, E>), grid, block, sh, s, a)
     if (data_complex) { if (exact) LAUNCH(true, true); else LAUNCH(true, false); }
     else { if (exact) LAUNCH(false, true); else LAUNCH(false, false); }

@@ -997,6 +997,39 @@ def test_u8_input_is_never_refused(api, L, orc, U, rate, n_taps, B, cplx):
     assert np.array_equal(outs[0][2].view(np.uint32), outs[1][2].view(np.uint32)), (U, rate, n_taps, B, cplx)
 
 
+@pytest.mark.parametrize("B", [8192, 16384, 65536])
+@pytest.mark.parametrize("U,rate,n_taps", [(3, 1.77, 381), (3, 0.77, 96), (1, 2.5, 32), (32, 1.77, 4064), (7, 3.3, 70)])
+@pytest.mark.parametrize("cplx", [True, False])
+def test_general_rate_calls_larger_than_the_lds(api, L, orc, B, U, rate, n_taps, cplx):
+    """Round 5: the direct general-rate kernel stages one reference call -- blksize samples -- per workgroup; a blksize of 8192 complex samples
+    or more does not fit the LDS and the bulk call fell through to the host-scheduled path (37 ms for 2^24 samples where blksize 4096 takes
+    0.5).  Such a call is now dealt to several workgroups, each with the input span its outputs reach.  Exact mode: the oracle's bits and its
+    per-call output counts (libdsp/resample.cxx:100-148 replayed call by call); the fused direct kernel within 1e-5."""
+    if (rate < 1.0 and B > 8192) or (B == 65536 and U > 3):
+        # 16384 samples x 3 phases at a step of 2.31 (65536 x 7 at 23.1, 65536 x 32 at 56.6): the float32 recurrence drifts by more outputs than the ceil(n_in / rate) + 2 a call may emit,
+        # the reference's object is left in its out_len-exhausted state (m_pos < -1, SURVEY.md section 5) and its NEXT call indexes m_out[][] at
+        # negative positions -- undefined behaviour there, a segmentation fault in the oracle's faithful restatement.  Nothing to compare with.
+        pytest.skip("the reference's own out_len-exhausted state: its next call reads out of bounds")
+    rate = float(np.float32(rate))
+    taps = synth.lowpass_taps(n_taps, 0.9 * min(1.0 / U, 1.0 / max(rate * U, 1.0)), gain=float(U))
+    w = 2 if cplx else 1
+    n = 5 * B + B // 3
+    x = synth.synth_f32(w * n, ch=88)
+    refs = [orc.Resample(taps, U, B).stream(np.ascontiguousarray(x[part::w]), rate)[0] for part in range(w)]
+    for exact in (True, False):
+        r = api.Rs(taps, U, B, mode=L.RS_RESAMPLE, data_complex=cplx)
+        r.set_exact(exact)
+        r.set_algo(L.RS_ALGO_DIRECT)
+        y = r.resample_array(x, rate, chunk=3 * B)[0]
+        for part in range(w):
+            got, ref = y[part::w], refs[part]
+            assert len(ref) - len(got) in (0, 1) and len(got) > 0, (B, U, rate, len(ref), len(got))
+            if exact:
+                assert np.array_equal(got.view(np.uint32), ref[: len(got)].view(np.uint32)), (B, U, rate, cplx)
+            else:
+                assert synth.rel_rms(got, ref[: len(got)]) <= TOL, (B, U, rate, cplx)
+
+
 # ----------------------------------------------------------------- edge cases / misuse
 def test_empty_and_tiny_inputs(api, L, orc):
     """n = 0 is a no-op; n < n_taps works and carries state; 1-tap filter is a gain."""
