@@ -39,3 +39,10 @@ def test_the_bulk_fir_call_matches_float64_convolution_over_the_matrix():
     stream length, chunking) against float64 convolution."""
     out = _run("sweep_fir_bulk.py", 900)
     assert "1728 combinations tried, 0 bad" in out, out[-3000:]
+
+
+def test_the_bulk_resampler_call_with_several_channels_in_both_modes():
+    """three channels at odd strides, on and off 16-byte boundaries, resample and decimate modes, two calls with carried state: every channel against
+    the oracle (432 combinations)"""
+    out = _run("sweep_bulk_channels.py", 900)
+    assert "432 combinations tried, 0 bad" in out, out[-3000:]
