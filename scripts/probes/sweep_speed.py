@@ -29,6 +29,7 @@ for (U, rate), plen, cplx in itertools.product(RATES, (8, 32, 127), (True, False
     try:
         y = api.DeviceArray(w * cap)
         r = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=cplx)
+        r.set_exact(os.environ.get("EXACT") == "1")          # EXACT=1: the bit-exact kernels
         for _ in range(3):
             k = r.process_stream(x, n, y, cap, rate)
         v = []

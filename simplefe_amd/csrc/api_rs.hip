@@ -497,7 +497,16 @@ static int rs_process_stream_impl(sfe_rs_t h, const void *d_in, size_t n_in, siz
                 if (!atoi(e) && r->in_u8) try_dma = false;
 #endif
             if (try_dma) rc = launch_poly_rt_dma(*pl, ta, r->data_complex, r->in_u8, r->n_channels, s);
-            if (rc == SFE_ESTATE) rc = launch_poly_tiled(*pl, ta, r->data_complex, r->exact_stream, r->in_u8, r->n_channels, s);
+            if (rc == SFE_ESTATE && pl->UP <= 8) rc = launch_poly_tiled(*pl, ta, r->data_complex, r->exact_stream, r->in_u8, r->n_channels, s);
+            if (rc == SFE_ESTATE && pl->UP > 8) {            // 9 ... 64 outputs per period and the tiled form declined: the generic kernel
+                if (r->in_u8) {
+                    r->u8_refused = true;
+                    set_error("rs_process_stream: u8 input needs a tiled kernel for this rate/tap shape");
+                    return SFE_ESTATE;
+                }
+                hist_fused = false;
+                rc = launch_poly_int(a, r->data_complex, 0, r->exact_stream, r->n_channels, s);
+            }
         } else {
             if (r->in_u8) {
                 r->u8_refused = true;          // (the public entry converts the bytes and comes back with float32)

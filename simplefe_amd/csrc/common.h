@@ -137,7 +137,8 @@ int launch_poly_int(const PolyArgs &a, int data_complex, int taps_complex, int e
 struct PolyTiledPlan {
     int    SP = 0, UP = 0, Lp = 0, e_max = 0;
     float *d_G = nullptr;        // [UP][Lp]
-    float *d_Gt = nullptr;       // [Lp][8]: the same taps, one row of all UP phases per local time (poly_rt_kernel: one scalar load per tap)
+    float *d_Gt = nullptr;       // [Lp][gt_pitch]: the same taps, one row of all UP phases per local time (poly_rt_kernel: one scalar load per tap)
+    int    gt_pitch = 8;         // floats per row of d_Gt: 8, or UP rounded up to a multiple of 8 for the shapes with 9 ... 64 outputs per period
 };
 struct PolyTiledArgs {
     const void *in;
@@ -161,6 +162,7 @@ struct PolyTiledArgs {
     // poly_rt_dma.hip: the input is the receive wire format (u8 offset binary; complex: byte pairs) -- the tile's raw bytes land at raw_off in LDS
     int         in_u8 = 0;
     unsigned    raw_off = 0;
+    int         gt_pitch = 8;         // PolyTiledPlan::gt_pitch
 };
 // returns SFE_OK, or SFE_ESTATE when (SP, UP, Lp) has no tiled instantiation (caller falls
 // back to launch_poly_int)

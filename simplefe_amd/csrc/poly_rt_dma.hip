@@ -312,6 +312,69 @@ __global__ __launch_bounds__(256) void poly_rt_dma_kernel(PolyTiledArgs a)
     }
 }
 
+// 9 ... 64 outputs per period (10/9, 16/15, 25/24, x16, x32: near-unity rate matching and strong interpolation; until round 5 these ran the generic
+// one-output-per-thread kernel at 0.05-0.3 of the roofline): the same tile, the same fetch; a thread takes one m and runs its UP phase sums EIGHT at
+// a time -- one sample read from the LDS feeds eight multiply-adds, the eight taps of a (local time, group) come as one scalar load from the
+// row-padded Gt (a.gt_pitch floats per local time) -- re-reading its Lp samples once per group.  Accumulation order per output: tap index
+// ascending, fused -- the bits the other fused kernels would give.
+template <bool CPLX>
+__global__ __launch_bounds__(256) void poly_rt_dma_many_kernel(PolyTiledArgs a)
+{
+    typedef typename El<CPLX>::T T;
+    constexpr int ESZ = CPLX ? 8 : 4, A16 = 16 / ESZ;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T *X = reinterpret_cast<T *>(smem);
+    const unsigned tid = threadIdx.x;
+    const int ch = blockIdx.y;
+    const T *hist = static_cast<const T *>(a.hist) + (size_t)ch * a.hl;
+    T *out = static_cast<T *>(a.out) + (size_t)ch * a.out_stride;
+    if (a.hist_out && blockIdx.x == a.tiles) {
+        carry_history<CPLX>(a, ch, tid);
+        return;
+    }
+    const unsigned SP = (unsigned)a.SP;
+    const int UP = a.UP, TMr = a.tm, pitch = a.gt_pitch;
+    const long long m0 = (long long)blockIdx.x * TMr;
+    const long long n_org = (long long)SP * m0 + a.e_max - (a.Lp - 1);
+    const unsigned sh = fetch_tile<CPLX>(a, ch, hist, X, smem, n_org, SP * (unsigned)TMr + (unsigned)a.Lp, tid);
+    __syncthreads();
+    const __attribute__((address_space(4))) float *gt = (const __attribute__((address_space(4))) float *)a.Gt;
+#pragma unroll 1
+    for (int mi = (int)tid; mi < TMr; mi += 256) {
+        const unsigned b = sh + SP * (unsigned)mi;
+        const long long k = (long long)UP * (m0 + mi);
+#pragma unroll 1
+        for (int g0 = 0; g0 < UP; g0 += 8) {
+            T acc[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) acc[r] = T{};
+#pragma unroll 2
+            for (int qt = a.Lp - 1; qt >= 0; --qt) {                 // local time descending = tap index ascending
+                const T x = X[b + (unsigned)qt];
+                float tp[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) tp[r] = gt[pitch * qt + g0 + r];
+#pragma unroll
+                for (int r = 0; r < 8; r++) acc[r] = El<CPLX>::mac(acc[r], tp[r], x);
+            }
+            T *o = out + k + g0;
+            if (g0 + 8 <= UP && k + g0 + 8 <= a.n_out && (reinterpret_cast<uintptr_t>(o) & 15u) == 0) {      // the group as 16-byte pieces
+#pragma unroll
+                for (int r = 0; r < 8; r += A16) {
+                    v4f q;
+                    if constexpr (CPLX) q = (v4f){acc[r].x, acc[r].y, acc[r + 1].x, acc[r + 1].y};
+                    else q = (v4f){acc[r], acc[r + 1], acc[r + 2], acc[r + 3]};
+                    *reinterpret_cast<v4f *>(o + r) = q;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; r++)
+                    if (g0 + r < UP && k + g0 + r < a.n_out) o[r] = acc[r];
+            }
+        }
+    }
+}
+
 // REAL streams at SMALL input steps (SP = 1 ... 5; SP = 1: the pure interpolators): a register window.  Lane t takes FOUR consecutive m,
 // 4 t ... 4 t + 3: their 4 Lp samples are Lp + 3 SP consecutive ones, read as whole aligned 16-byte groups (lane stride 16 SP bytes: no bank
 // conflicts for an odd SP) from the highest local time down -- one new group per four taps, the (3 SP + 6) / 4 above it kept in registers --
@@ -546,7 +609,15 @@ int launch_poly_rt_dma(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int d
     if (const char *e = getenv("SFE_RT_DMA_SP1"))      // experiment: every pure interpolator here (scripts/collect_r05_p.sh)
         if (atoi(e)) sp_min = 1;
 #endif
-    if (SP < sp_min || SP > 64 || UP < 1 || UP > 8 || plan.Lp <= 0 || !plan.d_Gt) return SFE_ESTATE;
+    if (UP > 8) {
+        // 9 ... 64 outputs per period: poly_rt_dma_many_kernel -- one sample per LDS read at a lane stride of SP samples, so only where that stride
+        // meets a bank at most twice (16/15, SP = 16: 16 lanes to a bank, 3.57 ms against the generic kernel's 2.14; profiles/r05/shapes_generic_kernel.txt)
+        int g = SP, b = data_complex ? 32 : 64;
+        while (b) { const int t = g % b; g = b; b = t; }
+        if (g > 2) return SFE_ESTATE;
+        sp_min = 1;
+    }
+    if (SP < sp_min || SP > 64 || UP < 1 || UP > 64 || plan.Lp <= 0 || !plan.d_Gt) return SFE_ESTATE;
     // 16-byte lanes: every channel's first sample on a 16-byte boundary (u8 input: 8 complex or 16 real samples per lane)
     const int in_a16 = in_u8 ? (data_complex ? 8 : 16) : a16;
     if ((reinterpret_cast<uintptr_t>(a0.in) & 15u) || (n_channels > 1 && (a0.in_stride % in_a16))) return SFE_ESTATE;
@@ -560,18 +631,20 @@ int launch_poly_rt_dma(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int d
     PolyTiledArgs a = a0;
     a.SP = SP;
     a.UP = UP;
-    a.tm = rt_dma_tile_m(SP, UP, data_complex ? 4096 : 8192);
+    a.tm = UP > 8 ? 256 : rt_dma_tile_m(SP, UP, data_complex ? 4096 : 8192);       // (many outputs per m: one m per thread)
+    a.gt_pitch = plan.gt_pitch;
+    while (UP > 8 && a.tm > 64 && ((size_t)SP * a.tm + plan.Lp + a16) * esz > 48 * 1024) a.tm /= 2;
     size_t lds = ((((size_t)SP * a.tm + plan.Lp + a16) * esz + 1023) >> 10) << 10;        // whole 1 KiB pieces
     a.y_off = 0;
     if (lds > 60 * 1024) return SFE_ESTATE;
-    if (UP >= 3 && lds + (size_t)4 * 64 * (UP + 1) * esz <= 60 * 1024) {      // + the four waves' output regions: 64 rows of UP + 1 cells each
+    if (UP >= 3 && UP <= 8 && lds + (size_t)4 * 64 * (UP + 1) * esz <= 60 * 1024) {      // + the four waves' output regions: 64 rows of UP + 1 cells each
         a.y_off = (unsigned)lds;                                          // (where they do not fit -- 11/8 -- the outputs leave lane by lane)
         lds += (size_t)4 * 64 * (UP + 1) * esz;
     }
     // real streams at small input steps: poly_int4_dma_kernel.  The interpolators up to x7 (x2 ... x5 13-24 % ahead of the one-sample-per-read
     // form, x6 / x7 5-7 %; x8 -- 256 multiply-adds per input sample: arithmetic, not the LDS -- 9 % behind it and stays:
     // profiles/r05/shapes_interpolators.txt) and SP = 2 ... 5 with up to five outputs per m (profiles/r05/shapes_real_window.txt)
-    bool window = !data_complex && int4_shape(SP, UP);
+    bool window = !data_complex && UP <= 8 && int4_shape(SP, UP);
 #ifdef SFE_DIAG
     if (const char *e = getenv("SFE_RT_DMA_WINDOW")) window = window && SP <= atoi(e);      // the largest SP that takes this form (0: none)
 #endif
@@ -598,7 +671,11 @@ int launch_poly_rt_dma(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int d
     a.tiles = (unsigned)tiles;
     const dim3 grid((unsigned)tiles + (a.hist_out ? 1u : 0u), (unsigned)n_channels);
     const int per_thread = (a.tm + 255) / 256;
-    if (window) {
+    if (UP > 8) {
+        const dim3 block(256);
+        if (data_complex) hipLaunchKernelGGL((poly_rt_dma_many_kernel<true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((poly_rt_dma_many_kernel<false>), grid, block, lds, s, a);
+    } else if (window) {
         const int sh = (int)((((long long)a.e_max - (plan.Lp - 1)) % 4 + 4) % 4);
         switch (SP) {
         case 1: launch_int4<1>(UP, sh, grid, lds, s, a); break;
