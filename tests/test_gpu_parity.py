@@ -1030,6 +1030,45 @@ def test_general_rate_calls_larger_than_the_lds(api, L, orc, B, U, rate, n_taps,
                 assert synth.rel_rms(got, ref[: len(got)]) <= TOL, (B, U, rate, cplx)
 
 
+@pytest.mark.parametrize("U,step", [(9, 10), (24, 25), (10, 9), (32, 33), (16, 1), (32, 1), (12, 5), (64, 3), (9, 2)])
+@pytest.mark.parametrize("cplx", [True, False])
+def test_nine_to_sixty_four_outputs_per_period(api, L, orc, U, step, cplx):
+    """Round 5 (poly_rt_dma.hip: poly_rt_dma_many_kernel): near-unity rate matching (10/9, 25/24, 33/32) and strong interpolation (x16, x32) -- 9 to
+    64 outputs per period -- through the tiled form: the LDS-DMA tile, one m per thread, its phase sums eight at a time.  Within 1e-5 of the oracle
+    (libdsp/resample.cxx:100-114 at an integer step) and BIT-IDENTICAL to the generic one-output-per-thread kernel, which still serves a stream
+    off a 16-byte boundary (the same sums in the same order); two calls with carried state, three channels, an output off a 16-byte boundary."""
+    taps = synth.lowpass_taps(24 * U - 1, 0.9 * min(1.0 / U, 1.0 / step), gain=float(U))
+    rate = float(np.float32(step) / np.float32(U))
+    w = 2 if cplx else 1
+    n, nch = 3 * 4096 + 1235, 3
+    x = np.stack([synth.synth_f32(w * n, ch=130 + c) for c in range(nch)])
+    cap = n * U // step + 16
+    cap += (-cap) % 4
+
+    def run(offset_samples, stride, out_shift=0):
+        buf = np.zeros(w * (offset_samples + stride * nch), np.float32)
+        for c in range(nch):
+            buf[w * (offset_samples + stride * c): w * (offset_samples + stride * c) + w * n] = x[c]
+        d = api.DeviceArray.from_numpy(buf)
+        d_out = api.DeviceArray(out_shift + w * cap * nch)
+        r = api.Rs(taps, U, 4096, mode=L.RS_RESAMPLE, data_complex=cplx, n_channels=nch)
+        r.set_algo(L.RS_ALGO_DIRECT)
+        cut = 2 * 4096
+        k1 = r.process_stream(d.ptr + 4 * w * offset_samples, cut, d_out.ptr + 4 * out_shift, cap, rate, in_stride=stride, out_stride=cap)
+        k2 = r.process_stream(d.ptr + 4 * w * (offset_samples + cut), n - cut, d_out.ptr + 4 * (out_shift + w * k1), cap - k1, rate, in_stride=stride, out_stride=cap)
+        return k1 + k2, d_out.to_numpy()[out_shift:].reshape(nch, w * cap)[:, : w * (k1 + k2)]
+
+    al = (n + 3) // 4 * 4
+    k, y = run(0, al)
+    ku, yu = run(1, al + 1)
+    assert k == ku and np.array_equal(y.view(np.uint32), yu.view(np.uint32)), (U, step, cplx)
+    ko, yo = run(0, al, out_shift=w)
+    assert k == ko and np.array_equal(y.view(np.uint32), yo.view(np.uint32)), (U, step, cplx)
+    for part in range(w):
+        ref = orc.Resample(taps, U, 4096).stream(np.ascontiguousarray(x[nch - 1, part::w]), rate)[0]
+        assert len(ref) - k in (0, 1) and synth.rel_rms(y[nch - 1, part::w], ref[:k]) <= TOL, (U, step, cplx, part)
+
+
 # ----------------------------------------------------------------- edge cases / misuse
 def test_empty_and_tiny_inputs(api, L, orc):
     """n = 0 is a no-op; n < n_taps works and carries state; 1-tap filter is a gain."""
