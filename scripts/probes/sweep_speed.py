@@ -30,8 +30,8 @@ for (U, rate), plen, cplx in itertools.product(RATES, (8, 32, 127), (True, False
         y = api.DeviceArray(w * cap)
         r = api.Rs(taps, U, 4096, mode=lib.RS_RESAMPLE, data_complex=cplx)
         r.set_exact(os.environ.get("EXACT") == "1")          # EXACT=1: the bit-exact kernels
-        for _ in range(3):
-            k = r.process_stream(x, n, y, cap, rate)
+        for _ in range(int(os.environ.get("WARM", "12"))):      # (an integer-step stream cut into equal calls cycles through up to `step` phase offsets, each with a plan
+            k = r.process_stream(x, n, y, cap, rate)               # of its own built on first use -- ~1 ms of host work for a transform-domain plan: not what this sweep is after)
         v = []
         for _ in range(3):
             t.start()
