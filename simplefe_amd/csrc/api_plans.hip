@@ -71,16 +71,16 @@ const PolyTiledPlan *get_tiled_plan(PlanCache &cache, const std::vector<float> &
     pl.UP = f.UP;
     pl.Lp = f.Lp;
     pl.e_max = f.e_max;
-    // (round 5: 9 ... 64 outputs per period -- 10/9, 25/24, x32 -- have a tiled form too, poly_rt_dma.hip's poly_rt_dma_many_kernel; where its
+    // (round 5: 9 ... 256 outputs per period -- 10/9, 25/24, x32, 147/160 -- have a tiled form too, poly_rt_dma.hip's poly_rt_dma_many_kernel; where its
     // launcher declines -- exact mode, unaligned channels -- the caller runs the generic kernel)
-    const bool many = pl.UP > 8 && pl.UP <= 64 && pl.SP >= 1 && pl.SP <= 64 && pl.Lp > 0;
+    const bool many = pl.UP > 8 && pl.UP <= 256 && pl.SP >= 1 && pl.SP <= 256 && pl.Lp > 0;      // (147/160, 160/147: 44.1 <-> 48 kHz)
     if (!poly_tiled_supported(pl.SP, pl.UP, pl.Lp) && !many) {
         cache.plans[key] = pl;          // d_G == nullptr marks "unsupported"
         return nullptr;
     }
     hipError_t e = hipMalloc(&pl.d_G, f.G.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(pl.d_G, f.G.data(), f.G.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess && pl.UP <= 64) {
+    if (e == hipSuccess && pl.UP <= 256) {
         // the same taps transposed, [local time][phase] padded to whole groups of 8 phases (the runtime-shape kernels read a row per tap)
         pl.gt_pitch = (pl.UP + 7) / 8 * 8;
         std::vector<float> gt((size_t)pl.Lp * pl.gt_pitch, 0.0f);

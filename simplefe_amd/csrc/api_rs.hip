@@ -498,7 +498,7 @@ static int rs_process_stream_impl(sfe_rs_t h, const void *d_in, size_t n_in, siz
 #endif
             if (try_dma) rc = launch_poly_rt_dma(*pl, ta, r->data_complex, r->in_u8, r->n_channels, s);
             if (rc == SFE_ESTATE && pl->UP <= 8) rc = launch_poly_tiled(*pl, ta, r->data_complex, r->exact_stream, r->in_u8, r->n_channels, s);
-            if (rc == SFE_ESTATE && pl->UP > 8) {            // 9 ... 64 outputs per period and the tiled form declined: the generic kernel
+            if (rc == SFE_ESTATE && pl->UP > 8) {            // 9 ... 256 outputs per period and the tiled form declined: the generic kernel
                 if (r->in_u8) {
                     r->u8_refused = true;
                     set_error("rs_process_stream: u8 input needs a tiled kernel for this rate/tap shape");

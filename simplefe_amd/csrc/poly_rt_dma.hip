@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void poly_rt_dma_kernel(PolyTiledArgs a)
     }
 }
 
-// 9 ... 64 outputs per period (10/9, 16/15, 25/24, x16, x32: near-unity rate matching and strong interpolation; until round 5 these ran the generic
+// 9 ... 256 outputs per period (10/9, 16/15, 25/24, 147/160, x16, x32: near-unity rate matching and strong interpolation; until round 5 these ran the generic
 // one-output-per-thread kernel at 0.05-0.3 of the roofline): the same tile, the same fetch; a thread takes one m and runs its UP phase sums EIGHT at
 // a time -- one sample read from the LDS feeds eight multiply-adds, the eight taps of a (local time, group) come as one scalar load from the
 // row-padded Gt (a.gt_pitch floats per local time) -- re-reading its Lp samples once per group.  Accumulation order per output: tap index
@@ -339,12 +339,17 @@ __global__ __launch_bounds__(256) void poly_rt_dma_many_kernel(PolyTiledArgs a)
     const unsigned sh = fetch_tile<CPLX>(a, ch, hist, X, smem, n_org, SP * (unsigned)TMr + (unsigned)a.Lp, tid);
     __syncthreads();
     const __attribute__((address_space(4))) float *gt = (const __attribute__((address_space(4))) float *)a.Gt;
-#pragma unroll 1
-    for (int mi = (int)tid; mi < TMr; mi += 256) {
+    // a tile of fewer than 256 m (a long input step): the threads beyond the m take the SAME m's later groups of
+    // phases -- thread = (m, group selector), consecutive lanes consecutive m
+    // (TMr: 64, 128 or 256 -- launcher -- so that a wave's lanes share their group selector: the taps stay SCALAR loads; per-lane groups made them
+    // vector loads and cost this kernel half its speed)
+    const int gsel = __builtin_amdgcn_readfirstlane((int)tid / TMr), gstep = 8 * (256 / TMr);
+    {
+        const int mi = (int)tid & (TMr - 1);
         const unsigned b = sh + SP * (unsigned)mi;
         const long long k = (long long)UP * (m0 + mi);
 #pragma unroll 1
-        for (int g0 = 0; g0 < UP; g0 += 8) {
+        for (int g0 = 8 * gsel; g0 < UP; g0 += gstep) {
             T acc[8];
 #pragma unroll
             for (int r = 0; r < 8; r++) acc[r] = T{};
@@ -610,14 +615,14 @@ int launch_poly_rt_dma(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int d
         if (atoi(e)) sp_min = 1;
 #endif
     if (UP > 8) {
-        // 9 ... 64 outputs per period: poly_rt_dma_many_kernel -- one sample per LDS read at a lane stride of SP samples, so only where that stride
+        // 9 ... 256 outputs per period: poly_rt_dma_many_kernel -- one sample per LDS read at a lane stride of SP samples, so only where that stride
         // meets a bank at most twice (16/15, SP = 16: 16 lanes to a bank, 3.57 ms against the generic kernel's 2.14; profiles/r05/shapes_generic_kernel.txt)
         int g = SP, b = data_complex ? 32 : 64;
         while (b) { const int t = g % b; g = b; b = t; }
         if (g > 2) return SFE_ESTATE;
         sp_min = 1;
     }
-    if (SP < sp_min || SP > 64 || UP < 1 || UP > 64 || plan.Lp <= 0 || !plan.d_Gt) return SFE_ESTATE;
+    if (SP < sp_min || SP > (UP > 8 ? 256 : 64) || UP < 1 || UP > 256 || plan.Lp <= 0 || !plan.d_Gt) return SFE_ESTATE;
     // 16-byte lanes: every channel's first sample on a 16-byte boundary (u8 input: 8 complex or 16 real samples per lane)
     const int in_a16 = in_u8 ? (data_complex ? 8 : 16) : a16;
     if ((reinterpret_cast<uintptr_t>(a0.in) & 15u) || (n_channels > 1 && (a0.in_stride % in_a16))) return SFE_ESTATE;
@@ -633,7 +638,7 @@ int launch_poly_rt_dma(const PolyTiledPlan &plan, const PolyTiledArgs &a0, int d
     a.UP = UP;
     a.tm = UP > 8 ? 256 : rt_dma_tile_m(SP, UP, data_complex ? 4096 : 8192);       // (many outputs per m: one m per thread)
     a.gt_pitch = plan.gt_pitch;
-    while (UP > 8 && a.tm > 64 && ((size_t)SP * a.tm + plan.Lp + a16) * esz > 48 * 1024) a.tm /= 2;
+    while (UP > 8 && a.tm > 64 && ((size_t)SP * a.tm + plan.Lp + a16) * esz > 48 * 1024) a.tm /= 2;       // (64, 128 or 256: the kernel deals threads as (m, group), whole waves per group)
     size_t lds = ((((size_t)SP * a.tm + plan.Lp + a16) * esz + 1023) >> 10) << 10;        // whole 1 KiB pieces
     a.y_off = 0;
     if (lds > 60 * 1024) return SFE_ESTATE;

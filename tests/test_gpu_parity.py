@@ -1030,7 +1030,7 @@ def test_general_rate_calls_larger_than_the_lds(api, L, orc, B, U, rate, n_taps,
                 assert synth.rel_rms(got, ref[: len(got)]) <= TOL, (B, U, rate, cplx)
 
 
-@pytest.mark.parametrize("U,step", [(9, 10), (24, 25), (10, 9), (32, 33), (16, 1), (32, 1), (12, 5), (64, 3), (9, 2)])
+@pytest.mark.parametrize("U,step", [(9, 10), (24, 25), (10, 9), (32, 33), (16, 1), (32, 1), (12, 5), (64, 3), (9, 2), (160, 147), (147, 160), (256, 255), (100, 3)])
 @pytest.mark.parametrize("cplx", [True, False])
 def test_nine_to_sixty_four_outputs_per_period(api, L, orc, U, step, cplx):
     """Round 5 (poly_rt_dma.hip: poly_rt_dma_many_kernel): near-unity rate matching (10/9, 25/24, 33/32) and strong interpolation (x16, x32) -- 9 to
